@@ -1,0 +1,271 @@
+# coding=utf-8
+"""ctypes binding of libdccf_hip.so (include/dccf_hip.h).  No torch types cross the C ABI: wrappers pass
+``tensor.data_ptr()``, sizes and the current HIP stream.  There is no CPU fallback: if the library is missing or a
+call fails, a RuntimeError is raised."""
+import ctypes as C
+import os
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'lib', 'libdccf_hip.so')
+
+EXPORTS = ['dccf_ctx_create', 'dccf_ctx_destroy', 'dccf_ctx_reserve', 'dccf_last_error', 'dccf_abi_version',
+           'dccf_predict', 'dccf_train_fwdbwd', 'dccf_dense_opt_step', 'dccf_sumsq', 'mf_predict', 'mf_train_fwdbwd',
+           'mf_predict_full', 'dccf_sample_train_negatives', 'dccf_debug_candidates', 'dccf_debug_noise',
+           'dccf_debug_keep', 'dccf_debug_workspace']
+
+OPT_KIND = {'gd': 0, 'adagrad': 1, 'adam': 2}
+MF_KIND = {'RecModel': 0, 'BiasedMF': 1, 'IPSBiasedMF': 2}
+
+_f = C.c_void_p   # device pointers travel as plain addresses
+
+
+class ModelT(C.Structure):
+    _fields_ = [('user_num', C.c_int64), ('item_num', C.c_int64), ('D', C.c_int32), ('F', C.c_int32),
+                ('S', C.c_int32), ('A', C.c_int32), ('std', C.c_float), ('reserved', C.c_float),
+                ('U', _f), ('V', _f), ('W', _f), ('b', _f), ('feat', _f), ('expo', _f),
+                ('ipsP', _f), ('ipsQ', _f), ('ipsBu', _f), ('ipsBi', _f), ('ipsProp', _f),
+                ('ipsB0', C.c_float), ('ipsM', C.c_float), ('ipsD', C.c_int32), ('reserved2', C.c_int32)]
+
+
+class RandT(C.Structure):
+    _fields_ = [('mode', C.c_int32), ('reserved', C.c_int32), ('sample_item', _f), ('noise', _f), ('keep', _f),
+                ('seed', C.c_uint64), ('step', C.c_uint64)]
+
+
+class GradsT(C.Structure):
+    _fields_ = [('gU', _f), ('gV', _f), ('gW', _f), ('gb', _f)]
+
+
+class MFModelT(C.Structure):
+    _fields_ = [('user_num', C.c_int64), ('item_num', C.c_int64), ('D', C.c_int32), ('kind', C.c_int32),
+                ('P', _f), ('Q', _f), ('bu', _f), ('bi', _f), ('b0', _f), ('prop', _f), ('M', C.c_float),
+                ('reserved', C.c_float)]
+
+
+class MFGradsT(C.Structure):
+    _fields_ = [('gP', _f), ('gQ', _f), ('gbu', _f), ('gbi', _f), ('gb0', _f)]
+
+
+_lib = None
+
+
+def load():
+    """Loads the shared library (built in-tree by dccf_amd.build).  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError('libdccf_hip.so is missing (%s): run `python -m dccf_amd.build` — there is no CPU fallback'
+                           % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.dccf_last_error.restype = C.c_char_p
+    lib.dccf_abi_version.restype = C.c_int
+    i64, i32, u64, f32, vp = C.c_int64, C.c_int32, C.c_uint64, C.c_float, C.c_void_p
+    sig = {
+        'dccf_ctx_create': [C.POINTER(vp), C.c_int],
+        'dccf_ctx_destroy': [vp],
+        'dccf_ctx_reserve': [vp, i64, i32, i32, i32, i32],
+        'dccf_predict': [vp, C.POINTER(ModelT), C.POINTER(RandT), vp, i64, f32, vp, vp],
+        'dccf_train_fwdbwd': [vp, C.POINTER(ModelT), C.POINTER(RandT), vp, vp, i64, i32, f32, C.POINTER(GradsT), vp, vp, vp],
+        'dccf_dense_opt_step': [i32, vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, i32, vp],
+        'dccf_sumsq': [vp, i64, vp, vp],
+        'mf_predict': [C.POINTER(MFModelT), vp, i64, vp, vp],
+        'mf_train_fwdbwd': [vp, C.POINTER(MFModelT), vp, vp, i64, i32, C.POINTER(MFGradsT), vp, vp, vp],
+        'mf_predict_full': [C.POINTER(MFModelT), vp, vp],
+        'dccf_sample_train_negatives': [vp, vp, vp, vp, i64, i64, u64, u64, vp, vp],
+        'dccf_debug_candidates': [i64, i32, i64, u64, u64, vp, vp],
+        'dccf_debug_noise': [i64, i32, f32, u64, u64, vp, vp],
+        'dccf_debug_keep': [i64, i32, f32, u64, u64, vp, vp],
+        'dccf_debug_workspace': [vp, i64, i32, i32, i32, i32, i32, vp, C.POINTER(C.c_int64), vp],
+    }
+    for name, args in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != 0:
+        raise RuntimeError('libdccf_hip: %s (code %d)' % (load().dccf_last_error().decode(), code))
+
+
+def ptr(t, dtype=None):
+    """Device address of a contiguous CUDA(HIP) tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('expected a tensor in HBM (cuda device), got %s' % t.device)
+    if not t.is_contiguous():
+        raise RuntimeError('expected a contiguous tensor')
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError('expected dtype %s, got %s' % (dtype, t.dtype))
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Context(object):
+    """Opaque workspace owner (dccf_ctx)."""
+
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        check(load().dccf_ctx_create(C.byref(self.h), int(device)))
+
+    def reserve(self, max_rows, D, F, S, A):
+        check(load().dccf_ctx_reserve(self.h, int(max_rows), int(D), int(F), int(S), int(A)))
+
+    def __del__(self):
+        try:
+            if self.h:
+                load().dccf_ctx_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def model_struct(U, V, W, b, feat, expo, S, A, std, ips=None):
+    m = ModelT()
+    m.user_num, m.D = U.shape
+    m.item_num = V.shape[0]
+    m.F = feat.shape[1]
+    m.S, m.A, m.std = int(S), int(A), float(std)
+    f32 = torch.float32
+    m.U, m.V, m.W, m.b, m.feat = ptr(U, f32), ptr(V, f32), ptr(W, f32), ptr(b, f32), ptr(feat, f32)
+    m.expo = ptr(expo, f32)
+    if tuple(W.shape) != (m.D, m.D + m.F) or V.shape[1] != m.D or feat.shape[0] != m.item_num:
+        raise RuntimeError('inconsistent parameter shapes')
+    if expo is not None and tuple(expo.shape) != (m.user_num, m.item_num):
+        raise RuntimeError('expo must be [user_num, item_num]')
+    if ips is not None:
+        m.ipsP, m.ipsQ = ptr(ips['P'], f32), ptr(ips['Q'], f32)
+        m.ipsBu, m.ipsBi, m.ipsProp = ptr(ips['bu'], f32), ptr(ips['bi'], f32), ptr(ips['prop'], f32)
+        m.ipsB0, m.ipsM, m.ipsD = float(ips['b0']), float(ips['M']), int(ips['P'].shape[1])
+    m._refs = (U, V, W, b, feat, expo, ips)   # the struct holds raw addresses: keep the tensors alive with it
+    return m
+
+
+def rand_struct(sample_item=None, noise=None, keep=None, seed=None, step=0):
+    r = RandT()
+    if seed is not None:
+        r.mode, r.seed, r.step = 1, int(seed) & 0xFFFFFFFFFFFFFFFF, int(step)
+    else:
+        r.mode = 0
+        r.sample_item = ptr(sample_item, torch.int64)
+        r.noise = ptr(noise, torch.float32)
+        r.keep = ptr(keep, torch.uint8)
+        r._refs = (sample_item, noise, keep)
+    return r
+
+
+def dccf_predict(ctx, m, r, X, dropout, out=None):
+    N = X.shape[0]
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=X.device)
+    check(load().dccf_predict(ctx.h, C.byref(m), C.byref(r), ptr(X, torch.int64), N, float(dropout), ptr(out), stream()))
+    return out
+
+
+def dccf_train_fwdbwd(ctx, m, r, X, Y, rank, dropout, gU, gV, gW, gb, pred=None, loss=None):
+    N = X.shape[0]
+    if pred is None:
+        pred = torch.empty(N, dtype=torch.float32, device=X.device)
+    if loss is None:
+        loss = torch.empty(1, dtype=torch.float32, device=X.device)
+    g = GradsT(ptr(gU), ptr(gV), ptr(gW), ptr(gb))
+    check(load().dccf_train_fwdbwd(ctx.h, C.byref(m), C.byref(r), ptr(X, torch.int64), ptr(Y), N, int(rank),
+                                   float(dropout), C.byref(g), ptr(pred), ptr(loss), stream()))
+    return pred, loss
+
+
+def dense_opt_step(kind, p, g, s1, s2, lr, wd, l2, clip, step, zero_grad=True):
+    check(load().dccf_dense_opt_step(OPT_KIND[kind.lower()], ptr(p, torch.float32), ptr(g, torch.float32), ptr(s1),
+                                     ptr(s2), p.numel(), float(lr), float(wd), float(l2), float(clip), int(step),
+                                     1 if zero_grad else 0, stream()))
+
+
+def sumsq(p):
+    out = torch.zeros(1, dtype=torch.float32, device=p.device)
+    check(load().dccf_sumsq(ptr(p, torch.float32), p.numel(), ptr(out), stream()))
+    return out
+
+
+def mf_struct(kind, P, Q, bu=None, bi=None, b0=None, prop=None, M=0.1):
+    m = MFModelT()
+    m.user_num, m.D = P.shape
+    m.item_num = Q.shape[0]
+    m.kind = MF_KIND[kind]
+    f32 = torch.float32
+    m.P, m.Q, m.bu, m.bi, m.b0, m.prop = ptr(P, f32), ptr(Q, f32), ptr(bu, f32), ptr(bi, f32), ptr(b0, f32), ptr(prop, f32)
+    m.M = float(M)
+    m._refs = (P, Q, bu, bi, b0, prop)
+    return m
+
+
+def mf_predict(m, X, out=None):
+    N = X.shape[0]
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=X.device)
+    check(load().mf_predict(C.byref(m), ptr(X, torch.int64), N, ptr(out), stream()))
+    return out
+
+
+def mf_train_fwdbwd(ctx, m, X, Y, rank, gP, gQ, gbu=None, gbi=None, gb0=None, pred=None, loss=None):
+    N = X.shape[0]
+    if pred is None:
+        pred = torch.empty(N, dtype=torch.float32, device=X.device)
+    if loss is None:
+        loss = torch.empty(1, dtype=torch.float32, device=X.device)
+    g = MFGradsT(ptr(gP), ptr(gQ), ptr(gbu), ptr(gbi), ptr(gb0))
+    check(load().mf_train_fwdbwd(ctx.h if ctx is not None else None, C.byref(m), ptr(X, torch.int64), ptr(Y), N,
+                                 int(rank), C.byref(g), ptr(pred), ptr(loss), stream()))
+    return pred, loss
+
+
+def mf_predict_full(m, out=None, device=None):
+    if out is None:
+        out = torch.empty((m.user_num, m.item_num), dtype=torch.float32, device=device)
+    check(load().mf_predict_full(C.byref(m), ptr(out, torch.float32), stream()))
+    return out
+
+
+def sample_train_negatives(rows_indptr, rows, hist_indptr, hist_items, user_num, item_num, seed, epoch, out=None):
+    if out is None:
+        out = torch.empty(rows.shape[0], dtype=torch.int64, device=rows.device)
+    i64 = torch.int64
+    check(load().dccf_sample_train_negatives(ptr(rows_indptr, i64), ptr(rows, i64), ptr(hist_indptr, i64),
+                                             ptr(hist_items, i64), int(user_num), int(item_num),
+                                             int(seed) & 0xFFFFFFFFFFFFFFFF, int(epoch), ptr(out, i64), stream()))
+    return out
+
+
+def debug_candidates(N, S, item_num, seed, step, device):
+    out = torch.empty((N, S), dtype=torch.int64, device=device)
+    check(load().dccf_debug_candidates(N, S, item_num, int(seed), int(step), ptr(out), stream()))
+    return out
+
+
+def debug_noise(L, F, std, seed, step, device):
+    out = torch.zeros((L, F), dtype=torch.float32, device=device)
+    check(load().dccf_debug_noise(L, F, float(std), int(seed), int(step), ptr(out), stream()))
+    return out
+
+
+def debug_keep(L, D, dropout, seed, step, device):
+    out = torch.empty((L, D), dtype=torch.uint8, device=device)
+    check(load().dccf_debug_keep(L, D, float(dropout), int(seed), int(step), ptr(out), stream()))
+    return out
+
+
+def debug_workspace(ctx, N, D, F, S, A, which, device):
+    """Workspace array `which` of the last call (tests only): 0 cand 1 WT 2 base 3 h/dz 4 m 5 dmns 6 dzn."""
+    info = (C.c_int64 * 4)()
+    check(load().dccf_debug_workspace(ctx.h, N, D, F, S, A, which, None, info, stream()))
+    out = torch.empty(info[2], dtype=torch.int32 if which == 0 else torch.float32, device=device)
+    check(load().dccf_debug_workspace(ctx.h, N, D, F, S, A, which, ptr(out), info, stream()))
+    return out, int(info[0]), int(info[1])

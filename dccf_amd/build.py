@@ -1,0 +1,49 @@
+# coding=utf-8
+"""Builds libdccf_hip.so (gfx950) in-tree with hipcc.  `python -m dccf_amd.build` or __graft_entry__.build()."""
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, 'lib', 'libdccf_hip.so')
+SRCS = sorted(glob.glob(os.path.join(HERE, 'csrc', '*.hip')))
+DEPS = SRCS + sorted(glob.glob(os.path.join(HERE, 'csrc', '*.hpp'))) + [os.path.join(os.path.dirname(HERE), 'include', 'dccf_hip.h')]
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(s) > t for s in DEPS)
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return LIB
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    # The host process is PyTorch-ROCm, whose wheel ships its OWN HIP runtime (torch/lib/libamdhip64.so).  Two HIP
+    # runtimes in one process abort at the first launch, so the library is linked against torch's copy (same soname
+    # -> the loader reuses the one torch already mapped) instead of /opt/rocm/lib/libamdhip64.so.7.
+    import torch
+    tlib = os.path.join(os.path.dirname(torch.__file__), 'lib')
+    objs = []
+    for src in SRCS:
+        obj = os.path.join(os.path.dirname(LIB), os.path.basename(src).replace('.hip', '.o'))
+        c = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-result',
+             '-c', src, '-o', obj]
+        if verbose:
+            print(' '.join(c))
+        subprocess.check_call(c)
+        objs.append(obj)
+    cmd = [os.environ.get('CXX', 'g++'), '-shared', '-o', LIB] + objs + \
+          ['-L' + tlib, '-lamdhip64', '-Wl,-rpath,' + tlib, '-Wl,--no-undefined']
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

@@ -1,0 +1,120 @@
+// common.hpp — shared device helpers for libdccf_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/dccf_hip.h"
+
+#define DCCF_ABI_VERSION 1
+
+// ---------------------------------------------------------------------------------------------- errors
+extern thread_local char g_dccf_err[512];
+static inline int dccf_fail(int code, const char* msg) {
+  snprintf(g_dccf_err, sizeof(g_dccf_err), "%s", msg);
+  return code;
+}
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) {                                                                    \
+      snprintf(g_dccf_err, sizeof(g_dccf_err), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+               __FILE__, __LINE__);                                                            \
+      return (int)_e;                                                                          \
+    }                                                                                          \
+  } while (0)
+#define ARG_CHECK(cond, msg) \
+  do {                       \
+    if (!(cond)) return dccf_fail(-1, "argument error: " msg); \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------- context
+struct dccf_ctx {
+  int device;
+  char* ws;         // one grow-only slab
+  size_t ws_bytes;
+};
+int dccf_ws_ensure(dccf_ctx* ctx, size_t bytes);
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---------------------------------------------------------------------------------------------- Philox4x32-10
+// Counter-based RNG of the fused random draws (oracle/philox.py restates it bit for bit).
+#define PHILOX_M0 0xD2511F53u
+#define PHILOX_M1 0xCD9E8D57u
+#define PHILOX_W0 0x9E3779B9u
+#define PHILOX_W1 0xBB67AE85u
+#define STREAM_CAND 1u
+#define STREAM_NOISE 2u
+#define STREAM_DROP 3u
+#define STREAM_NEG 4u
+
+struct u32x4 {
+  uint32_t x, y, z, w;
+};
+
+__device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                               uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)PHILOX_M0 * c0;
+    const uint64_t p1 = (uint64_t)PHILOX_M1 * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1;
+    c3 = (uint32_t)p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += PHILOX_W0;
+    k1 += PHILOX_W1;
+  }
+  return u32x4{c0, c1, c2, c3};
+}
+
+struct rng_key {
+  uint32_t k0, k1, s0, s1;  // key words, step words
+};
+static inline rng_key make_key(uint64_t seed, uint32_t stream, uint64_t step) {
+  rng_key k;
+  k.k0 = (uint32_t)seed;
+  k.k1 = (uint32_t)(seed >> 32) ^ stream;
+  k.s0 = (uint32_t)step;
+  k.s1 = (uint32_t)(step >> 32);
+  return k;
+}
+
+// 23-bit uniform strictly inside (0,1), exact in fp32.
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 9) + 0.5f) * 0x1p-23f; }
+
+// Box-Muller on the hardware transcendentals: v_log_f32 is log2, v_sin/v_cos take revolutions (sin(2*pi*x)).
+// nscale = -2 * ln(2) * std^2, so r = std * sqrt(-2 ln u1).
+__device__ __forceinline__ void box_muller(uint32_t xa, uint32_t xb, float nscale, float& z0, float& z1) {
+  const float u1 = u01(xa), u2 = u01(xb);
+  const float r = __builtin_amdgcn_sqrtf(nscale * __builtin_amdgcn_logf(u1));
+  z0 = r * __builtin_amdgcn_cosf(u2);
+  z1 = r * __builtin_amdgcn_sinf(u2);
+}
+
+// the 4 normals of noise words (l, c1): f = 128*(c1/32) + (c1%32) + 32*o, o = 0..3
+__device__ __forceinline__ void noise4(uint32_t l, uint32_t c1, const rng_key& k, float nscale, float out[4]) {
+  const u32x4 r = philox4x32_10(l, c1, k.s0, k.s1, k.k0, k.k1);
+  box_muller(r.x, r.y, nscale, out[0], out[1]);
+  box_muller(r.z, r.w, nscale, out[2], out[3]);
+}
+
+__device__ __forceinline__ uint32_t pick4(const u32x4& r, int i) {
+  return i == 0 ? r.x : (i == 1 ? r.y : (i == 2 ? r.z : r.w));
+}
+
+static inline uint32_t drop_threshold(float p) {
+  double t = (double)p * 4294967296.0;
+  if (t < 0) t = 0;
+  if (t > 4294967295.0) t = 4294967295.0;
+  return (uint32_t)t;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

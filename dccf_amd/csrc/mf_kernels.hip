@@ -1,0 +1,348 @@
+// mf_kernels.hip — RecModel / BiasedMF / IPSBiasedMF: pairwise predict, fused forward+BPR+backward with LDS-staged
+// duplicate-row reduction, the full U x I exposure matrix (fp32 MFMA + bias/propensity epilogue), and the fused
+// on-device training-negative sampler.
+//
+// Reference: src/models/RecModel.py:38-48, src/models/BiasedMF.py:17-33, src/models/IPSBiasedMF.py:37-57,
+// src/models/BaseModel.py:203-219 (BPR / MSE), README.md:28-30 (full matrix), and
+// src/data_processor/DataProcessor.py:446-524 (negatives).
+//
+// The pairwise kernels are gather / scatter-add kernels — HBM-bound byte movers: one embedding row is one
+// wave-instruction (D=64 -> 256 B), rows are staged in LDS, duplicate (table,row) targets inside a block's window are
+// chained and summed on chip so that each distinct row leaves through ONE 256-B float-atomic row add.
+#include "common.hpp"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float mf_score(const mf_model_t& M, int64_t u, int64_t i, float dot, float& inv_prop) {
+  float p = dot;
+  inv_prop = 1.f;
+  if (M.kind >= 1) p = p + M.bu[u] + M.bi[i] + M.b0[0];
+  if (M.kind == 2) {
+    const float pr = fmaxf(M.prop[i], M.M);
+    p = p / pr;
+    inv_prop = pr;   // NOTE: holds the clipped propensity; gradients divide by it
+  }
+  return p;
+}
+
+// ------------------------------------------------------------------------------------------------ predict
+__global__ __launch_bounds__(256) void k_mf_predict(mf_model_t M, const int64_t* __restrict__ X, int64_t N,
+                                                    float* __restrict__ pred) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t n = wave; n < N; n += nw) {
+    const int64_t u = X[2 * n], i = X[2 * n + 1];
+    float acc = 0.f;
+    for (int d = lane; d < M.D; d += 64) acc = fmaf(M.P[u * M.D + d], M.Q[i * M.D + d], acc);
+    acc = wave_sum(acc);
+    float ip;
+    if (lane == 0) pred[n] = mf_score(M, u, i, acc, ip);
+  }
+}
+
+extern "C" int mf_predict(const mf_model_t* M, const int64_t* X, int64_t N, float* prediction, void* stream) {
+  ARG_CHECK(M && X && prediction && N >= 0, "NULL argument");
+  ARG_CHECK(M->P && M->Q && M->D >= 1 && M->kind >= 0 && M->kind <= 2, "bad model");
+  ARG_CHECK(M->kind == 0 || (M->bu && M->bi && M->b0), "bias pointers missing");
+  ARG_CHECK(M->kind != 2 || M->prop, "propensity missing");
+  if (N == 0) return 0;
+  const int grid = (int)min((int64_t)2048, (N + 3) / 4);
+  hipLaunchKernelGGL(k_mf_predict, dim3(grid), dim3(256), 0, (hipStream_t)stream, *M, X, N, prediction);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ train fwd+bwd
+// A block walks chunks of CH = 64 rows of X.  rank 1: a chunk is 32 pairs = rows [k0,k0+32) and [B+k0, B+k0+32).
+#define MF_CH 64
+__global__ __launch_bounds__(256) void k_mf_train(mf_model_t M, mf_grads_t G, const int64_t* __restrict__ X,
+                                                  const float* __restrict__ Y, int64_t N, int rank,
+                                                  float* __restrict__ pred, float* __restrict__ loss) {
+  extern __shared__ float sm[];
+  const int D = M.D;
+  float* Pr = sm;                         // [CH][D]  user rows
+  float* Qr = Pr + MF_CH * D;             // [CH][D]  item rows
+  float* gs = Qr + MF_CH * D;             // [CH]     d loss / d (raw score)  (after the propensity division)
+  float* pl = gs + MF_CH;                 // [CH]     predictions
+  int64_t* uid = (int64_t*)(pl + MF_CH);  // [CH]
+  int64_t* iid = uid + MF_CH;             // [CH]
+  int64_t* rown = iid + MF_CH;            // [CH]  global row of each chunk slot (-1 = empty)
+  float* ipr = (float*)(rown + MF_CH);    // [CH]  clipped propensity
+  int* nxtU = (int*)(ipr + MF_CH);        // [CH]  chain of later slots with the same user, -1 end; -2 = not a head
+  int* nxtI = nxtU + MF_CH;               // [CH]
+  int* headU = nxtI + MF_CH;              // [CH]  1 if first occurrence
+  int* headI = headU + MF_CH;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t B = N / 2;
+  const int64_t units = rank == 1 ? B : N;
+  const int per = rank == 1 ? MF_CH / 2 : MF_CH;
+  const int64_t nchunks = (units + per - 1) / per;
+  float lsum = 0.f;
+  for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const int64_t k0 = c * per;
+    if (threadIdx.x < MF_CH) {
+      const int s = threadIdx.x;
+      int64_t n = -1;
+      if (rank == 1) {
+        const int64_t k = k0 + (s % per);
+        if (k < B) n = s < per ? k : B + k;
+      } else if (k0 + s < N) {
+        n = k0 + s;
+      }
+      rown[s] = n;
+      uid[s] = n >= 0 ? X[2 * n] : -1;
+      iid[s] = n >= 0 ? X[2 * n + 1] : -1;
+    }
+    __syncthreads();
+    // phase 0: gather rows, scores
+    for (int s = wave; s < MF_CH; s += 4) {
+      if (rown[s] < 0) continue;
+      const int64_t u = uid[s], i = iid[s];
+      float acc = 0.f;
+      for (int d = lane; d < D; d += 64) {
+        const float pv = M.P[u * D + d], qv = M.Q[i * D + d];
+        Pr[s * D + d] = pv;
+        Qr[s * D + d] = qv;
+        acc = fmaf(pv, qv, acc);
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) {
+        float ip;
+        const float p = mf_score(M, u, i, acc, ip);
+        pl[s] = p;
+        ipr[s] = ip;
+        pred[rown[s]] = p;
+      }
+    }
+    __syncthreads();
+    // phase 1: loss gradient per slot + duplicate chains (slot order; users vs users, items vs items)
+    if (threadIdx.x < MF_CH) {
+      const int s = threadIdx.x;
+      float g = 0.f;
+      if (rown[s] >= 0) {
+        if (rank == 1) {
+          const int j = s % per;
+          const float d = pl[j] - pl[per + j];
+          const float sg = 1.f / (1.f + expf(-d));
+          const float gp = -(1.f - sg);
+          g = s < per ? gp : -gp;
+          if (s < per) lsum += -logf(sg);
+        } else {
+          const float diff = pl[s] - Y[rown[s]];
+          g = 2.f * diff / (float)N;
+          lsum += diff * diff / (float)N;
+        }
+        g = g / ipr[s];
+      }
+      gs[s] = g;
+      int hu = 1, hi = 1, nu = -1, ni = -1;
+      if (rown[s] < 0) { hu = 0; hi = 0; }
+      else {
+        for (int j = 0; j < s; ++j) {
+          if (uid[j] == uid[s]) hu = 0;
+          if (iid[j] == iid[s]) hi = 0;
+        }
+        for (int j = MF_CH - 1; j > s; --j) {
+          if (uid[j] == uid[s]) nu = j;
+          if (iid[j] == iid[s]) ni = j;
+        }
+      }
+      headU[s] = hu; headI[s] = hi; nxtU[s] = nu; nxtI[s] = ni;
+    }
+    __syncthreads();
+    // phase 2: one atomic row add per distinct user / item of the chunk
+    for (int s = wave; s < MF_CH; s += 4) {
+      if (rown[s] < 0) continue;
+      if (headU[s]) {
+        for (int d = lane; d < D; d += 64) {
+          float v = 0.f;
+          for (int j = s; j >= 0; j = nxtU[j]) v = fmaf(gs[j], Qr[j * D + d], v);
+          atomicAdd(&G.gP[uid[s] * D + d], v);
+        }
+        if (M.kind >= 1 && lane == 0) {
+          float v = 0.f;
+          for (int j = s; j >= 0; j = nxtU[j]) v += gs[j];
+          atomicAdd(&G.gbu[uid[s]], v);
+        }
+      }
+      if (headI[s]) {
+        for (int d = lane; d < D; d += 64) {
+          float v = 0.f;
+          for (int j = s; j >= 0; j = nxtI[j]) v = fmaf(gs[j], Pr[j * D + d], v);
+          atomicAdd(&G.gQ[iid[s] * D + d], v);
+        }
+        if (M.kind >= 1 && lane == 0) {
+          float v = 0.f;
+          for (int j = s; j >= 0; j = nxtI[j]) v += gs[j];
+          atomicAdd(&G.gbi[iid[s]], v);
+        }
+      }
+    }
+    if (M.kind >= 1 && threadIdx.x == 0) {
+      float v = 0.f;
+      for (int s = 0; s < MF_CH; ++s) v += gs[s];
+      atomicAdd(G.gb0, v);
+    }
+    __syncthreads();
+  }
+  __shared__ float red[4];
+  lsum = wave_sum(lsum);
+  if (lane == 0) red[wave] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, red[0] + red[1] + red[2] + red[3]);
+}
+
+extern "C" int mf_train_fwdbwd(dccf_ctx* ctx, const mf_model_t* M, const int64_t* X, const float* Y, int64_t N,
+                               int32_t rank, const mf_grads_t* G, float* prediction, float* loss, void* stream) {
+  (void)ctx;
+  ARG_CHECK(M && X && G && prediction && loss && N >= 0, "NULL argument");
+  ARG_CHECK(M->P && M->Q && M->D >= 1 && M->D <= 256 && M->kind >= 0 && M->kind <= 2, "bad model");
+  ARG_CHECK(G->gP && G->gQ, "NULL gradient pointer");
+  ARG_CHECK(M->kind == 0 || (M->bu && M->bi && M->b0 && G->gbu && G->gbi && G->gb0), "bias pointers missing");
+  ARG_CHECK(M->kind != 2 || M->prop, "propensity missing");
+  ARG_CHECK(rank == 0 || rank == 1, "rank must be 0 or 1");
+  if (rank == 1) ARG_CHECK(N % 2 == 0, "rank==1 needs [positives ; negatives] (even N)");
+  if (rank == 0) ARG_CHECK(Y != nullptr, "rank==0 needs Y");
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), st));
+  if (N == 0) return 0;
+  const int per = rank == 1 ? MF_CH / 2 : MF_CH;
+  const int64_t units = rank == 1 ? N / 2 : N;
+  const int64_t nchunks = (units + per - 1) / per;
+  const size_t smem = (size_t)2 * MF_CH * M->D * 4 + MF_CH * (4 + 4 + 8 + 8 + 8 + 4 + 4 + 4 + 4 + 4);
+  const int grid = (int)min((int64_t)2048, nchunks);
+  hipLaunchKernelGGL(k_mf_train, dim3(grid), dim3(256), smem, st, *M, *G, X, Y, N, rank, prediction, loss);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ full U x I matrix
+// out[u][i] = (P[u].Q[i] + bu[u] + bi[i] + b0) / max(prop[i], M): 128 x 128 tile per block, 4 waves x (64 x 64),
+// fp32 MFMA 32x32x2 over K = D, operands staged in LDS with a one-float row pad (conflict-free ds_read_b32).
+// Output-write bound (U*I*4 bytes) for D <= 64.
+#define FT 128
+__global__ __launch_bounds__(256) void k_mf_full(mf_model_t M, float* __restrict__ out) {
+  extern __shared__ float sm[];
+  const int D = M.D, LD = D + 1;
+  float* Ps = sm;              // [FT][LD]
+  float* Qs = Ps + FT * LD;    // [FT][LD]
+  const int64_t gx = (M.item_num + FT - 1) / FT;
+  const int64_t u0 = ((int64_t)blockIdx.x / gx) * FT, i0 = ((int64_t)blockIdx.x % gx) * FT;
+  for (int idx = threadIdx.x; idx < FT * D; idx += 256) {
+    const int r = idx / D, k = idx % D;
+    Ps[r * LD + k] = (u0 + r < M.user_num) ? M.P[(u0 + r) * D + k] : 0.f;
+    Qs[r * LD + k] = (i0 + r < M.item_num) ? M.Q[(i0 + r) * D + k] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, c31 = lane & 31;
+  const int wu = (wave >> 1) * 64, wi = (wave & 1) * 64;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  for (int k = 0; k < D; k += 2) {
+    float av[2], bv[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) av[a] = Ps[(wu + a * 32 + c31) * LD + k + h];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) bv[b] = Qs[(wi + b * 32 + c31) * LD + k + h];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+  }
+  const float b0 = M.kind >= 1 ? M.b0[0] : 0.f;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int64_t i = i0 + wi + b * 32 + c31;
+    if (i >= M.item_num) continue;
+    const float bi = M.kind >= 1 ? M.bi[i] : 0.f;
+    const float pr = M.kind == 2 ? fmaxf(M.prop[i], M.M) : 1.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t u = u0 + wu + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (u >= M.user_num) continue;
+        float v = acc[a][b][r];
+        if (M.kind >= 1) v = v + M.bu[u] + bi + b0;
+        if (M.kind == 2) v = v / pr;
+        out[u * M.item_num + i] = v;
+      }
+  }
+}
+
+extern "C" int mf_predict_full(const mf_model_t* M, float* out, void* stream) {
+  ARG_CHECK(M && out, "NULL argument");
+  ARG_CHECK(M->P && M->Q && M->D >= 2 && M->D % 2 == 0 && M->D <= 128 && M->kind >= 0 && M->kind <= 2, "bad model");
+  ARG_CHECK(M->kind == 0 || (M->bu && M->bi && M->b0), "bias pointers missing");
+  ARG_CHECK(M->kind != 2 || M->prop, "propensity missing");
+  const int64_t nblk = ((M->item_num + FT - 1) / FT) * ((M->user_num + FT - 1) / FT);
+  ARG_CHECK(nblk < 2147483647LL, "matrix too large for one launch");
+  const dim3 grid((unsigned)nblk);
+  const size_t smem = (size_t)2 * FT * (M->D + 1) * 4;
+  HIP_TRY(hipFuncSetAttribute((const void*)k_mf_full, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(k_mf_full, grid, dim3(256), smem, (hipStream_t)stream, *M, out);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ train negatives
+// One thread per user: its deg(u) train rows get distinct uniform negatives outside its train history (sorted CSR ->
+// binary search) — the reference's per-epoch tmp_history_dict rule.  Draw j of user u is word j%4 of
+// Philox(c0=u, c1=j/4, c2=epoch); oracle/philox.py::train_negatives restates it bit for bit.
+__global__ __launch_bounds__(256) void k_sample_neg(const int64_t* __restrict__ rows_indptr,
+                                                    const int64_t* __restrict__ rows,
+                                                    const int64_t* __restrict__ hist_indptr,
+                                                    const int64_t* __restrict__ hist_items, int64_t user_num,
+                                                    int64_t item_num, rng_key key, int64_t* __restrict__ neg_out) {
+  for (int64_t u = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; u < user_num; u += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r0 = rows_indptr[u], r1 = rows_indptr[u + 1];
+    const int64_t h0 = hist_indptr[u], h1 = hist_indptr[u + 1];
+    uint32_t j = 0;
+    u32x4 cur{0, 0, 0, 0};
+    for (int64_t r = r0; r < r1; ++r) {
+      const int64_t remain = item_num - (h1 - h0) - (r - r0);
+      const bool low = 5 * remain < item_num;   // remain / item_num < 0.2
+      int64_t it;
+      if (remain < 1) { neg_out[rows[r]] = -1; continue; }   // reference asserts (DataProcessor.py:495)
+      for (;;) {
+        if ((j & 3) == 0) cur = philox4x32_10((uint32_t)u, j >> 2, key.s0, key.s1, key.k0, key.k1);
+        it = (int64_t)(((uint64_t)pick4(cur, j & 3) * (uint64_t)item_num) >> 32);
+        ++j;
+        if (low && it == 0) continue;
+        int64_t lo = h0, hi = h1;   // binary search in the sorted history
+        while (lo < hi) {
+          const int64_t mid = (lo + hi) >> 1;
+          if (hist_items[mid] < it) lo = mid + 1; else hi = mid;
+        }
+        if (lo < h1 && hist_items[lo] == it) continue;
+        bool dup = false;
+        for (int64_t q = r0; q < r; ++q)
+          if (neg_out[rows[q]] == it) { dup = true; break; }
+        if (!dup) break;
+      }
+      neg_out[rows[r]] = it;
+    }
+  }
+}
+
+extern "C" int dccf_sample_train_negatives(const int64_t* rows_indptr, const int64_t* rows, const int64_t* hist_indptr,
+                                           const int64_t* hist_items, int64_t user_num, int64_t item_num, uint64_t seed,
+                                           uint64_t epoch, int64_t* neg_out, void* stream) {
+  ARG_CHECK(rows_indptr && rows && hist_indptr && hist_items && neg_out, "NULL argument");
+  ARG_CHECK(user_num > 0 && item_num > 0 && item_num < 4294967296LL, "bad user_num / item_num");
+  const int grid = (int)min((int64_t)4096, (user_num + 255) / 256);
+  rng_key key = make_key(seed, STREAM_NEG, 0);
+  key.s0 = (uint32_t)epoch;
+  key.s1 = 0;
+  hipLaunchKernelGGL(k_sample_neg, dim3(grid), dim3(256), 0, (hipStream_t)stream, rows_indptr, rows, hist_indptr,
+                     hist_items, user_num, item_num, key, neg_out);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}

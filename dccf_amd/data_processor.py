@@ -1,0 +1,232 @@
+# coding=utf-8
+"""DataProcessor with the reference's surface (src/data_processor/DataProcessor.py:15-524).
+
+Two training feeds:
+  * ``prepare_batches(data, batch_size, train=True)`` — the reference's host path, restated: one numpy-RNG negative
+    per train row with the per-epoch ``tmp_history`` rule (:446-524), feed dicts ``X=[pos;neg]`` (:160-207).  For the
+    same numpy seed and call order it yields the reference's batches bit for bit (tests/test_host_logic.py).
+  * ``device_epoch(epoch)`` — the MI355X path: the train set, its per-user row lists and sorted histories live in HBM
+    (CSR), negatives for the whole epoch come from ONE kernel (``dccf_sample_train_negatives``: Philox streams keyed
+    by (seed, epoch, uid)), and the epoch's batches are views of device tensors — no per-epoch host loop, no H2D.
+Evaluation negatives (:73-111, :408-444) are sampled once per run on the host exactly as the reference does.
+"""
+import logging
+from collections import defaultdict
+
+import numpy as np
+import torch
+
+from dccf_amd import utils, _lib
+
+
+class DataProcessor(object):
+    data_columns = ['X']
+
+    @staticmethod
+    def parse_dp_args(parser):
+        parser.add_argument('--test_neg_n', type=int, default=100,
+                            help='Negative sample num for each instance in test/validation set.')
+        return parser
+
+    def __init__(self, data_loader, model, rank, test_neg_n, seed=2019):
+        self.data_loader, self.model, self.rank, self.test_neg_n = data_loader, model, rank, test_neg_n
+        self.train_data, self.validation_data, self.test_data = None, None, None
+        self.seed = seed
+        if self.rank == 1:
+            self.train_history_dict = defaultdict(set)
+            for uid, items in data_loader.train_user_his.items():
+                self.train_history_dict[uid] = set(items)
+            self.vt_history_dict = defaultdict(set)
+            for uid, items in data_loader.vt_user_his.items():
+                self.vt_history_dict[uid] = set(items)
+        self.vt_batches_buffer = {}
+        self._dev = None
+
+    # ------------------------------------------------------------------ data dicts
+    def format_data_dict(self, df):
+        """src/data_processor/DataProcessor.py:292-356 for the id-only models of this path (append_id, no side
+        features): X = [uid, iid] int64, Y = label fp32."""
+        model, dl = self.model, self.data_loader
+        if (dl.user_df is not None and model.include_user_features) or (dl.item_df is not None and model.include_item_features) \
+                or model.include_context_features or model.include_id or not model.append_id:
+            raise NotImplementedError('side-feature models are outside the DCCF hot path')
+        data = {'uid': df['uid'].values, 'iid': df['iid'].values}
+        if dl.label in df.columns:
+            data['Y'] = np.array(df[dl.label], dtype=np.float32)
+        else:
+            logging.warning('No Labels In Data: ' + dl.label)
+            data['Y'] = np.zeros(len(df), dtype=np.float32)
+        data['X'] = df[['uid', 'iid']].values.astype(int)
+        assert len(data['X']) == len(data['Y'])
+        return data
+
+    def get_train_data(self, epoch):
+        """:56-70 — shuffled in unison for epoch >= 0."""
+        if self.train_data is None or epoch < 0:
+            logging.info('Prepare Train Data...')
+            self.train_data = self.format_data_dict(self.data_loader.train_df)
+            self.train_data[utils.K_SAMPLE_ID] = np.arange(0, len(self.train_data['Y']))
+        if epoch >= 0:
+            utils.shuffle_in_unison_scary(self.train_data)
+        return self.train_data
+
+    def _eval_data(self, df):
+        import pandas as pd
+        if self.rank == 1:
+            neg_df = self.generate_neg_df(df['uid'].tolist(), df['iid'].tolist(), df, self.test_neg_n, train=False)
+            df = pd.concat([df, neg_df], ignore_index=True)
+        data = self.format_data_dict(df)
+        data[utils.K_SAMPLE_ID] = np.arange(0, len(data['Y']))
+        return data
+
+    def get_validation_data(self):
+        if self.validation_data is None:
+            logging.info('Prepare Validation Data...')
+            self.validation_data = self._eval_data(self.data_loader.validation_df)
+        return self.validation_data
+
+    def get_test_data(self):
+        if self.test_data is None:
+            logging.info('Prepare Test Data...')
+            self.test_data = self._eval_data(self.data_loader.test_df)
+        return self.test_data
+
+    # ------------------------------------------------------------------ negatives (host, reference algorithm)
+    def generate_neg_df(self, uid_list, iid_list, df, neg_n, train):
+        """:408-444.  Eval: one set of neg_n negatives per DISTINCT user (first occurrence, :420-426)."""
+        import pandas as pd
+        if not train:
+            seen, fu, fi = set(), [], []
+            for u, i in zip(uid_list, iid_list):
+                if u not in seen:
+                    seen.add(u)
+                    fu.append(u)
+                    fi.append(i)
+        else:
+            fu, fi = uid_list, iid_list
+        uids, negs, poss = self._sample_neg_from_uid_list(fu, fi, neg_n, train)
+        neg_df = pd.DataFrame({'uid': uids, 'iid_neg': negs, 'iid': poss})
+        neg_df = pd.merge(neg_df, df, on=['uid', 'iid'], how='left')
+        neg_df = neg_df.drop_duplicates(subset=['uid', 'iid_neg', 'iid']).drop(columns=['iid'])
+        neg_df = neg_df.rename(columns={'iid_neg': 'iid'})[df.columns]
+        neg_df[self.data_loader.label] = 0
+        return neg_df
+
+    def _sample_neg_from_uid_list(self, uids, iids, neg_n, train):
+        """:446-524 — same draws from the global numpy RNG, same rejection sets, same low-remaining fallback."""
+        item_num = self.data_loader.item_num
+        u_out, n_out, p_out = [], [], []
+        tmp = defaultdict(set)
+        for idx, uid in enumerate(uids):
+            if train:
+                inter = self.train_history_dict[uid] | tmp[uid]
+            else:
+                inter = self.train_history_dict[uid] | self.vt_history_dict[uid] | tmp[uid]
+            remain_n = item_num - len(inter)
+            assert remain_n >= neg_n
+            if 1.0 * remain_n / item_num < 0.2:
+                remain = [i for i in range(1, item_num) if i not in inter]
+                picks = np.random.choice(remain, neg_n, replace=False)
+                n_out.extend(picks)
+                tmp[uid].update(picks)
+            else:
+                mine = tmp[uid]
+                for _ in range(neg_n):
+                    iid = np.random.randint(item_num)
+                    while iid in inter or iid in mine:
+                        iid = np.random.randint(item_num)
+                    n_out.append(iid)
+                    mine.add(iid)
+            u_out.extend([uid] * neg_n)
+            p_out.extend([iids[idx]] * neg_n)
+            if not train:
+                tmp = defaultdict(set)
+        return u_out, n_out, p_out
+
+    # ------------------------------------------------------------------ host batches (reference layout)
+    def _feed_rt(self, data, b0, batch_size, train):
+        b1 = min(len(data['X']), b0 + batch_size)
+        fd = {'train': train, 'rank': 0, utils.K_SAMPLE_ID: data[utils.K_SAMPLE_ID][b0:b1],
+              'Y': utils.numpy_to_torch(data['Y'][b0:b1]) if 'Y' in data else utils.numpy_to_torch(np.zeros(b1 - b0, np.float32)),
+              'X': utils.numpy_to_torch(data['X'][b0:b1])}
+        return fd
+
+    def _feed_rk(self, data, b0, batch_size, train, neg_data):
+        """:160-207."""
+        if not train:
+            fd = self._feed_rt(data, b0, batch_size, train)
+            fd['rank'] = 1
+            return fd
+        b1 = min(len(data['X']), b0 + batch_size)
+        real = b1 - b0
+        y = np.concatenate([np.ones(real, dtype=np.float32), np.zeros(real, dtype=np.float32)])
+        sid = data[utils.K_SAMPLE_ID][b0:b1]
+        return {'train': True, 'rank': 1, 'Y': utils.numpy_to_torch(y),
+                utils.K_SAMPLE_ID: np.concatenate([sid, sid + len(self.train_data['Y'])]),
+                utils.REAL_BATCH_SIZE: real, utils.TOTAL_BATCH_SIZE: real * 2,
+                'X': utils.numpy_to_torch(np.concatenate([data['X'][b0:b1], neg_data['X'][b0:b1]]))}
+
+    def prepare_batches(self, data, batch_size, train):
+        """:252-275 (+ :209-250).  Validation/test batch lists are cached as in the reference."""
+        if data is None:
+            return None
+        key = ''
+        if data is self.validation_data:
+            key = 'validation_' + str(batch_size)
+        elif data is self.test_data:
+            key = 'test_' + str(batch_size)
+        if key in self.vt_batches_buffer:
+            return self.vt_batches_buffer[key]
+        n = len(data['X'])
+        assert n > 0
+        neg_data = None
+        if self.rank == 1 and train:
+            neg_df = self.generate_neg_df(data['uid'], data['iid'], self.data_loader.train_df, 1, train=True)
+            neg_data = self.format_data_dict(neg_df)
+        batches = []
+        for b0 in range(0, n, batch_size):
+            if self.rank == 1:
+                batches.append(self._feed_rk(data, b0, batch_size, train, neg_data))
+            else:
+                batches.append(self._feed_rt(data, b0, batch_size, train))
+        if key:
+            self.vt_batches_buffer[key] = batches
+        return batches
+
+    # ------------------------------------------------------------------ device-resident epoch (fused negatives)
+    def _build_device_state(self):
+        dl = self.data_loader
+        tr = dl.train_df
+        uid = tr['uid'].values.astype(np.int64)
+        iid = tr['iid'].values.astype(np.int64)
+        U = int(dl.user_num)
+        order = np.argsort(uid, kind='stable')                      # rows of each user, ascending sample id
+        rows_indptr = np.searchsorted(uid[order], np.arange(U + 1)).astype(np.int64)
+        pos = tr[tr[dl.label] > 0] if dl.label in tr.columns else tr
+        key = np.unique(pos['uid'].values.astype(np.int64) * int(dl.item_num) + pos['iid'].values.astype(np.int64))
+        hu, hi = key // int(dl.item_num), key % int(dl.item_num)   # sorted by user, then item; de-duplicated
+        hist_indptr = np.searchsorted(hu, np.arange(U + 1)).astype(np.int64)
+        t = utils.numpy_to_torch
+        self._dev = dict(uid=t(uid), iid=t(iid), rows=t(order.astype(np.int64)), rows_indptr=t(rows_indptr),
+                         hist_indptr=t(hist_indptr), hist_items=t(hi.astype(np.int64)), n=len(uid))
+
+    def device_epoch(self, epoch, batch_size):
+        """Returns (X_all [2, T, 2] int64 in HBM (pos rows, neg rows, already permuted), sample_id perm [T]).
+        The permutation plays the role of shuffle_in_unison_scary (utils.py:82-92); negatives are drawn on device."""
+        if self._dev is None:
+            self._build_device_state()
+        d = self._dev
+        dl = self.data_loader
+        neg = _lib.sample_train_negatives(d['rows_indptr'], d['rows'], d['hist_indptr'], d['hist_items'], dl.user_num,
+                                          dl.item_num, self.seed, epoch)
+        g = torch.Generator(device='cpu')
+        g.manual_seed((int(self.seed) * 1000003 + int(epoch)) & 0x7FFFFFFFFFFFFFFF)
+        perm = torch.randperm(d['n'], generator=g).to(d['uid'].device)
+        u = d['uid'][perm]
+        X = torch.stack([torch.stack([u, d['iid'][perm]], 1), torch.stack([u, neg[perm]], 1)], 0).contiguous()
+        return X, perm
+
+    @staticmethod
+    def device_batch(X, b0, b1):
+        """Rows [b0,b1) of a device epoch as the reference's [pos ; neg] layout: int64 [2*(b1-b0), 2]."""
+        return torch.cat([X[0, b0:b1], X[1, b0:b1]], 0)

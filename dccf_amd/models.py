@@ -1,0 +1,389 @@
+# coding=utf-8
+"""Model classes with the reference's contract (src/models/BaseModel.py:16-23), backed by the HIP path.
+
+Same class names, flags, constructor arguments, ``predict`` / ``forward`` return dicts, ``l2``, ``count_variables``,
+``save_model`` / ``load_model`` and ``state_dict`` keys and shapes as the reference (so ``.pt`` files interchange:
+``uid_embeddings.weight``, ``iid_embeddings.weight``, ``mlp.0.weight``, ``mlp.0.bias``, ``user_bias.weight`` [U,1],
+``item_bias.weight`` [I,1], ``global_bias`` []).  What differs is underneath: parameters are views of ONE flat fp32
+buffer in HBM (so the dense regularised optimizer step is a single streaming kernel), and ``forward`` in training mode
+runs the fused forward + loss + backward kernels and leaves the loss-term gradients in the flat gradient buffer —
+there is no autograd graph.  No CPU fallback: without the HIP library or a GPU these classes raise.
+"""
+import logging
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from dccf_amd import _lib, utils
+from dccf_amd.rank_metrics import evaluate_method as _evaluate_method
+
+
+class _ParamModule(object):
+    """What ``model.apply(fn)`` visits: stands in for the reference's nn.Embedding / nn.Linear modules."""
+
+    def __init__(self, kind, weight, bias=None):
+        self.kind, self.weight, self.bias = kind, weight, bias
+
+
+class FusedOptimizer(object):
+    """torch.optim.{SGD,Adagrad,Adam}(lr, weight_decay=l2) + the explicit l2 term + clip_grad_value_(50) of
+    src/runners/BaseRunner.py:83-107,181-187 as ONE dense kernel over the flat parameter buffer."""
+
+    def __init__(self, model, name, lr, l2, clip=50.0):
+        self.model, self.name, self.lr, self.l2, self.clip = model, name.lower(), lr, l2, clip
+        self.t = 0
+        n = model.flat_p.numel()
+        dev = model.flat_p.device
+        self.s1 = torch.zeros(n, dtype=torch.float32, device=dev) if self.name != 'gd' else None
+        self.s2 = torch.zeros(n, dtype=torch.float32, device=dev) if self.name == 'adam' else None
+
+    def zero_grad(self):
+        """Grads are zeroed by the fused step itself (src/runners/BaseRunner.py:178 becomes a no-op)."""
+        return
+
+    def step(self):
+        self.t += 1
+        m = self.model
+        _lib.dense_opt_step(self.name, m.flat_p, m.flat_g, self.s1, self.s2, self.lr, self.l2, self.l2, self.clip, self.t,
+                            zero_grad=True)
+
+
+class BaseModel(object):
+    append_id = False
+    include_id = True
+    include_user_features = True
+    include_item_features = True
+    include_context_features = False
+
+    @staticmethod
+    def parse_model_args(parser, model_name='BaseModel'):
+        parser.add_argument('--model_path', type=str, default='../model/%s/%s.pt' % (model_name, model_name),
+                            help='Model save path.')
+        return parser
+
+    @staticmethod
+    def evaluate_method(p, data, metrics):
+        """src/models/BaseModel.py:55-128."""
+        return _evaluate_method(p, data, metrics)
+
+    @staticmethod
+    def init_paras(m):
+        """src/models/BaseModel.py:130-142: N(0, 0.01) for every Embedding weight and Linear weight AND bias."""
+        if m.kind in ('linear', 'embedding'):
+            torch.nn.init.normal_(m.weight, mean=0.0, std=0.01)
+            if m.kind == 'linear' and m.bias is not None:
+                torch.nn.init.normal_(m.bias, mean=0.0, std=0.01)
+
+    def __init__(self, label_min, label_max, feature_num, random_seed=2018, model_path='../model/Model/Model.pt'):
+        self.label_min, self.label_max, self.feature_num = label_min, label_max, feature_num
+        self.random_seed, self.model_path = random_seed, model_path
+        torch.manual_seed(self.random_seed)
+        self.device = utils.device()
+        self.ctx = _lib.Context(self.device.index or 0)
+        self.training = False
+        self._call = 0            # counter of forwards: the `step` word of the Philox streams
+        self._specs = OrderedDict()
+        self._modules = []
+        self._init_weights()
+        self._allocate()
+        self.total_parameters = self.count_variables()
+        logging.info('# of params: %d' % self.total_parameters)
+        self.optimizer = None
+
+    # ---- parameter plumbing
+    def _declare(self, name, shape, init='default'):
+        self._specs[name] = (tuple(shape), init)
+
+    def _allocate(self):
+        sizes = [int(np.prod(s)) if len(s) else 1 for s, _ in self._specs.values()]
+        pads = [(n + 3) // 4 * 4 for n in sizes]
+        self.flat_p = torch.zeros(sum(pads), dtype=torch.float32, device=self.device)
+        self.flat_g = torch.zeros_like(self.flat_p)
+        self.params, self.grads = OrderedDict(), OrderedDict()
+        o = 0
+        for (name, (shape, init)), n, pd in zip(self._specs.items(), sizes, pads):
+            self.params[name] = self.flat_p[o:o + n].view(shape)
+            self.grads[name] = self.flat_g[o:o + n].view(shape)
+            o += pd
+            t = self.params[name]
+            # torch defaults of the layers the reference builds, overwritten by main.py's model.apply(init_paras)
+            if init == 'embedding':
+                torch.nn.init.normal_(t)
+            elif init == 'linear_w':
+                torch.nn.init.kaiming_uniform_(t, a=5 ** 0.5)
+            elif init == 'linear_b':
+                bound = 1.0 / (self._specs[name.replace('bias', 'weight')][0][1] ** 0.5)
+                torch.nn.init.uniform_(t, -bound, bound)
+            elif isinstance(init, float):
+                t.fill_(init)
+
+    def apply(self, fn):
+        for m in self._modules:
+            fn(m)
+        return self
+
+    def parameters(self):
+        return list(self.params.values())
+
+    def named_parameters(self):
+        return list(self.params.items())
+
+    def state_dict(self):
+        return OrderedDict((k, v.detach().clone()) for k, v in self.params.items())
+
+    def load_state_dict(self, sd):
+        missing = [k for k in self.params if k not in sd]
+        extra = [k for k in sd if k not in self.params]
+        if missing or extra:
+            raise RuntimeError('state_dict mismatch: missing %s unexpected %s' % (missing, extra))
+        for k, v in self.params.items():
+            v.copy_(sd[k].to(self.device).view(v.shape))
+
+    def count_variables(self):
+        return sum(p.numel() for p in self.params.values())
+
+    def l2(self):
+        """src/models/BaseModel.py:179-187: sum over all parameters of p^2 (pad elements of the flat buffer are zero)."""
+        return _lib.sumsq(self.flat_p)[0]
+
+    def train(self):
+        self.training = True
+        return self
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def cuda(self):
+        return self
+
+    def __call__(self, feed_dict):
+        return self.forward(feed_dict)
+
+    def save_model(self, model_path=None):
+        """src/models/BaseModel.py:224-236."""
+        model_path = model_path or self.model_path
+        d = os.path.dirname(model_path)
+        if d and not os.path.exists(d):
+            os.makedirs(d)
+        torch.save(OrderedDict((k, v.cpu()) for k, v in self.state_dict().items()), model_path)
+        logging.info('Save model to ' + model_path)
+
+    def load_model(self, model_path=None):
+        """src/models/BaseModel.py:238-248."""
+        model_path = model_path or self.model_path
+        self.load_state_dict(torch.load(model_path, map_location='cpu'))
+        self.eval()
+        logging.info('Load model from ' + model_path)
+
+    def _next_step(self):
+        self._call += 1
+        return self._call
+
+    def _init_weights(self):
+        raise NotImplementedError
+
+    def predict(self, feed_dict):
+        raise NotImplementedError
+
+    def forward(self, feed_dict):
+        raise NotImplementedError
+
+
+class RecModel(BaseModel):
+    """src/models/RecModel.py:9-48 — plain MF dot."""
+    append_id = True
+    include_id = False
+    include_user_features = False
+    include_item_features = False
+    kind = 'RecModel'
+
+    @staticmethod
+    def parse_model_args(parser, model_name='RecModel'):
+        parser.add_argument('--u_vector_size', type=int, default=64, help='Size of user vectors.')
+        parser.add_argument('--i_vector_size', type=int, default=64, help='Size of item vectors.')
+        return BaseModel.parse_model_args(parser, model_name)
+
+    def __init__(self, label_min, label_max, feature_num, user_num, item_num, u_vector_size, i_vector_size, random_seed,
+                 model_path):
+        self.u_vector_size, self.i_vector_size = u_vector_size, i_vector_size
+        assert self.u_vector_size == self.i_vector_size
+        self.ui_vector_size = self.u_vector_size
+        self.user_num, self.item_num = int(user_num), int(item_num)
+        BaseModel.__init__(self, label_min=label_min, label_max=label_max, feature_num=feature_num,
+                           random_seed=random_seed, model_path=model_path)
+
+    def _init_weights(self):
+        self._declare('uid_embeddings.weight', (self.user_num, self.ui_vector_size), 'embedding')
+        self._declare('iid_embeddings.weight', (self.item_num, self.ui_vector_size), 'embedding')
+
+    def _allocate(self):
+        BaseModel._allocate(self)
+        p = self.params
+        self._modules = [_ParamModule('embedding', p[k]) for k in p if k.endswith('embeddings.weight') or k.endswith('_bias.weight')]
+
+    propensity = None
+    M = 0.1
+
+    def _struct(self):
+        p = self.params
+        if self.kind == 'RecModel':
+            return _lib.mf_struct(self.kind, p['uid_embeddings.weight'], p['iid_embeddings.weight'])
+        return _lib.mf_struct(self.kind, p['uid_embeddings.weight'], p['iid_embeddings.weight'],
+                              p['user_bias.weight'].view(-1), p['item_bias.weight'].view(-1), p['global_bias'].view(-1),
+                              self.propensity, self.M)
+
+    def predict(self, feed_dict):
+        pred = _lib.mf_predict(self._struct(), feed_dict['X'].contiguous())
+        return {'prediction': pred, 'check': []}
+
+    def forward(self, feed_dict):
+        """BaseModel.forward (src/models/BaseModel.py:203-219).  In training mode the backward of the loss term is
+        fused in and its gradients are accumulated into ``flat_g``."""
+        if not self.training:
+            out = self.predict(feed_dict)
+            return out
+        g = self.grads
+        X = feed_dict['X'].contiguous()
+        if self.kind == 'RecModel':
+            pred, loss = _lib.mf_train_fwdbwd(self.ctx, self._struct(), X, feed_dict['Y'], feed_dict['rank'],
+                                              g['uid_embeddings.weight'], g['iid_embeddings.weight'])
+        else:
+            pred, loss = _lib.mf_train_fwdbwd(self.ctx, self._struct(), X, feed_dict['Y'], feed_dict['rank'],
+                                              g['uid_embeddings.weight'], g['iid_embeddings.weight'],
+                                              g['user_bias.weight'].view(-1), g['item_bias.weight'].view(-1),
+                                              g['global_bias'].view(-1))
+        return {'prediction': pred, 'check': [], 'loss': loss[0]}
+
+    def full_matrix(self):
+        """README.md:28-30: the full predicted user x item matrix (the exposure probabilities DCCF loads)."""
+        return _lib.mf_predict_full(self._struct(), device=self.device)
+
+
+class BiasedMF(RecModel):
+    """src/models/BiasedMF.py:9-33."""
+    kind = 'BiasedMF'
+
+    def _init_weights(self):
+        RecModel._init_weights(self)
+        self._declare('user_bias.weight', (self.user_num, 1), 'embedding')
+        self._declare('item_bias.weight', (self.item_num, 1), 'embedding')
+        self._declare('global_bias', (), 0.1)
+
+
+class IPSBiasedMF(BiasedMF):
+    """src/models/IPSBiasedMF.py:12-57."""
+    kind = 'IPSBiasedMF'
+
+    @staticmethod
+    def parse_model_args(parser, model_name='IPSBiasedMF'):
+        parser.add_argument('--M', type=float, default=0.1, help='minimum propensity to avoid high variance.')
+        return RecModel.parse_model_args(parser, model_name)
+
+    def __init__(self, path, dataset, M, label_min, label_max, feature_num, user_num, item_num, u_vector_size,
+                 i_vector_size, random_seed, model_path):
+        self.path, self.dataset = path, dataset
+        RecModel.__init__(self, label_min=label_min, label_max=label_max, feature_num=feature_num, user_num=user_num,
+                          item_num=item_num, u_vector_size=u_vector_size, i_vector_size=i_vector_size,
+                          random_seed=random_seed, model_path=model_path)
+        self.M = M
+        self.propensity = utils.numpy_to_torch(np.load(os.path.join(path, dataset + utils.PROPENSITY_SUFFIX)).astype(np.float32))
+
+
+class DMF(RecModel):
+    """Only the flag and constructor plumbing DCCF inherits (src/models/DMF.py:11-23); DMF itself is not constructible
+    from the reference's main.py and is outside the hot path."""
+
+    @staticmethod
+    def parse_model_args(parser, model_name='DMF'):
+        parser.add_argument('--n_layers', type=int, default=1, help='Number of mlp layers.')
+        return RecModel.parse_model_args(parser, model_name)
+
+
+class DCCF(DMF):
+    """src/models/DCCF.py:14-127."""
+    kind = 'DCCF'
+
+    @staticmethod
+    def parse_model_args(parser, model_name='DCCF'):
+        parser.add_argument('--sentence-model', type=str, default='paraphrase-distilroberta-base-v1',
+                            help='the name of sentence model')
+        parser.add_argument('--sample-num', type=int, default=10, help='the number of sampled items')
+        parser.add_argument('--attribute-num', type=int, default=2, help='the number of item features')
+        parser.add_argument('--std', type=float, default=0.1, help='std of feature distribution')
+        return DMF.parse_model_args(parser, model_name)
+
+    def __init__(self, path, dataset, sentence_model, sample_num, attribute_num, std, label_min, label_max, feature_num,
+                 user_num, item_num, u_vector_size, i_vector_size, n_layers, random_seed, model_path,
+                 feature_embedding=None, expo_prob=None, ips_factors=None):
+        """``feature_embedding`` / ``expo_prob`` tensors may be passed instead of the .npy files (benchmarks);
+        ``ips_factors`` (dict P,Q,bu,bi,prop,b0,M) replaces the dense exposure matrix by on-the-fly IPSBiasedMF scores."""
+        self.path, self.dataset, self.sentence_model = path, dataset, sentence_model
+        self.sample_num, self.attribute_num, self.std = sample_num, attribute_num, std
+        self.n_layers = n_layers
+        if n_layers != 1:
+            raise NotImplementedError('the HIP path implements the default --n_layers 1 (src/models/DMF.py:14)')
+        self._feat_in, self._expo_in, self.ips_factors = feature_embedding, expo_prob, ips_factors
+        RecModel.__init__(self, label_min=label_min, label_max=label_max, feature_num=feature_num, user_num=user_num,
+                          item_num=item_num, u_vector_size=u_vector_size, i_vector_size=i_vector_size,
+                          random_seed=random_seed, model_path=model_path)
+
+    def _init_weights(self):
+        """src/models/DCCF.py:47-64."""
+        if self._feat_in is not None:
+            self.feature_embedding = self._feat_in.to(self.device, torch.float32).contiguous()
+        else:
+            f = np.load(os.path.join(self.path, self.dataset + '_' + self.sentence_model + '.npy'))
+            self.feature_embedding = utils.numpy_to_torch(f.astype(np.float32))
+        if self._expo_in is not None:
+            self.expo_prob = self._expo_in.to(self.device, torch.float32).contiguous()
+        elif self.ips_factors is not None:
+            self.expo_prob = None
+        else:
+            e = np.load(os.path.join(self.path, self.dataset + utils.EXPO_SUFFIX), mmap_mode='r')
+            self.expo_prob = torch.empty(e.shape, dtype=torch.float32, device=self.device)
+            rows = max(1, (256 << 20) // (4 * e.shape[1]))          # stream the U x I matrix to HBM in 256 MiB slabs
+            for r0 in range(0, e.shape[0], rows):
+                self.expo_prob[r0:r0 + rows].copy_(torch.from_numpy(np.ascontiguousarray(e[r0:r0 + rows], dtype=np.float32)))
+        D, F = self.ui_vector_size, self.feature_embedding.shape[1]
+        self._declare('uid_embeddings.weight', (self.user_num, D), 'embedding')
+        self._declare('iid_embeddings.weight', (self.item_num, D), 'embedding')
+        self._declare('mlp.0.weight', (D, D + F), 'linear_w')
+        self._declare('mlp.0.bias', (D,), 'linear_b')
+
+    def _allocate(self):
+        BaseModel._allocate(self)
+        p = self.params
+        self._modules = [_ParamModule('embedding', p['uid_embeddings.weight']), _ParamModule('embedding', p['iid_embeddings.weight']),
+                         _ParamModule('linear', p['mlp.0.weight'], p['mlp.0.bias'])]
+
+    def _struct(self):
+        p = self.params
+        return _lib.model_struct(p['uid_embeddings.weight'], p['iid_embeddings.weight'], p['mlp.0.weight'], p['mlp.0.bias'],
+                                 self.feature_embedding, self.expo_prob, self.sample_num, self.attribute_num, self.std,
+                                 ips=self.ips_factors)
+
+    def _rand(self, feed_dict):
+        inj = feed_dict.get('inject')
+        if inj is not None:   # parity tests: the reference's captured draws
+            return _lib.rand_struct(sample_item=inj['sample_item'], noise=inj['noise'], keep=inj.get('keep'))
+        return _lib.rand_struct(seed=self.random_seed, step=self._next_step())
+
+    def predict(self, feed_dict):
+        """src/models/DCCF.py:66-107.  Fresh candidates and noise on every call, also in eval mode, as in the reference."""
+        pred = _lib.dccf_predict(self.ctx, self._struct(), self._rand(feed_dict), feed_dict['X'].contiguous(),
+                                 feed_dict['dropout'])
+        return {'prediction': pred, 'check': [('prediction', pred)]}
+
+    def forward(self, feed_dict):
+        """src/models/DCCF.py:109-127 (+ the backward of the loss term when training)."""
+        if not self.training:
+            return self.predict(feed_dict)
+        g = self.grads
+        pred, loss = _lib.dccf_train_fwdbwd(self.ctx, self._struct(), self._rand(feed_dict), feed_dict['X'].contiguous(),
+                                            feed_dict['Y'], feed_dict['rank'], feed_dict['dropout'],
+                                            g['uid_embeddings.weight'], g['iid_embeddings.weight'], g['mlp.0.weight'],
+                                            g['mlp.0.bias'])
+        return {'prediction': pred, 'check': [('prediction', pred)], 'loss': loss[0]}

@@ -1,0 +1,195 @@
+# coding=utf-8
+"""BaseRunner with the reference's surface (src/runners/BaseRunner.py:16-355): same flags, same epoch loop, same log
+lines, same early-stop rule, same best-model save/restore.  The training step itself is the fused HIP path:
+``model(batch)`` runs forward + loss + backward kernels, ``optimizer.step()`` is the dense l2 + clip + update kernel."""
+import logging
+import os
+from time import time
+
+import numpy as np
+import pandas as pd
+import torch
+
+from dccf_amd import utils
+from dccf_amd.models import FusedOptimizer
+
+
+class BaseRunner(object):
+    @staticmethod
+    def parse_runner_args(parser):
+        """src/runners/BaseRunner.py:18-48 — identical flags and defaults, plus --fused_sampling for this build."""
+        parser.add_argument('--load', type=int, default=0, help='Whether load model and continue to train')
+        parser.add_argument('--epoch', type=int, default=100, help='Number of epochs.')
+        parser.add_argument('--check_epoch', type=int, default=1, help='Check every epochs.')
+        parser.add_argument('--early_stop', type=int, default=1, help='whether to early-stop.')
+        parser.add_argument('--lr', type=float, default=0.01, help='Learning rate.')
+        parser.add_argument('--batch_size', type=int, default=128, help='Batch size during training.')
+        parser.add_argument('--eval_batch_size', type=int, default=128 * 128, help='Batch size during testing.')
+        parser.add_argument('--dropout', type=float, default=0.2, help='Dropout probability for each deep layer')
+        parser.add_argument('--l2', type=float, default=1e-4, help='Weight of l2_regularize in loss.')
+        parser.add_argument('--optimizer', type=str, default='GD', help='optimizer: GD, Adam, Adagrad')
+        parser.add_argument('--metric', type=str, default='RMSE', help='metrics: RMSE, MAE, AUC, F1, Accuracy, Precision, Recall')
+        parser.add_argument('--skip_eval', type=int, default=0, help='number of epochs without evaluation')
+        parser.add_argument('--fused_sampling', type=int, default=1,
+                            help='1: train negatives and batches stay on the GPU (Philox); 0: the reference host path')
+        return parser
+
+    def __init__(self, optimizer='GD', learning_rate=0.01, epoch=100, batch_size=128, eval_batch_size=128 * 128,
+                 dropout=0.2, l2=1e-5, metrics='RMSE', check_epoch=10, early_stop=1, fused_sampling=1):
+        self.optimizer_name, self.learning_rate, self.epoch = optimizer, learning_rate, epoch
+        self.batch_size, self.eval_batch_size = batch_size, eval_batch_size
+        self.dropout, self.no_dropout, self.l2_weight = dropout, 0.0, l2
+        self.metrics = metrics.lower().split(',')
+        self.check_epoch, self.early_stop, self.fused_sampling = check_epoch, early_stop, fused_sampling
+        self.time = None
+        self.train_results, self.valid_results, self.test_results = [], [], []
+
+    def _build_optimizer(self, model):
+        """src/runners/BaseRunner.py:83-107."""
+        name = self.optimizer_name.lower()
+        if name not in ('gd', 'adagrad', 'adam'):
+            logging.error('Unknown Optimizer: ' + self.optimizer_name)
+            assert self.optimizer_name in ['GD', 'Adagrad', 'Adam']
+        logging.info('Optimizer: ' + {'gd': 'GD', 'adagrad': 'Adagrad', 'adam': 'Adam'}[name])
+        return FusedOptimizer(model, name, self.learning_rate, self.l2_weight, clip=50.0)
+
+    def _check_time(self, start=False):
+        if self.time is None or start:
+            self.time = [time()] * 2
+            return self.time[0]
+        t = self.time[1]
+        self.time[1] = time()
+        return self.time[1] - t
+
+    def batches_add_control(self, batches, train):
+        for b in batches:
+            b['train'] = train
+            b['dropout'] = self.dropout if train else self.no_dropout
+        return batches
+
+    def predict(self, model, data, data_processor):
+        """src/runners/BaseRunner.py:134-157: batched predict, reordered by sample_id."""
+        batches = self.batches_add_control(data_processor.prepare_batches(data, self.eval_batch_size, train=False), train=False)
+        model.eval()
+        preds = [model.predict(b)['prediction'] for b in batches]
+        predictions = torch.cat(preds).cpu().numpy() if preds else np.zeros(0, dtype=np.float32)
+        sample_ids = np.concatenate([b[utils.K_SAMPLE_ID] for b in batches])
+        out = np.empty_like(predictions)
+        # reorder_dict of the reference: later duplicates win; sample ids of one split are unique
+        pos = np.empty(int(sample_ids.max()) + 1 if len(sample_ids) else 0, dtype=np.int64)
+        pos[sample_ids] = np.arange(len(sample_ids))
+        out = predictions[pos[data[utils.K_SAMPLE_ID]]]
+        return out
+
+    def fit(self, model, data, data_processor, epoch=-1):
+        """src/runners/BaseRunner.py:159-191.  One optimizer step per batch (accumulate_size reaches the threshold on
+        every batch in the reference, :172-188)."""
+        if model.optimizer is None:
+            model.optimizer = self._build_optimizer(model)
+        model.train()
+        out = None
+        if self.fused_sampling and data_processor.rank == 1:
+            X, perm = data_processor.device_epoch(max(epoch, 0), self.batch_size)
+            T = X.shape[1]
+            ones = torch.ones(self.batch_size, dtype=torch.float32, device=X.device)
+            for b0 in range(0, T, self.batch_size):
+                b1 = min(T, b0 + self.batch_size)
+                n = b1 - b0
+                batch = {'X': data_processor.device_batch(X, b0, b1), 'Y': torch.cat([ones[:n], ones[:n] * 0]), 'rank': 1,
+                         'train': True, 'dropout': self.dropout, utils.REAL_BATCH_SIZE: n}
+                model.optimizer.zero_grad()
+                out = model(batch)
+                model.optimizer.step()        # + l2 term, clip_grad_value_(50), update: one dense kernel
+        else:
+            batches = self.batches_add_control(data_processor.prepare_batches(data, self.batch_size, train=True), train=True)
+            for batch in batches:
+                model.optimizer.zero_grad()
+                out = model(batch)
+                model.optimizer.step()
+        model.eval()
+        return out
+
+    def eva_termination(self, model):
+        """src/runners/BaseRunner.py:193-210."""
+        metric, valid = self.metrics[0], self.valid_results
+        if len(valid) > 20 and metric in utils.LOWER_METRIC_LIST and utils.strictly_increasing(valid[-5:]):
+            return True
+        elif len(valid) > 20 and metric not in utils.LOWER_METRIC_LIST and utils.strictly_decreasing(valid[-5:]):
+            return True
+        elif len(valid) - valid.index(utils.best_result(metric, valid)) > 20:
+            return True
+        return False
+
+    def train(self, model, data_processor, skip_eval=0):
+        """src/runners/BaseRunner.py:212-303."""
+        train_data = data_processor.get_train_data(epoch=-1)
+        validation_data = data_processor.get_validation_data()
+        test_data = data_processor.get_test_data()
+        self._check_time(start=True)
+        nm = [-1.0] * len(self.metrics)
+        init_train = self.evaluate(model, train_data, data_processor, metrics=['rmse', 'mae']) if train_data is not None else nm
+        init_valid = self.evaluate(model, validation_data, data_processor) if validation_data is not None else nm
+        init_test = self.evaluate(model, test_data, data_processor) if test_data is not None else nm
+        logging.info('Init: \t train= %s validation= %s test= %s [%.1f s] ' % (
+            utils.format_metric(init_train), utils.format_metric(init_valid), utils.format_metric(init_test),
+            self._check_time()) + ','.join(self.metrics))
+        try:
+            for epoch in range(self.epoch):
+                self._check_time()
+                epoch_train_data = data_processor.get_train_data(epoch=epoch)
+                last_batch = self.fit(model, epoch_train_data, data_processor, epoch=epoch)
+                if self.check_epoch > 0 and (epoch == 1 or epoch % self.check_epoch == 0):
+                    self.check(model, last_batch)
+                training_time = self._check_time()
+                if epoch >= skip_eval:
+                    train_result = self.evaluate(model, train_data, data_processor, metrics=['rmse', 'mae']) if train_data is not None else nm
+                    valid_result = self.evaluate(model, validation_data, data_processor) if validation_data is not None else nm
+                    test_result = self.evaluate(model, test_data, data_processor) if test_data is not None else nm
+                    testing_time = self._check_time()
+                    self.train_results.append(train_result)
+                    self.valid_results.append(valid_result)
+                    self.test_results.append(test_result)
+                    logging.info('Epoch %5d [%.1f s]\t train= %s validation= %s test= %s [%.1f s] '
+                                 % (epoch + 1, training_time, utils.format_metric(train_result),
+                                    utils.format_metric(valid_result), utils.format_metric(test_result), testing_time)
+                                 + ','.join(self.metrics))
+                    if utils.best_result(self.metrics[0], self.valid_results) == self.valid_results[-1]:
+                        model.save_model()
+                    if self.eva_termination(model) and self.early_stop == 1:
+                        logging.info('Early stop at %d based on validation result.' % (epoch + 1))
+                        break
+                if epoch < skip_eval:
+                    logging.info('Epoch %5d [%.1f s]' % (epoch + 1, training_time))
+        except KeyboardInterrupt:
+            logging.info('Early stop manually')
+        if self.valid_results:
+            for what, res in (('validation', self.valid_results), ('test', self.test_results)):
+                best = utils.best_result(self.metrics[0], res)
+                be = res.index(best)
+                logging.info('Best Iter(%s)= %5d\t train= %s valid= %s test= %s [%.1f s] '
+                             % (what, be + 1, utils.format_metric(self.train_results[be]),
+                                utils.format_metric(self.valid_results[be]), utils.format_metric(self.test_results[be]),
+                                self.time[1] - self.time[0]) + ','.join(self.metrics))
+            model.load_model()
+
+    def evaluate(self, model, data, data_processor, metrics=None, write_rank=False):
+        """src/runners/BaseRunner.py:305-332."""
+        if metrics is None:
+            metrics = self.metrics
+        predictions = self.predict(model, data, data_processor)
+        if write_rank:
+            df = pd.DataFrame({'uid': data['uid'], 'iid': data['iid'], 'score': predictions, 'label': data['Y']})
+            df = df.sort_values(by='uid')
+            df.to_csv(os.path.join(data_processor.data_loader.path, utils.RANK_FILE_NAME), sep='\t', index=False)
+        return model.evaluate_method(predictions, data, metrics=metrics)
+
+    def check(self, model, out_dict):
+        """src/runners/BaseRunner.py:334-355."""
+        logging.info(os.linesep)
+        for name, t in out_dict['check']:
+            d = np.array(t.detach().cpu())
+            logging.info(os.linesep.join([name + '\t' + str(d.shape), np.array2string(d, threshold=20)]) + os.linesep)
+        loss, l2 = float(out_dict['loss']), float(model.l2()) * self.l2_weight
+        logging.info('loss = %.4f, l2 = %.4f' % (loss, l2))
+        if not (abs(loss) * 0.005 < l2 < abs(loss) * 0.1):
+            logging.warning('l2 inappropriate: loss = %.4f, l2 = %.4f' % (loss, l2))

@@ -1,0 +1,94 @@
+# coding=utf-8
+"""Host helpers and constants with the names the reference uses (src/utils/utils.py, src/utils/global_p.py)."""
+import logging
+import os
+
+import numpy as np
+import torch
+
+LOWER_METRIC_LIST = ['rmse', 'mae']
+
+# file suffixes / dict keys (src/utils/global_p.py:19-31,49-53,84-92)
+TRAIN_SUFFIX = '.train.csv'
+VALIDATION_SUFFIX = '.validation.csv'
+TEST_SUFFIX = '.test.csv'
+INFO_SUFFIX = '.info.json'
+USER_SUFFIX = '.user.csv'
+ITEM_SUFFIX = '.item.csv'
+TRAIN_GROUP_SUFFIX = '.train_group.csv'
+VT_GROUP_SUFFIX = '.vt_group.csv'
+RANK_FILE_NAME = 'rank.csv'
+PROPENSITY_SUFFIX = '.propensity.npy'
+EXPO_SUFFIX = '.ips_expo_prob.npy'
+K_SAMPLE_ID = 'sample_id'
+REAL_BATCH_SIZE = 'real_batch_size'
+TOTAL_BATCH_SIZE = 'total_batch_size'
+
+
+def parse_global_args(parser):
+    """src/utils/utils.py:10-28 — same flags and defaults."""
+    parser.add_argument('--gpu', type=str, default='0', help='Set CUDA_VISIBLE_DEVICES')
+    parser.add_argument('--verbose', type=int, default=logging.INFO, help='Logging Level, 0, 10, ..., 50')
+    parser.add_argument('--log_file', type=str, default='../log/log.txt', help='Logging file path')
+    parser.add_argument('--result_file', type=str, default='../result/result.npy', help='Result file path')
+    parser.add_argument('--random_seed', type=int, default=2019, help='Random seed of numpy and torch.')
+    parser.add_argument('--train', type=int, default=1, help='To train the model or not.')
+    return parser
+
+
+def format_metric(metric):
+    """src/utils/utils.py:64-79: floats with four decimals, ints as ints, comma separated."""
+    if not isinstance(metric, (tuple, list)):
+        metric = [metric]
+    out = []
+    for m in metric:
+        if isinstance(m, (float, np.floating)):
+            out.append('%.4f' % m)
+        elif isinstance(m, (int, np.integer)):
+            out.append('%d' % m)
+    return ','.join(out)
+
+
+def shuffle_in_unison_scary(data):
+    """src/utils/utils.py:82-92: every array of the dict gets the same permutation (same RNG state restored)."""
+    state = np.random.get_state()
+    for k in data:
+        np.random.set_state(state)
+        np.random.shuffle(data[k])
+    return data
+
+
+def best_result(metric, results_list):
+    """src/utils/utils.py:95-107."""
+    if isinstance(metric, (list, tuple)):
+        metric = metric[0]
+    return min(results_list) if metric in LOWER_METRIC_LIST else max(results_list)
+
+
+def strictly_increasing(l):
+    return all(x < y for x, y in zip(l, l[1:]))
+
+
+def strictly_decreasing(l):
+    return all(x > y for x, y in zip(l, l[1:]))
+
+
+def device():
+    if not torch.cuda.is_available():
+        raise RuntimeError('dccf_amd needs an MI355X (no CPU fallback): torch.cuda.is_available() is False')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def numpy_to_torch(d):
+    """src/utils/utils.py:154-163: numpy -> tensor in HBM."""
+    return torch.from_numpy(np.ascontiguousarray(d)).to(device())
+
+
+def check_dir_and_mkdir(path):
+    """src/utils/utils.py:170-178."""
+    if os.path.basename(path).find('.') == -1 or path.endswith('/'):
+        dirname = path
+    else:
+        dirname = os.path.dirname(path)
+    if dirname and not os.path.exists(dirname):
+        os.makedirs(dirname)

@@ -1,0 +1,150 @@
+/*
+ * dccf_hip.h — C ABI of the MI355X-native DCCF training / predict hot path (libdccf_hip.so).
+ *
+ * The reference (rutgerswiselab/DCCF) has no FFI: its plug-in boundary is a Python class picked by
+ * `--model_name` (src/main.py:43,120-148) whose arithmetic is a sequence of stock PyTorch ops.  Each entry point
+ * below replaces one such group of call sites; the host side (dccf_amd/, Python like the reference) keeps the
+ * reference's class / runner interface and calls these through ctypes.  INTEGRATION.md shows the binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless a comment says "host"; PyTorch-ROCm owns all buffers;
+ *   - ids are int64 as in the reference (`feed_dict['X']`, src/data_processor/DataProcessor.py:149-158);
+ *   - all floating point is fp32, row-major, no padding; `stream` is a hipStream_t (NULL = default stream);
+ *   - every function is stream-ordered and returns 0 on success, <0 for an argument error, >0 = hipError_t;
+ *     `dccf_last_error()` returns a thread-local message.  No C++ exception crosses this boundary;
+ *   - the library allocates nothing except the workspace owned by a `dccf_ctx` (grow-only; call
+ *     `dccf_ctx_reserve` up front to keep the step functions allocation-free, e.g. for hipGraph capture).
+ */
+#ifndef DCCF_HIP_H
+#define DCCF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dccf_ctx dccf_ctx;
+
+/* ---- context ------------------------------------------------------------------------------------------- */
+int dccf_ctx_create(dccf_ctx** out, int device);
+int dccf_ctx_destroy(dccf_ctx* ctx);
+/* Pre-size the workspace for batches of up to `max_rows` rows of X (train: 2*batch_size; eval: eval_batch_size). */
+int dccf_ctx_reserve(dccf_ctx* ctx, int64_t max_rows, int32_t D, int32_t F, int32_t S, int32_t A);
+const char* dccf_last_error(void);
+int dccf_abi_version(void);
+
+/* ---- DCCF model view: replaces the attributes set up by DCCF._init_weights (src/models/DCCF.py:47-64) ----- */
+typedef struct {
+  int64_t user_num, item_num;
+  int32_t D;            /* --u_vector_size == --i_vector_size (src/models/RecModel.py:17-27); 16, 32, 64 or 128 */
+  int32_t F;            /* feature width, taken from the .npy (src/models/DCCF.py:59); <= 1024                 */
+  int32_t S;            /* --sample-num   (src/models/DCCF.py:19)                                              */
+  int32_t A;            /* --attribute-num (src/models/DCCF.py:20)                                             */
+  float   std;          /* --std          (src/models/DCCF.py:21)                                              */
+  float   reserved;
+  const float* U;       /* uid_embeddings.weight [user_num, D]                                                 */
+  const float* V;       /* iid_embeddings.weight [item_num, D]                                                 */
+  const float* W;       /* mlp.0.weight [D, D+F]                                                               */
+  const float* b;       /* mlp.0.bias   [D]                                                                    */
+  const float* feat;    /* feature_embedding [item_num, F]      (frozen)                                       */
+  const float* expo;    /* expo_prob [user_num, item_num] (frozen) or NULL -> computed from the factors below  */
+  /* on-the-fly exposure = IPSBiasedMF.predict(u, i) (src/models/IPSBiasedMF.py:37-57): exactly the number the   */
+  /* dense file would hold (README.md:28-30), for tables too large for a dense U x I matrix                     */
+  const float* ipsP;    /* [user_num, ipsD] */
+  const float* ipsQ;    /* [item_num, ipsD] */
+  const float* ipsBu;   /* [user_num]       */
+  const float* ipsBi;   /* [item_num]       */
+  const float* ipsProp; /* [item_num]       */
+  float   ipsB0, ipsM;
+  int32_t ipsD, reserved2;
+} dccf_model_t;
+
+/* ---- the random draws of DCCF.predict (src/models/DCCF.py:72,87,94) ---------------------------------------- */
+typedef struct {
+  int32_t mode;                /* 0 = injected ("golden"): use the three arrays; 1 = fused: Philox4x32-10(seed, step) */
+  int32_t reserved;
+  const int64_t* sample_item;  /* [N, S]      candidates as torch.randint would return them                      */
+  const float*   noise;        /* [N*(S+1)*A, F]  N(0, std^2) draws (already scaled by std)                       */
+  const uint8_t* keep;         /* [N*(S+1)*A, D]  dropout keep mask (1 = kept) or NULL = keep all                 */
+  uint64_t seed;               /* fused mode: stream key                                                        */
+  uint64_t step;               /* fused mode: call counter (one value per forward)                              */
+} dccf_rand_t;
+
+typedef struct {             /* dense-shaped gradients of the LOSS term, accumulated (+=) — zero them first     */
+  float* gU;                 /* [user_num, D]   */
+  float* gV;                 /* [item_num, D]   */
+  float* gW;                 /* [D, D+F]        */
+  float* gb;                 /* [D]             */
+} dccf_grads_t;
+
+/* DCCF.predict (src/models/DCCF.py:66-107): X int64 [N,2] -> prediction fp32 [N].  `dropout` is feed_dict['dropout']. */
+int dccf_predict(dccf_ctx* ctx, const dccf_model_t* model, const dccf_rand_t* rnd, const int64_t* X, int64_t N,
+                 float dropout, float* prediction, void* stream);
+
+/* DCCF.forward + loss.backward() (src/models/DCCF.py:109-127, src/runners/BaseRunner.py:180-183) for the loss term:
+ * rank==1: rows [0,N/2) positives, [N/2,N) their negatives, loss = -sum log sigmoid(pos-neg); rank==0: MSE vs Y.
+ * Writes prediction [N], loss [1] (device scalar) and accumulates the four gradients. */
+int dccf_train_fwdbwd(dccf_ctx* ctx, const dccf_model_t* model, const dccf_rand_t* rnd, const int64_t* X,
+                      const float* Y, int64_t N, int32_t rank, float dropout, const dccf_grads_t* grads,
+                      float* prediction, float* loss, void* stream);
+
+/* ---- dense regularised optimizer step: replaces `+ model.l2()*l2` in the loss, clip_grad_value_(50) and
+ * torch.optim.{SGD,Adagrad,Adam}(lr, weight_decay=l2).step()  (src/runners/BaseRunner.py:92-100,181-187).
+ *   g_total = clip(g + l2 * 2p, +-clip);  then the optimizer with coupled weight decay `wd` (torch semantics);
+ *   `step` is the 1-based step count (bias correction); s1/s2 are Adam's exp_avg/exp_avg_sq or Adagrad's sum (s2 unused);
+ *   zero_grad != 0 writes zeros back into g (the next step's `optimizer.zero_grad()`, src/runners/BaseRunner.py:178). */
+#define DCCF_OPT_GD 0
+#define DCCF_OPT_ADAGRAD 1
+#define DCCF_OPT_ADAM 2
+int dccf_dense_opt_step(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t n, float lr, float wd,
+                        float l2, float clip, int64_t step, int32_t zero_grad, void* stream);
+/* BaseModel.l2 (src/models/BaseModel.py:179-187): out[0] += sum p^2  (out must be zeroed by the caller). */
+int dccf_sumsq(const float* p, int64_t n, float* out, void* stream);
+
+/* ---- MF family: RecModel / BiasedMF / IPSBiasedMF predict (src/models/RecModel.py:38-48, BiasedMF.py:17-33,
+ * IPSBiasedMF.py:37-57) ------------------------------------------------------------------------------------ */
+typedef struct {
+  int64_t user_num, item_num;
+  int32_t D;
+  int32_t kind;           /* 0 RecModel, 1 BiasedMF, 2 IPSBiasedMF */
+  const float* P;         /* uid_embeddings.weight [user_num, D] */
+  const float* Q;         /* iid_embeddings.weight [item_num, D] */
+  const float* bu;        /* user_bias.weight [user_num] (kind>=1) */
+  const float* bi;        /* item_bias.weight [item_num] (kind>=1) */
+  const float* b0;        /* global_bias [1] device scalar (kind>=1) */
+  const float* prop;      /* propensity [item_num] (kind==2) */
+  float M;                /* --M (src/models/IPSBiasedMF.py:14) */
+  float reserved;
+} mf_model_t;
+
+typedef struct { float* gP; float* gQ; float* gbu; float* gbi; float* gb0; } mf_grads_t;
+
+int mf_predict(const mf_model_t* model, const int64_t* X, int64_t N, float* prediction, void* stream);
+int mf_train_fwdbwd(dccf_ctx* ctx, const mf_model_t* model, const int64_t* X, const float* Y, int64_t N, int32_t rank,
+                    const mf_grads_t* grads, float* prediction, float* loss, void* stream);
+/* "save the full predicted user-item matrix as the exposure probability" (README.md:28-30): out [user_num, item_num]. */
+int mf_predict_full(const mf_model_t* model, float* out, void* stream);
+
+/* ---- fused on-device training negatives: replaces DataProcessor._sample_neg_from_uid_list for train=True, neg_n=1
+ * (src/data_processor/DataProcessor.py:446-524).  rows_indptr/rows: the train rows (sample ids) of each user (CSR);
+ * hist_indptr/hist_items: each user's train positives, sorted ascending (CSR).  neg_out[sample_id] = negative item. */
+int dccf_sample_train_negatives(const int64_t* rows_indptr, const int64_t* rows, const int64_t* hist_indptr,
+                                const int64_t* hist_items, int64_t user_num, int64_t item_num, uint64_t seed,
+                                uint64_t epoch, int64_t* neg_out, void* stream);
+
+/* ---- the fused-mode random streams written out (for parity tests: fused == injected on the same draws) ---------- */
+int dccf_debug_candidates(int64_t N, int32_t S, int64_t item_num, uint64_t seed, uint64_t step, int64_t* out, void* stream);
+int dccf_debug_noise(int64_t L, int32_t F, float std, uint64_t seed, uint64_t step, float* out, void* stream);
+int dccf_debug_keep(int64_t L, int32_t D, float dropout, uint64_t seed, uint64_t step, uint8_t* out, void* stream);
+
+/* Copies one workspace array of the last call with these shapes to dst (device; NULL = only fill info[4] =
+ * {DP, FP, element count, element size}).  which: 0 cand(int32) 1 WT 2 base 3 h/dz 4 m 5 dmns 6 dzn.  Tests only. */
+int dccf_debug_workspace(dccf_ctx* ctx, int64_t N, int32_t D, int32_t F, int32_t S, int32_t A, int32_t which, void* dst,
+                         int64_t* info, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCCF_HIP_H */

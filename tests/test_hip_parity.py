@@ -1,0 +1,376 @@
+# coding=utf-8
+"""Parity of the HIP path (through the C ABI) against the golden vectors of the reference and against the oracle.
+Run on the GPU box:  python -m pytest tests -m gpu"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import dccf_oracle as O
+from oracle import philox as PH
+
+pytestmark = pytest.mark.gpu
+
+DCCF_CASES = ['dccf_d16_f32_adam', 'dccf_d64_f768_adam', 'dccf_d64_f32_nodrop_gd', 'dccf_d32_f160_adagrad',
+              'dccf_d128_f768_adam', 'dccf_d64_f768_mse']
+PKEYS = ['uid_embeddings.weight', 'iid_embeddings.weight', 'mlp.0.weight', 'mlp.0.bias']
+
+# fp32 tolerances (relative to the largest magnitude of the compared tensor): summation order differs between
+# ATen / numpy / the MFMA k-order, and float atomics reorder the scatter sums.
+FWD_RTOL, FWD_ATOL = 3e-5, 1e-6
+GRAD_RTOL, GRAD_ATOL = 1e-4, 2e-6
+PARAM_RTOL, PARAM_ATOL = 3e-5, 2e-7
+# After an optimizer step: Adam/Adagrad move every element by ~lr * g/|g|, which turns the RELATIVE error of a small
+# gradient element into an absolute parameter error of lr * rel_err; agreement is therefore stated in fractions of one
+# step: 0.5 % of lr on top of the fp32 tolerance above.
+STEP_FRAC = 5e-3
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def T(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(dev()).contiguous()
+
+
+def close(a, b, rtol, atol, what=''):
+    a = a.detach().cpu().numpy().astype(np.float64) if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(np.abs(b).max(), 1e-30)
+    err = np.abs(a - b).max()
+    assert err <= atol + rtol * scale, '%s: max err %g (scale %g)' % (what, err, scale)
+
+
+@pytest.fixture(scope='module')
+def L():
+    from dccf_amd import _lib
+    _lib.load()
+    return _lib
+
+
+@pytest.fixture(scope='module')
+def ctx(L):
+    return L.Context(0)
+
+
+class FlatParams(object):
+    """One flat fp32 buffer [U | V | W | b] with views, plus grads and optimizer state — how the host side holds them."""
+
+    def __init__(self, P):
+        self.keys = list(P.keys())
+        sizes = [int(np.prod(P[k].shape)) for k in self.keys]
+        pad = [(s + 3) // 4 * 4 for s in sizes]
+        n = sum(pad)
+        self.p = torch.zeros(n, dtype=torch.float32, device=dev())
+        self.g = torch.zeros_like(self.p)
+        self.s1 = torch.zeros_like(self.p)
+        self.s2 = torch.zeros_like(self.p)
+        self.views, self.gviews = {}, {}
+        o = 0
+        for k, s, pd in zip(self.keys, sizes, pad):
+            self.views[k] = self.p[o:o + s].view(*P[k].shape)
+            self.gviews[k] = self.g[o:o + s].view(*P[k].shape)
+            self.views[k].copy_(T(P[k]))
+            o += pd
+
+
+@pytest.mark.parametrize('name', DCCF_CASES)
+def test_dccf_injected_train_steps_match_reference(L, ctx, name):
+    g = load_golden(name)
+    A, S, p, rank = int(g['A']), int(g['S']), float(g['dropout']), int(g['rank'])
+    fp = FlatParams({k: g['init/' + k] for k in PKEYS})
+    feat, expo = T(g['feat']), T(g['expo'])
+    kind = str(g['optimizer']).lower()
+    for s in range(int(g['steps'])):
+        pre = 's%d/' % s
+        v = fp.views
+        m = L.model_struct(v[PKEYS[0]], v[PKEYS[1]], v[PKEYS[2]], v[PKEYS[3]], feat, expo, S, A, float(g['std']))
+        X, Y = T(g[pre + 'X']), T(g[pre + 'Y'])
+        r = L.rand_struct(sample_item=T(g[pre + 'sample_item']), noise=T(g[pre + 'noise']),
+                          keep=T(g[pre + 'mask']) if p > 0 else None)
+        # predict-only entry point on the same draws
+        close(L.dccf_predict(ctx, m, r, X, p), g[pre + 'prediction'], FWD_RTOL, FWD_ATOL, name + ' predict')
+        gv = fp.gviews
+        pred, loss = L.dccf_train_fwdbwd(ctx, m, r, X, Y, rank, p, gv[PKEYS[0]], gv[PKEYS[1]], gv[PKEYS[2]], gv[PKEYS[3]])
+        close(pred, g[pre + 'prediction'], FWD_RTOL, FWD_ATOL, name + ' pred')
+        close(loss, g[pre + 'loss'].reshape(1), FWD_RTOL, FWD_ATOL, name + ' loss')
+        for k in PKEYS:
+            close(gv[k], g[pre + 'gloss/' + k], GRAD_RTOL, GRAD_ATOL, name + ' gloss ' + k)
+        close(L.sumsq(fp.p), g[pre + 'l2'].reshape(1), 1e-5, 0, name + ' l2')
+        L.dense_opt_step(kind, fp.p, fp.g, fp.s1, fp.s2, float(g['lr']), float(g['l2']), float(g['l2']), 50.0, s + 1)
+        assert float(fp.g.abs().max()) == 0.0     # fused zero_grad
+        for k in PKEYS:
+            close(fp.views[k], g[pre + 'after/' + k], PARAM_RTOL, PARAM_ATOL + STEP_FRAC * float(g['lr']), name + ' after ' + k)
+
+
+@pytest.mark.parametrize('name', DCCF_CASES)
+def test_dccf_injected_eval_predict(L, ctx, name):
+    g = load_golden(name)
+    last = 's%d/after/' % (int(g['steps']) - 1)
+    P = [T(g[last + k]) for k in PKEYS]
+    m = L.model_struct(P[0], P[1], P[2], P[3], T(g['feat']), T(g['expo']), int(g['S']), int(g['A']), float(g['std']))
+    r = L.rand_struct(sample_item=T(g['eval/sample_item']), noise=T(g['eval/noise']))
+    close(L.dccf_predict(ctx, m, r, T(g['eval/X']), 0.0), g['eval/prediction'], FWD_RTOL, FWD_ATOL, name + ' eval')
+
+
+def test_fused_streams_match_oracle(L):
+    """The on-device random streams against oracle/philox.py: integers bit-exact, normals to fp32 rounding."""
+    seed, step = 0x1234567890ABCDEF, 77
+    c = L.debug_candidates(37, 10, 5000, seed, step, dev()).cpu().numpy()
+    assert np.array_equal(c, PH.candidates(seed, step, 37, 10, 5000))
+    assert c.min() >= 0 and c.max() < 5000
+    for p in (0.2, 0.5):
+        k = L.debug_keep(201, 64, p, seed, step, dev()).cpu().numpy()
+        assert np.array_equal(k, PH.dropout_keep(seed, step, 201, 64, float(np.float32(p))))
+    assert L.debug_keep(50, 64, 0.0, seed, step, dev()).cpu().numpy().min() == 1
+    for F in (32, 160, 768):
+        z = L.debug_noise(97, F, 0.1, seed, step, dev()).cpu().numpy()
+        zo = PH.noise(seed, step, 97, F, 0.1)
+        assert np.abs(z - zo).max() <= 2e-6 * 0.1 * 6 + 1e-7, np.abs(z - zo).max()
+    # distribution sanity of the device normals
+    z = L.debug_noise(4096, 768, 1.0, 99, 3, dev()).double()
+    assert abs(float(z.mean())) < 2e-3 and abs(float(z.std()) - 1.0) < 2e-3
+    assert abs(float((z ** 4).mean()) - 3.0) < 3e-2
+
+
+@pytest.mark.parametrize('D,F,S,A,p,rank', [(64, 768, 10, 2, 0.2, 1), (16, 32, 10, 2, 0.2, 1), (128, 768, 10, 2, 0.2, 1),
+                                            (32, 160, 4, 3, 0.5, 0), (64, 768, 10, 2, 0.0, 1)])
+def test_fused_equals_injected_on_device_draws(L, ctx, D, F, S, A, p, rank):
+    """Fused mode (Philox in registers) must equal injected mode fed with the very same draws written out by the
+    debug entry points — and both must equal the oracle on those draws."""
+    rng = np.random.RandomState(D + F)
+    U_, I_, pairs = 300, 200, 37
+    N = 2 * pairs
+    P = {'uid_embeddings.weight': (rng.randn(U_, D) * 0.3).astype(np.float32),
+         'iid_embeddings.weight': (rng.randn(I_, D) * 0.3).astype(np.float32),
+         'mlp.0.weight': (rng.randn(D, D + F) * 0.1).astype(np.float32),
+         'mlp.0.bias': (rng.randn(D) * 0.1).astype(np.float32)}
+    feat = (rng.randn(I_, F) * 0.5).astype(np.float32)
+    expo = rng.randn(U_, I_).astype(np.float32)
+    u = rng.randint(0, U_, pairs)
+    X = np.concatenate([np.stack([u, rng.randint(0, I_, pairs)], 1), np.stack([u, rng.randint(0, I_, pairs)], 1)]).astype(np.int64)
+    Y = rng.randint(0, 2, N).astype(np.float32)
+    seed, step, std = 20191104, 5, 0.1
+    Ld = N * (S + 1) * A
+    tp = {k: T(v) for k, v in P.items()}
+    m = L.model_struct(tp[PKEYS[0]], tp[PKEYS[1]], tp[PKEYS[2]], tp[PKEYS[3]], T(feat), T(expo), S, A, std)
+    si = L.debug_candidates(N, S, I_, seed, step, dev())
+    nz = L.debug_noise(Ld, F, std, seed, step, dev())
+    kp = L.debug_keep(Ld, D, p, seed, step, dev())
+    outs = []
+    for r in (L.rand_struct(seed=seed, step=step), L.rand_struct(sample_item=si, noise=nz, keep=kp if p > 0 else None)):
+        gr = [torch.zeros_like(tp[k]) for k in PKEYS]
+        pred, loss = L.dccf_train_fwdbwd(ctx, m, r, T(X), T(Y), rank, p, *gr)
+        torch.cuda.synchronize()
+        outs.append((pred.cpu().numpy(), loss.cpu().numpy(), [x.cpu().numpy() for x in gr]))
+    # same arithmetic, same order -> forward bit-exact; grads equal up to atomic ordering
+    assert np.array_equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][2], outs[1][2]):
+        close(a, b, 2e-6, 1e-8, 'fused vs injected grads')
+    fw = O.dccf_forward(P, feat, expo, X, si.cpu().numpy(), nz.cpu().numpy(), kp.cpu().numpy(), p, A)
+    close(outs[0][0], fw['prediction'], FWD_RTOL, FWD_ATOL, 'fused pred vs oracle')
+    loss, dpred = O.loss_and_dpred(fw['prediction'], Y, rank)
+    close(outs[0][1], np.asarray(loss).reshape(1), FWD_RTOL, FWD_ATOL, 'fused loss vs oracle')
+    grads = O.dccf_backward(P, fw, dpred, A)
+    for k, a in zip(PKEYS, outs[0][2]):
+        close(a, grads[k], GRAD_RTOL, GRAD_ATOL, 'fused grad vs oracle ' + k)
+
+
+def test_dccf_on_the_fly_exposure_equals_dense(L, ctx):
+    """expo == NULL: exposure computed from the IPSBiasedMF factors must equal the dense-matrix path fed with
+    mf_predict_full of the same factors (README.md:28-30)."""
+    rng = np.random.RandomState(3)
+    U_, I_, D, F, S, A = 150, 260, 64, 768, 10, 2
+    ips = dict(P=T((rng.randn(U_, 32) * 0.3).astype(np.float32)), Q=T((rng.randn(I_, 32) * 0.3).astype(np.float32)),
+               bu=T((rng.randn(U_) * 0.1).astype(np.float32)), bi=T((rng.randn(I_) * 0.1).astype(np.float32)),
+               prop=T(rng.rand(I_).astype(np.float32)), b0=0.1, M=0.1)
+    b0 = torch.full((1,), 0.1, device=dev())
+    mf = L.mf_struct('IPSBiasedMF', ips['P'], ips['Q'], ips['bu'], ips['bi'], b0, ips['prop'], 0.1)
+    dense = L.mf_predict_full(mf, device=dev())
+    Pm = [T((rng.randn(U_, D) * 0.3).astype(np.float32)), T((rng.randn(I_, D) * 0.3).astype(np.float32)),
+          T((rng.randn(D, D + F) * 0.1).astype(np.float32)), T((rng.randn(D) * 0.1).astype(np.float32))]
+    feat = T((rng.randn(I_, F) * 0.5).astype(np.float32))
+    X = T(np.stack([rng.randint(0, U_, 64), rng.randint(0, I_, 64)], 1).astype(np.int64))
+    r = L.rand_struct(seed=11, step=1)
+    a = L.dccf_predict(ctx, L.model_struct(Pm[0], Pm[1], Pm[2], Pm[3], feat, dense, S, A, 0.1), r, X, 0.0)
+    b = L.dccf_predict(ctx, L.model_struct(Pm[0], Pm[1], Pm[2], Pm[3], feat, None, S, A, 0.1, ips=ips), r, X, 0.0)
+    close(a, b.cpu().numpy(), 2e-5, 1e-6, 'on-the-fly exposure')
+
+
+@pytest.mark.parametrize('kind', ['RecModel', 'BiasedMF', 'IPSBiasedMF'])
+def test_mf_family_matches_reference(L, ctx, kind):
+    g = load_golden('mf_' + kind.lower())
+    keys = [k[5:] for k in g if k.startswith('init/')]
+    fp = FlatParams({k: g['init/' + k].reshape(-1) if g['init/' + k].ndim == 0 else g['init/' + k] for k in keys})
+    prop = T(g['propensity']) if kind == 'IPSBiasedMF' else None
+
+    def struct():
+        v = fp.views
+        if kind == 'RecModel':
+            return L.mf_struct(kind, v['uid_embeddings.weight'], v['iid_embeddings.weight'])
+        return L.mf_struct(kind, v['uid_embeddings.weight'], v['iid_embeddings.weight'], v['user_bias.weight'].view(-1),
+                           v['item_bias.weight'].view(-1), v['global_bias'].view(-1), prop, float(g['M']))
+
+    for s in range(2):
+        pre = 's%d/' % s
+        X, Y = T(g[pre + 'X']), T(g[pre + 'Y'])
+        m = struct()
+        close(L.mf_predict(m, X), g[pre + 'prediction'], FWD_RTOL, FWD_ATOL, kind + ' predict')
+        gv = fp.gviews
+        if kind == 'RecModel':
+            pred, loss = L.mf_train_fwdbwd(ctx, m, X, Y, 1, gv['uid_embeddings.weight'], gv['iid_embeddings.weight'])
+        else:
+            pred, loss = L.mf_train_fwdbwd(ctx, m, X, Y, 1, gv['uid_embeddings.weight'], gv['iid_embeddings.weight'],
+                                           gv['user_bias.weight'].view(-1), gv['item_bias.weight'].view(-1),
+                                           gv['global_bias'].view(-1))
+        close(pred, g[pre + 'prediction'], FWD_RTOL, FWD_ATOL, kind + ' pred')
+        close(loss, g[pre + 'loss'].reshape(1), FWD_RTOL, FWD_ATOL, kind + ' loss')
+        for k in keys:
+            close(gv[k].view(g[pre + 'gloss/' + k].shape), g[pre + 'gloss/' + k], GRAD_RTOL, GRAD_ATOL, kind + ' gloss ' + k)
+        L.dense_opt_step('adam', fp.p, fp.g, fp.s1, fp.s2, float(g['lr']), float(g['l2']), float(g['l2']), 50.0, s + 1)
+        for k in keys:
+            atol = 1e-5 if k == 'global_bias' else PARAM_ATOL + STEP_FRAC * float(g['lr'])   # see tests/test_oracle_golden.py
+            close(fp.views[k].view(g[pre + 'after/' + k].shape), g[pre + 'after/' + k], PARAM_RTOL, atol, kind + ' after ' + k)
+    close(L.mf_predict_full(struct(), device=dev()), g['full'], FWD_RTOL, FWD_ATOL, kind + ' full matrix')
+
+
+def test_mf_train_mse_and_duplicates_vs_oracle(L, ctx):
+    """rank==0 (MSE) and a batch full of duplicate users/items (exercises the LDS duplicate-row chains)."""
+    rng = np.random.RandomState(8)
+    U_, I_, D, N = 9, 7, 64, 333
+    P = {'uid_embeddings.weight': rng.randn(U_, D).astype(np.float32) * 0.3,
+         'iid_embeddings.weight': rng.randn(I_, D).astype(np.float32) * 0.3,
+         'user_bias.weight': rng.randn(U_, 1).astype(np.float32) * 0.1,
+         'item_bias.weight': rng.randn(I_, 1).astype(np.float32) * 0.1,
+         'global_bias': np.float32(0.1)}
+    prop = rng.rand(I_).astype(np.float32)
+    X = np.stack([rng.randint(0, U_, N), rng.randint(0, I_, N)], 1).astype(np.int64)
+    Y = rng.randint(0, 2, N).astype(np.float32)
+    pred_o, fw = O.mf_forward(P, X, 'IPSBiasedMF', prop, 0.1)
+    loss_o, dpred = O.loss_and_dpred(pred_o, Y, 0)
+    go = O.mf_backward(P, fw, dpred, 'IPSBiasedMF')
+    t = {k: T(np.asarray(v).reshape(-1) if np.ndim(v) == 0 else v) for k, v in P.items()}
+    m = L.mf_struct('IPSBiasedMF', t['uid_embeddings.weight'], t['iid_embeddings.weight'], t['user_bias.weight'].view(-1),
+                    t['item_bias.weight'].view(-1), t['global_bias'], T(prop), 0.1)
+    gr = {k: torch.zeros_like(v) for k, v in t.items()}
+    pred, loss = L.mf_train_fwdbwd(ctx, m, T(X), T(Y), 0, gr['uid_embeddings.weight'], gr['iid_embeddings.weight'],
+                                   gr['user_bias.weight'].view(-1), gr['item_bias.weight'].view(-1), gr['global_bias'])
+    close(pred, pred_o, FWD_RTOL, FWD_ATOL, 'mse pred')
+    close(loss, np.asarray(loss_o).reshape(1), FWD_RTOL, FWD_ATOL, 'mse loss')
+    for k in P:
+        close(gr[k].view(np.shape(go[k]) or (1,)), np.asarray(go[k]).reshape(np.shape(go[k]) or (1,)), GRAD_RTOL, GRAD_ATOL, 'mse grad ' + k)
+
+
+@pytest.mark.parametrize('name', ['gd', 'adagrad', 'adam'])
+def test_dense_optimizer_matches_reference(L, name):
+    g = load_golden('opt_' + name)
+    keys = [k[5:] for k in g if k.startswith('init/')]
+    fp = FlatParams({k: g['init/' + k] for k in keys})
+    for s in range(int(g['steps'])):
+        pre = 's%d/' % s
+        for k in keys:
+            fp.gviews[k].copy_(T(g[pre + 'sparse/' + k]))
+        L.dense_opt_step(name, fp.p, fp.g, fp.s1, fp.s2, float(g['lr']), float(g['l2']), float(g['l2']), 50.0, s + 1,
+                         zero_grad=(s % 2 == 0))
+        if s % 2 == 1:
+            fp.g.zero_()
+        for k in keys:
+            close(fp.views[k], g[pre + 'after/' + k], 1e-5, 1e-7, name + ' after ' + k)
+
+
+def test_dense_optimizer_tail_and_large(L):
+    """n not a multiple of 4 and n larger than one grid sweep, against the oracle's optimizer."""
+    rng = np.random.RandomState(2)
+    for n in (1, 7, 1027, 3 * 1024 * 1024 + 5):
+        p0 = rng.randn(n).astype(np.float32)
+        g0 = (rng.randn(n) * 30).astype(np.float32)
+        n_pad = (n + 3) // 4 * 4
+        buf = torch.zeros(4, n_pad, dtype=torch.float32, device=dev())
+        buf[0, :n] = T(p0)
+        opt = O.DenseOptimizer('adam', 0.01, 1e-3)
+        P = {'p': p0.copy()}
+        for step in (1, 2):
+            buf[1, :n] = T(g0)
+            L.dense_opt_step('adam', buf[0, :n], buf[1, :n], buf[2, :n], buf[3, :n], 0.01, 1e-3, 1e-3, 50.0, step)
+            P, _ = O.train_step(P, opt, 1e-3, {'p': g0})
+            close(buf[0, :n], P['p'], 1e-5, 1e-7, 'adam n=%d step %d' % (n, step))
+
+
+def test_train_negative_sampler_matches_oracle(L):
+    rng = np.random.RandomState(4)
+    U_, I_ = 300, 120
+    uids, hist = [], []
+    indptr = [0]
+    for u in range(U_):
+        deg = int(rng.randint(0, 40)) if u != 7 else 110      # user 7: fewer than 20 % of the items remain
+        items = np.sort(rng.choice(I_, size=min(deg, I_ - 2), replace=False))
+        hist.append(items)
+        indptr.append(indptr[-1] + len(items))
+        k = len(items) if u != 7 else 5
+        uids.extend([u] * k)
+    uids = np.array(uids, dtype=np.int64)
+    perm = rng.permutation(len(uids))
+    uids = uids[perm]                                  # sample-id order
+    hist_items = np.concatenate(hist).astype(np.int64)
+    hist_indptr = np.array(indptr, dtype=np.int64)
+    order = np.argsort(uids, kind='stable')
+    rows = order.astype(np.int64)                      # rows of each user in ascending sample id
+    rows_indptr = np.searchsorted(uids[order], np.arange(U_ + 1)).astype(np.int64)
+    for epoch in (0, 3):
+        out = L.sample_train_negatives(T(rows_indptr), T(rows), T(hist_indptr), T(hist_items), U_, I_, 2019, epoch).cpu().numpy()
+        ref = PH.train_negatives(2019, epoch, uids, I_, hist_indptr, hist_items)
+        assert np.array_equal(out, ref)
+        for u in range(U_):
+            mine = out[uids == u]
+            assert len(set(mine.tolist())) == len(mine)                      # distinct within the epoch
+            assert not set(mine.tolist()) & set(hist[u].tolist())            # never a train positive
+        assert 0 not in out[uids == 7]                                       # low-remaining regime skips item 0
+    a = L.sample_train_negatives(T(rows_indptr), T(rows), T(hist_indptr), T(hist_items), U_, I_, 2019, 0).cpu().numpy()
+    b = L.sample_train_negatives(T(rows_indptr), T(rows), T(hist_indptr), T(hist_items), U_, I_, 2019, 1).cpu().numpy()
+    assert not np.array_equal(a, b)
+
+
+def test_argument_errors_are_reported(L, ctx):
+    t = torch.zeros(4, 16, device=dev())
+    with pytest.raises(RuntimeError):
+        L.dense_opt_step('adam', t.view(-1), t.view(-1), None, None, 0.1, 0, 0, 50, 1)
+    with pytest.raises(RuntimeError):
+        L.dense_opt_step('adam', torch.zeros(4), torch.zeros(4), torch.zeros(4), torch.zeros(4), 0.1, 0, 0, 50, 1)  # CPU tensors
+    W = torch.zeros(24, 24 + 8, device=dev())
+    m = L.model_struct(torch.zeros(5, 24, device=dev()), torch.zeros(5, 24, device=dev()), W, torch.zeros(24, device=dev()),
+                       torch.zeros(5, 8, device=dev()), torch.zeros(5, 5, device=dev()), 10, 2, 0.1)
+    with pytest.raises(RuntimeError, match='D must be'):
+        L.dccf_predict(ctx, m, L.rand_struct(seed=1), torch.zeros(2, 2, dtype=torch.int64, device=dev()), 0.0)
+    # empty batch is legal
+    m = L.model_struct(torch.zeros(5, 16, device=dev()), torch.zeros(5, 16, device=dev()), torch.zeros(16, 24, device=dev()),
+                       torch.zeros(16, device=dev()), torch.zeros(5, 8, device=dev()), torch.zeros(5, 5, device=dev()), 10, 2, 0.1)
+    out = L.dccf_predict(ctx, m, L.rand_struct(seed=1), torch.zeros(0, 2, dtype=torch.int64, device=dev()), 0.0)
+    assert out.shape == (0,)
+
+
+def test_large_batch_properties(L, ctx):
+    """At eval size (N = 16384 rows, the reference's eval_batch_size) the oracle is too slow; check size-independent
+    properties: determinism of the fused draws, a different step gives different draws, and splitting the batch
+    gives the same predictions row by row (rows are independent given the counters' row index)."""
+    rng = np.random.RandomState(6)
+    U_, I_, D, F, S, A, N = 2000, 3000, 64, 768, 10, 2, 16384
+    Pm = [T((rng.randn(U_, D) * 0.3).astype(np.float32)), T((rng.randn(I_, D) * 0.3).astype(np.float32)),
+          T((rng.randn(D, D + F) * 0.05).astype(np.float32)), T((rng.randn(D) * 0.1).astype(np.float32))]
+    feat = T((rng.randn(I_, F) * 0.5).astype(np.float32))
+    expo = T(rng.randn(U_, I_).astype(np.float32))
+    m = L.model_struct(Pm[0], Pm[1], Pm[2], Pm[3], feat, expo, S, A, 0.1)
+    X = T(np.stack([rng.randint(0, U_, N), rng.randint(0, I_, N)], 1).astype(np.int64))
+    a = L.dccf_predict(ctx, m, L.rand_struct(seed=5, step=9), X, 0.0).clone()
+    b = L.dccf_predict(ctx, m, L.rand_struct(seed=5, step=9), X, 0.0).clone()
+    c = L.dccf_predict(ctx, m, L.rand_struct(seed=5, step=10), X, 0.0).clone()
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert bool(torch.isfinite(a).all())
+    head = L.dccf_predict(ctx, m, L.rand_struct(seed=5, step=9), X[:4096].contiguous(), 0.0)
+    assert torch.equal(head, a[:4096])
+    # Monte-Carlo consistency: the mean over many noise draws approaches the noise-free score's neighbourhood
+    close(a.mean().reshape(1), c.mean().reshape(1).cpu().numpy(), 5e-2, 1e-3, 'step-to-step mean')
