@@ -1,0 +1,200 @@
+# coding=utf-8
+"""bench.py — DCCF training throughput on MI355X (BASELINE.json: "train pairs/sec at rank=64 Electronics").
+
+    python bench.py [--gpus N --steps K --warmup W]        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One step = one optimizer step of the reference's training loop (src/runners/BaseRunner.py:175-188) over one batch of
+`--batch_size` (user, positive, sampled negative) pairs: forward (Monte-Carlo exposure-weighted MF score with fresh
+Gaussian feature noise), BPR loss, backward into dense-shaped gradients, and the dense l2 + clip + Adam update of EVERY
+parameter.  Workload (config.workload): Electronics-shaped synthetic interactions (user_num / item_num below, Zipf item
+popularity), D = 64, the 768-d feature table, dense U x I exposure matrix and both embedding tables resident in HBM;
+candidates, noise, dropout masks and training negatives are drawn on the device.  Inputs are in HBM when timing starts.
+
+The JSON line carries `roofline` (dominant kernel by measured time, HIP events on the launch stream) and `cpu_baseline`
+(oracle/torch_port.py, the reference's op sequence on the host cores, bounded sample) as the task contract asks.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix (v_mfma_f32_32x32x2_f32) dense peak
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=300)
+    p.add_argument('--warmup', type=int, default=30)
+    p.add_argument('--batch_size', type=int, default=128, help='pairs per step (reference default 128)')
+    p.add_argument('--users', type=int, default=192403, help='Amazon Electronics 5-core order of magnitude')
+    p.add_argument('--items', type=int, default=63001)
+    p.add_argument('--dim', type=int, default=64)
+    p.add_argument('--feat', type=int, default=768)
+    p.add_argument('--expo', type=str, default='auto', help='dense | factors | auto (dense when it fits one GPU)')
+    p.add_argument('--cpu_baseline', type=int, default=1)
+    p.add_argument('--cpu_steps', type=int, default=60)
+    p.add_argument('--seed', type=int, default=2019)
+    return p.parse_args()
+
+
+def synthetic_interactions(n, users, items, seed):
+    """Electronics-shaped: users uniform, items Zipf(0.8) over a random permutation."""
+    rng = np.random.RandomState(seed)
+    w = 1.0 / np.power(np.arange(1, items + 1, dtype=np.float64), 0.8)
+    w /= w.sum()
+    perm = rng.permutation(items)
+    uid = rng.randint(0, users, size=n).astype(np.int64)
+    iid = perm[rng.choice(items, size=n, p=w)].astype(np.int64)
+    key = np.unique(uid * items + iid)
+    rng.shuffle(key)
+    return key // items, key % items
+
+
+def cpu_baseline(args, feat_cpu, seed):
+    """The reference's op sequence on the host (oracle/torch_port.py), bounded: `cpu_steps` steps of the same batch
+    size on the full-size embedding tables; exposure rows only for the 2000 users the sample touches."""
+    from oracle import torch_port as TP
+    us = 2000
+    g = torch.Generator().manual_seed(seed)
+    expo_rows = torch.randn(us, args.items, generator=g)
+    model = TP.DCCFPort(args.users, args.items, args.dim, feat_cpu, expo_rows, seed=seed)
+    batches = TP.synthetic_batches(us, args.items, args.batch_size, args.cpu_steps + 3, seed=seed)
+    TP.train_steps(model, batches[:3])
+    t0 = time.time()
+    TP.train_steps(model, batches[3:])
+    dt = time.time() - t0
+    return {'value': args.cpu_steps * args.batch_size / dt, 'unit': 'pairs/s', 'cores': torch.get_num_threads(),
+            'kind': 'port',
+            'sample': '%d steps of batch_size %d (reference op sequence in PyTorch-CPU, full-size embedding tables, '
+                      'exposure rows of 2000 users), %.1f s' % (args.cpu_steps, args.batch_size, dt)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d'
+                             % (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+        from dccf_amd import sharded
+        return sharded.bench_main(args, rank, world, dev)
+
+    from dccf_amd import _lib as L
+    from dccf_amd.models import DCCF, FusedOptimizer
+    from dccf_amd.data_processor import DeviceTrainSet
+
+    U, I, D, F, B = args.users, args.items, args.dim, args.feat, args.batch_size
+    S, A, std, p_drop, lr, l2 = 10, 2, 0.1, 0.2, 1e-3, 1e-4
+    g = torch.Generator(device=dev).manual_seed(args.seed)
+    feat = torch.randn(I, F, generator=g, device=dev) * 0.05
+    expo_mode = args.expo
+    if expo_mode == 'auto':
+        expo_mode = 'dense' if U * I * 4 < 160e9 else 'factors'
+    expo, ips = None, None
+    if expo_mode == 'dense':
+        expo = torch.empty(U, I, device=dev)
+        rows = max(1, (1 << 30) // (4 * I))
+        for r0 in range(0, U, rows):
+            expo[r0:r0 + rows].normal_(generator=g)
+    else:
+        ips = dict(P=torch.randn(U, 64, generator=g, device=dev) * 0.1, Q=torch.randn(I, 64, generator=g, device=dev) * 0.1,
+                   bu=torch.randn(U, generator=g, device=dev) * 0.1, bi=torch.randn(I, generator=g, device=dev) * 0.1,
+                   prop=torch.rand(I, generator=g, device=dev), b0=0.1, M=0.1)
+    model = DCCF(path=None, dataset=None, sentence_model=None, sample_num=S, attribute_num=A, std=std, label_min=0,
+                 label_max=1, feature_num=0, user_num=U, item_num=I, u_vector_size=D, i_vector_size=D, n_layers=1,
+                 random_seed=args.seed, model_path='/tmp/bench.pt', feature_embedding=feat, expo_prob=expo, ips_factors=ips)
+    model.apply(model.init_paras)
+    opt = FusedOptimizer(model, 'adam', lr, l2)
+    model.optimizer = opt
+    model.train()
+
+    n_pairs = (args.steps + args.warmup + 2) * B
+    uid, iid = synthetic_interactions(int(n_pairs * 1.15) + 1000, U, I, args.seed)
+    uid, iid = uid[:n_pairs], iid[:n_pairs]
+    ds = DeviceTrainSet(uid, iid, U, I, args.seed)
+    model.ctx.reserve(2 * B, D, F, S, A)
+    y = torch.cat([torch.ones(B, device=dev), torch.zeros(B, device=dev)])
+    batch = {'Y': y, 'rank': 1, 'train': True, 'dropout': p_drop}
+
+    def run(full, k0, k1, events=None):
+        for k in range(k0, k1):
+            batch['X'] = full[k]
+            model(batch)
+            if events is not None:
+                events[k - k0][0].record()
+            opt.step()
+            if events is not None:
+                events[k - k0][1].record()
+
+    full, _ = ds.epoch_batches(0, B)             # warm-up epoch: its own negatives
+    run(full, 0, args.warmup)
+    torch.cuda.synchronize()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    model.ctx.profile(True)
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    full, _ = ds.epoch_batches(1, B)             # timed: the epoch's negative sampling + batch views are inside
+    run(full, args.warmup, args.warmup + args.steps, events)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+
+    prof = model.ctx.profile_read()
+    model.ctx.profile(False)
+    opt_ms = sum(a.elapsed_time(b) for a, b in events) / args.steps
+    kernels = {k: v[0] / max(v[1], 1) for k, v in prof.items()}     # ms per launch
+    kernels['dense_adam'] = opt_ms
+    n_params = model.flat_p.numel()
+    L_rows = 2 * B * (S + 1) * A
+    # algorithmic work per launch: dense Adam 28 B/param; noise GEMMs 2*L*F*D flop each
+    cand = {
+        'dense_adam': dict(bound='hbm', work=28.0 * n_params / 1e9, unit='GB/s', peak=HBM_PEAK_GBS),
+        'noise_fwd': dict(bound='mfma', work=2.0 * L_rows * F * D / 1e12, unit='TFLOP/s', peak=MFMA_F32_PEAK_TFLOPS),
+        'noise_bwd_eps': dict(bound='mfma', work=2.0 * L_rows * F * D / 1e12, unit='TFLOP/s', peak=MFMA_F32_PEAK_TFLOPS),
+    }
+    dom = max(cand, key=lambda k: kernels.get(k, 0.0))
+    c = cand[dom]
+    achieved = c['work'] / (kernels[dom] / 1e3)
+    roofline = {'kernel': dom, 'bound': c['bound'], 'achieved': round(achieved, 2), 'peak': c['peak'], 'unit': c['unit'],
+                'frac': round(achieved / c['peak'], 4), 'traffic': None,
+                'avg_launch_ms': round(kernels[dom], 5)}
+    value = args.steps * B / dt
+    out = {
+        'metric': 'train pairs/sec at rank=64 Electronics', 'value': round(value, 1), 'unit': 'pairs/s', 'n_gpus': 1,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'DCCF train step (fwd + BPR + bwd + dense l2/clip/Adam), Electronics-shaped synthetic: '
+                               'user_num=%d item_num=%d D=%d F=%d S=%d A=%d, exposure=%s, fused on-device negatives'
+                               % (U, I, D, F, S, A, expo_mode),
+                   'batch_size': B, 'optimizer': 'Adam lr=1e-3 l2=1e-4 dropout=0.2', 'params': n_params},
+        'roofline': roofline,
+        'kernel_ms': {k: round(v, 5) for k, v in sorted(kernels.items())},
+        'embedding_fwd_bwd': {   # 4D(3+6(S+1)) + 8F + 8(S+1) + 32 algorithmic bytes per pair
+            'bytes_per_pair': 4 * D * (3 + 6 * (S + 1)) + 8 * F + 8 * (S + 1) + 32,
+            'kernel_ms': round(sum(v for k, v in kernels.items() if k != 'dense_adam'), 5)},
+    }
+    ebp = out['embedding_fwd_bwd']
+    ebp['achieved_GBps'] = round(B * ebp['bytes_per_pair'] / (ebp['kernel_ms'] / 1e3) / 1e9, 2)
+    if args.cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(args, feat.cpu(), args.seed)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == '__main__':
+    main()

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(HERE, 'lib', 'libdccf_hip.so')
 EXPORTS = ['dccf_ctx_create', 'dccf_ctx_destroy', 'dccf_ctx_reserve', 'dccf_last_error', 'dccf_abi_version',
            'dccf_predict', 'dccf_train_fwdbwd', 'dccf_dense_opt_step', 'dccf_sumsq', 'mf_predict', 'mf_train_fwdbwd',
            'mf_predict_full', 'dccf_sample_train_negatives', 'dccf_debug_candidates', 'dccf_debug_noise',
-           'dccf_debug_keep', 'dccf_debug_workspace']
+           'dccf_debug_keep', 'dccf_debug_workspace', 'dccf_profile', 'dccf_profile_read']
 
 OPT_KIND = {'gd': 0, 'adagrad': 1, 'adam': 2}
 MF_KIND = {'RecModel': 0, 'BiasedMF': 1, 'IPSBiasedMF': 2}
@@ -67,6 +67,8 @@ def load():
         'dccf_ctx_create': [C.POINTER(vp), C.c_int],
         'dccf_ctx_destroy': [vp],
         'dccf_ctx_reserve': [vp, i64, i32, i32, i32, i32],
+        'dccf_profile': [vp, C.c_int],
+        'dccf_profile_read': [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
         'dccf_predict': [vp, C.POINTER(ModelT), C.POINTER(RandT), vp, i64, f32, vp, vp],
         'dccf_train_fwdbwd': [vp, C.POINTER(ModelT), C.POINTER(RandT), vp, vp, i64, i32, f32, C.POINTER(GradsT), vp, vp, vp],
         'dccf_dense_opt_step': [i32, vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, i32, vp],
@@ -119,6 +121,17 @@ class Context(object):
 
     def reserve(self, max_rows, D, F, S, A):
         check(load().dccf_ctx_reserve(self.h, int(max_rows), int(D), int(F), int(S), int(A)))
+
+    KERNELS = ['prep', 'base', 'noise_fwd', 'pair_epilogue', 'bwd_small', 'noise_bwd_eps', 'noise_bwd_feat', 'unused']
+
+    def profile(self, enable=True):
+        check(load().dccf_profile(self.h, 1 if enable else 0))
+
+    def profile_read(self):
+        """{kernel: (total ms, launches)} since the last read (synchronises the recorded events)."""
+        ms, cnt = (C.c_double * 8)(), (C.c_int64 * 8)()
+        check(load().dccf_profile_read(self.h, ms, cnt))
+        return {k: (ms[i], cnt[i]) for i, k in enumerate(self.KERNELS) if cnt[i]}
 
     def __del__(self):
         try:

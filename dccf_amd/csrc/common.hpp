@@ -29,11 +29,28 @@ static inline int dccf_fail(int code, const char* msg) {
   } while (0)
 
 // ---------------------------------------------------------------------------------------------- context
+#define DCCF_PROF_SLOTS 8     // 0 prep 1 base 2 noise_fwd 3 pair_epilogue 4 bwd_small 5 noise_bwd(eps) 6 noise_bwd(feat)
+#define DCCF_PROF_EVENTS 16384
 struct dccf_ctx {
   int device;
   char* ws;         // one grow-only slab
   size_t ws_bytes;
+  // optional per-kernel timing with HIP events on the launch stream (dccf_profile / dccf_profile_read)
+  int prof_on;
+  hipEvent_t* ev;
+  int* ev_slot;
+  int ev_used;
 };
+static inline void prof_begin(dccf_ctx* c, hipStream_t st) {
+  if (c->prof_on && c->ev_used + 2 <= DCCF_PROF_EVENTS) (void)hipEventRecord(c->ev[c->ev_used], st);
+}
+static inline void prof_end(dccf_ctx* c, int slot, hipStream_t st) {
+  if (c->prof_on && c->ev_used + 2 <= DCCF_PROF_EVENTS) {
+    (void)hipEventRecord(c->ev[c->ev_used + 1], st);
+    c->ev_slot[c->ev_used >> 1] = slot;
+    c->ev_used += 2;
+  }
+}
 int dccf_ws_ensure(dccf_ctx* ctx, size_t bytes);
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

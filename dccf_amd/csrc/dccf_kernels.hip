@@ -520,16 +520,20 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
   {
     const int64_t total = (int64_t)(D + y.FP) * y.DP + y.NS + (y.GY > 1 ? y.L : 0) + 1;
     const int grid = (int)min((int64_t)2048, (total + 255) / 256);
+    prof_begin(ctx, st);
     hipLaunchKernelGGL(k_prep, dim3(grid), dim3(256), 0, st, M->W, WT, D, F, y.DP, y.FP, X, rnd->sample_item, cand, N,
                        M->S, M->item_num, fused ? 1 : 0, ckey, m, y.GY > 1 ? y.L : (int64_t)0, train ? loss : nullptr);
+    prof_end(ctx, 0, st);
   }
   {
     const int64_t ng = (N + BASE_RB - 1) / BASE_RB;
     const int grid = (int)min((int64_t)2048, ng);
     const size_t smem = ((size_t)BASE_RB * F + (size_t)BASE_RB * S1 * D + (size_t)256 * BASE_RB) * 4;
     ARG_CHECK(smem <= 160 * 1024, "S too large for the base kernel's LDS tile");
+    prof_begin(ctx, st);
     hipLaunchKernelGGL(k_base, dim3(grid), dim3(256), smem, st, WT, M->b, M->V, M->feat, X, cand, base, N, S1, D, F,
                        y.DP);
+    prof_end(ctx, 1, st);
   }
   {
     const int64_t ntiles = (y.L + 31) / 32;
@@ -538,15 +542,19 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
 #define LAUNCH_FWD(ND_, MODE_)                                                                                      \
   hipLaunchKernelGGL((k_noise_fwd<ND_, MODE_>), grid, block, smem, st, WT, base, M->U, X, rnd->noise, rnd->keep, hbuf, \
                      m, y.L, S1, A, D, F, y.DP, nkey, dkey, nscale, thr, kscale)
+    prof_begin(ctx, st);
     if (y.ND == 1) { if (fused) LAUNCH_FWD(1, 0); else LAUNCH_FWD(1, 1); }
     else           { if (fused) LAUNCH_FWD(2, 0); else LAUNCH_FWD(2, 1); }
+    prof_end(ctx, 2, st);
 #undef LAUNCH_FWD
   }
   {
     const int64_t units = (train && rank == 1) ? N / 2 : N;
     const int grid = (int)min((int64_t)2048, (units + 255) / 256);
+    prof_begin(ctx, st);
     hipLaunchKernelGGL(k_pair_epilogue, dim3(grid), dim3(256), 0, st, *M, X, Y, cand, m, dmns, pred, loss, N, rank,
                        train ? 1 : 0);
+    prof_end(ctx, 3, st);
   }
   if (train) {
     {
@@ -555,20 +563,26 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
       const int grid = (int)min((int64_t)512, ng);
       const size_t smem = (size_t)RB * S1 * y.DP * 4 * 2 + (size_t)RB * S1 * 4 * 2;
       ARG_CHECK(smem <= 160 * 1024, "S too large for the backward kernel's LDS tile");
+      prof_begin(ctx, st);
       hipLaunchKernelGGL(k_bwd_small, dim3(grid), dim3(256), max(smem, (size_t)1024), st, M->W, M->U, M->V, X, cand,
                          dmns, hbuf, dzn, G->gU, G->gV, G->gW, G->gb, N, S1, A, D, F, y.DP, kscale);
+      prof_end(ctx, 4, st);
     }
     {
       const int64_t ntiles = (y.L + 31) / 32;
       const dim3 grid((unsigned)min((int64_t)256, ntiles), y.GY), block(64 * y.NC);
 #define LAUNCH_BWD(ND_, MODE_, A_, B_, R_, G_)                                                                    \
   hipLaunchKernelGGL((k_noise_bwd<ND_, MODE_>), G_, block, 0, st, A_, B_, X, G->gW, R_, D, F, y.DP, nkey, nscale)
+      prof_begin(ctx, st);
       if (y.ND == 1) { if (fused) LAUNCH_BWD(1, 0, hbuf, nullptr, y.L, grid); else LAUNCH_BWD(1, 1, hbuf, rnd->noise, y.L, grid); }
       else           { if (fused) LAUNCH_BWD(2, 0, hbuf, nullptr, y.L, grid); else LAUNCH_BWD(2, 1, hbuf, rnd->noise, y.L, grid); }
+      prof_end(ctx, 5, st);
       const int64_t ntn = (N + 31) / 32;
       const dim3 gridn((unsigned)min((int64_t)256, ntn), y.GY);
+      prof_begin(ctx, st);
       if (y.ND == 1) LAUNCH_BWD(1, 2, dzn, M->feat, N, gridn);
       else           LAUNCH_BWD(2, 2, dzn, M->feat, N, gridn);
+      prof_end(ctx, 6, st);
 #undef LAUNCH_BWD
     }
   }

@@ -21,13 +21,50 @@ extern "C" int dccf_ctx_create(dccf_ctx** out, int device) {
   c->device = device;
   c->ws = nullptr;
   c->ws_bytes = 0;
+  c->prof_on = 0;
+  c->ev = nullptr;
+  c->ev_slot = nullptr;
+  c->ev_used = 0;
   *out = c;
+  return 0;
+}
+
+// Per-kernel timing: HIP events recorded on the launch stream around every kernel of dccf_predict / dccf_train_fwdbwd.
+extern "C" int dccf_profile(dccf_ctx* ctx, int enable) {
+  ARG_CHECK(ctx != nullptr, "ctx is NULL");
+  if (enable && !ctx->ev) {
+    ctx->ev = new hipEvent_t[DCCF_PROF_EVENTS];
+    ctx->ev_slot = new int[DCCF_PROF_EVENTS / 2];
+    for (int i = 0; i < DCCF_PROF_EVENTS; ++i) HIP_TRY(hipEventCreate(&ctx->ev[i]));
+  }
+  ctx->prof_on = enable ? 1 : 0;
+  ctx->ev_used = 0;
+  return 0;
+}
+
+// Adds the elapsed ms and launch counts since the last read into ms[DCCF_PROF_SLOTS] / counts[...] (host arrays).
+extern "C" int dccf_profile_read(dccf_ctx* ctx, double* ms, int64_t* counts) {
+  ARG_CHECK(ctx && ms && counts, "NULL argument");
+  for (int i = 0; i + 1 < ctx->ev_used; i += 2) {
+    HIP_TRY(hipEventSynchronize(ctx->ev[i + 1]));
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, ctx->ev[i], ctx->ev[i + 1]));
+    const int s = ctx->ev_slot[i >> 1];
+    ms[s] += (double)t;
+    counts[s] += 1;
+  }
+  ctx->ev_used = 0;
   return 0;
 }
 
 extern "C" int dccf_ctx_destroy(dccf_ctx* ctx) {
   if (!ctx) return 0;
   if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->ev) {
+    for (int i = 0; i < DCCF_PROF_EVENTS; ++i) (void)hipEventDestroy(ctx->ev[i]);
+    delete[] ctx->ev;
+    delete[] ctx->ev_slot;
+  }
   delete ctx;
   return 0;
 }

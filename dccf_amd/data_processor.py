@@ -194,39 +194,56 @@ class DataProcessor(object):
         return batches
 
     # ------------------------------------------------------------------ device-resident epoch (fused negatives)
-    def _build_device_state(self):
-        dl = self.data_loader
-        tr = dl.train_df
-        uid = tr['uid'].values.astype(np.int64)
-        iid = tr['iid'].values.astype(np.int64)
-        U = int(dl.user_num)
-        order = np.argsort(uid, kind='stable')                      # rows of each user, ascending sample id
-        rows_indptr = np.searchsorted(uid[order], np.arange(U + 1)).astype(np.int64)
-        pos = tr[tr[dl.label] > 0] if dl.label in tr.columns else tr
-        key = np.unique(pos['uid'].values.astype(np.int64) * int(dl.item_num) + pos['iid'].values.astype(np.int64))
-        hu, hi = key // int(dl.item_num), key % int(dl.item_num)   # sorted by user, then item; de-duplicated
-        hist_indptr = np.searchsorted(hu, np.arange(U + 1)).astype(np.int64)
-        t = utils.numpy_to_torch
-        self._dev = dict(uid=t(uid), iid=t(iid), rows=t(order.astype(np.int64)), rows_indptr=t(rows_indptr),
-                         hist_indptr=t(hist_indptr), hist_items=t(hi.astype(np.int64)), n=len(uid))
-
     def device_epoch(self, epoch, batch_size):
-        """Returns (X_all [2, T, 2] int64 in HBM (pos rows, neg rows, already permuted), sample_id perm [T]).
-        The permutation plays the role of shuffle_in_unison_scary (utils.py:82-92); negatives are drawn on device."""
+        """The epoch's batches as device tensors: (full [nb, 2B, 2] int64, tail [2r, 2] or None).  See DeviceTrainSet."""
         if self._dev is None:
-            self._build_device_state()
-        d = self._dev
-        dl = self.data_loader
-        neg = _lib.sample_train_negatives(d['rows_indptr'], d['rows'], d['hist_indptr'], d['hist_items'], dl.user_num,
-                                          dl.item_num, self.seed, epoch)
-        g = torch.Generator(device='cpu')
-        g.manual_seed((int(self.seed) * 1000003 + int(epoch)) & 0x7FFFFFFFFFFFFFFF)
-        perm = torch.randperm(d['n'], generator=g).to(d['uid'].device)
-        u = d['uid'][perm]
-        X = torch.stack([torch.stack([u, d['iid'][perm]], 1), torch.stack([u, neg[perm]], 1)], 0).contiguous()
-        return X, perm
+            dl = self.data_loader
+            tr = dl.train_df
+            pos = tr[tr[dl.label] > 0] if dl.label in tr.columns else tr
+            self._dev = DeviceTrainSet(tr['uid'].values, tr['iid'].values, dl.user_num, dl.item_num, self.seed,
+                                       hist_uid=pos['uid'].values, hist_iid=pos['iid'].values)
+        return self._dev.epoch_batches(epoch, batch_size)
 
-    @staticmethod
-    def device_batch(X, b0, b1):
-        """Rows [b0,b1) of a device epoch as the reference's [pos ; neg] layout: int64 [2*(b1-b0), 2]."""
-        return torch.cat([X[0, b0:b1], X[1, b0:b1]], 0)
+
+class DeviceTrainSet(object):
+    """The train interactions resident in HBM: uid/iid arrays, each user's rows (CSR, ascending sample id) and sorted
+    train history (CSR).  Per epoch ONE kernel draws every row's negative (dccf_sample_train_negatives, the per-epoch
+    tmp_history rule of src/data_processor/DataProcessor.py:479-517), a device permutation plays the role of
+    shuffle_in_unison_scary (src/utils/utils.py:82-92), and the batches X = [pos ; neg] (:160-207) are views of one
+    [n_batches, 2B, 2] tensor — no host loop, no H2D copy."""
+
+    def __init__(self, uid, iid, user_num, item_num, seed, hist_uid=None, hist_iid=None):
+        uid = np.asarray(uid, dtype=np.int64)
+        iid = np.asarray(iid, dtype=np.int64)
+        self.user_num, self.item_num, self.seed, self.n = int(user_num), int(item_num), int(seed), len(uid)
+        order = np.argsort(uid, kind='stable')
+        rows_indptr = np.searchsorted(uid[order], np.arange(self.user_num + 1)).astype(np.int64)
+        hu = uid if hist_uid is None else np.asarray(hist_uid, dtype=np.int64)
+        hi = iid if hist_iid is None else np.asarray(hist_iid, dtype=np.int64)
+        key = np.unique(hu * self.item_num + hi)                     # sorted by user then item, de-duplicated
+        ku, ki = key // self.item_num, key % self.item_num
+        hist_indptr = np.searchsorted(ku, np.arange(self.user_num + 1)).astype(np.int64)
+        t = utils.numpy_to_torch
+        self.uid, self.iid = t(uid), t(iid)
+        self.rows, self.rows_indptr = t(order.astype(np.int64)), t(rows_indptr)
+        self.hist_indptr, self.hist_items = t(hist_indptr), t(ki.astype(np.int64))
+        self.neg = torch.empty(self.n, dtype=torch.int64, device=self.uid.device)
+
+    def sample_negatives(self, epoch):
+        return _lib.sample_train_negatives(self.rows_indptr, self.rows, self.hist_indptr, self.hist_items, self.user_num,
+                                           self.item_num, self.seed, epoch, out=self.neg)
+
+    def epoch_batches(self, epoch, batch_size):
+        neg = self.sample_negatives(epoch)
+        g = torch.Generator(device=self.uid.device)
+        g.manual_seed((self.seed * 1000003 + int(epoch)) & 0x7FFFFFFFFFFFFFFF)
+        perm = torch.randperm(self.n, generator=g, device=self.uid.device)
+        u = self.uid[perm]
+        pos = torch.stack([u, self.iid[perm]], 1)
+        ngx = torch.stack([u, neg[perm]], 1)
+        nb = self.n // batch_size
+        full = torch.cat([pos[:nb * batch_size].view(nb, batch_size, 2), ngx[:nb * batch_size].view(nb, batch_size, 2)], 1).contiguous()
+        tail = None
+        if self.n % batch_size:
+            tail = torch.cat([pos[nb * batch_size:], ngx[nb * batch_size:]], 0).contiguous()
+        return full, tail

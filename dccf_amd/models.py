@@ -360,16 +360,23 @@ class DCCF(DMF):
                          _ParamModule('linear', p['mlp.0.weight'], p['mlp.0.bias'])]
 
     def _struct(self):
-        p = self.params
-        return _lib.model_struct(p['uid_embeddings.weight'], p['iid_embeddings.weight'], p['mlp.0.weight'], p['mlp.0.bias'],
-                                 self.feature_embedding, self.expo_prob, self.sample_num, self.attribute_num, self.std,
-                                 ips=self.ips_factors)
+        """The C view of the model; parameter storage never moves, so it is built once."""
+        if getattr(self, '_ms', None) is None:
+            p = self.params
+            self._ms = _lib.model_struct(p['uid_embeddings.weight'], p['iid_embeddings.weight'], p['mlp.0.weight'],
+                                         p['mlp.0.bias'], self.feature_embedding, self.expo_prob, self.sample_num,
+                                         self.attribute_num, self.std, ips=self.ips_factors)
+            self._rs = _lib.rand_struct(seed=self.random_seed, step=0)
+            self._loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        return self._ms
 
     def _rand(self, feed_dict):
         inj = feed_dict.get('inject')
         if inj is not None:   # parity tests: the reference's captured draws
             return _lib.rand_struct(sample_item=inj['sample_item'], noise=inj['noise'], keep=inj.get('keep'))
-        return _lib.rand_struct(seed=self.random_seed, step=self._next_step())
+        self._struct()
+        self._rs.step = self._next_step()
+        return self._rs
 
     def predict(self, feed_dict):
         """src/models/DCCF.py:66-107.  Fresh candidates and noise on every call, also in eval mode, as in the reference."""
@@ -382,8 +389,9 @@ class DCCF(DMF):
         if not self.training:
             return self.predict(feed_dict)
         g = self.grads
-        pred, loss = _lib.dccf_train_fwdbwd(self.ctx, self._struct(), self._rand(feed_dict), feed_dict['X'].contiguous(),
+        ms = self._struct()
+        pred, loss = _lib.dccf_train_fwdbwd(self.ctx, ms, self._rand(feed_dict), feed_dict['X'].contiguous(),
                                             feed_dict['Y'], feed_dict['rank'], feed_dict['dropout'],
                                             g['uid_embeddings.weight'], g['iid_embeddings.weight'], g['mlp.0.weight'],
-                                            g['mlp.0.bias'])
+                                            g['mlp.0.bias'], loss=self._loss)
         return {'prediction': pred, 'check': [('prediction', pred)], 'loss': loss[0]}

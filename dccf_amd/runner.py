@@ -89,17 +89,22 @@ class BaseRunner(object):
         model.train()
         out = None
         if self.fused_sampling and data_processor.rank == 1:
-            X, perm = data_processor.device_epoch(max(epoch, 0), self.batch_size)
-            T = X.shape[1]
-            ones = torch.ones(self.batch_size, dtype=torch.float32, device=X.device)
-            for b0 in range(0, T, self.batch_size):
-                b1 = min(T, b0 + self.batch_size)
-                n = b1 - b0
-                batch = {'X': data_processor.device_batch(X, b0, b1), 'Y': torch.cat([ones[:n], ones[:n] * 0]), 'rank': 1,
-                         'train': True, 'dropout': self.dropout, utils.REAL_BATCH_SIZE: n}
+            full, tail = data_processor.device_epoch(max(epoch, 0), self.batch_size)
+            B = self.batch_size
+            y = torch.cat([torch.ones(B, device=full.device), torch.zeros(B, device=full.device)])
+            batch = {'Y': y, 'rank': 1, 'train': True, 'dropout': self.dropout, utils.REAL_BATCH_SIZE: B}
+            for k in range(full.shape[0]):
+                batch['X'] = full[k]
                 model.optimizer.zero_grad()
                 out = model(batch)
                 model.optimizer.step()        # + l2 term, clip_grad_value_(50), update: one dense kernel
+            if tail is not None:
+                r = tail.shape[0] // 2
+                batch = {'X': tail, 'Y': torch.cat([y[:r], y[B:B + r]]), 'rank': 1, 'train': True, 'dropout': self.dropout,
+                         utils.REAL_BATCH_SIZE: r}
+                model.optimizer.zero_grad()
+                out = model(batch)
+                model.optimizer.step()
         else:
             batches = self.batches_add_control(data_processor.prepare_batches(data, self.batch_size, train=True), train=True)
             for batch in batches:

@@ -34,6 +34,11 @@ int dccf_ctx_destroy(dccf_ctx* ctx);
 int dccf_ctx_reserve(dccf_ctx* ctx, int64_t max_rows, int32_t D, int32_t F, int32_t S, int32_t A);
 const char* dccf_last_error(void);
 int dccf_abi_version(void);
+/* Optional per-kernel timing: HIP events on the launch stream around every kernel of dccf_predict / dccf_train_fwdbwd.
+ * dccf_profile_read adds elapsed ms / launch counts since the last read into HOST arrays of 8 slots:
+ * 0 prep, 1 base, 2 noise_fwd, 3 pair_epilogue, 4 bwd_small, 5 noise_bwd(eps), 6 noise_bwd(feat). */
+int dccf_profile(dccf_ctx* ctx, int enable);
+int dccf_profile_read(dccf_ctx* ctx, double* ms, int64_t* counts);
 
 /* ---- DCCF model view: replaces the attributes set up by DCCF._init_weights (src/models/DCCF.py:47-64) ----- */
 typedef struct {
