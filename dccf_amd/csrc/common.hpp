@@ -7,6 +7,7 @@
 #include "../../include/dccf_hip.h"
 
 #define DCCF_ABI_VERSION 1
+#pragma clang fp contract(off)
 
 // ---------------------------------------------------------------------------------------------- errors
 extern thread_local char g_dccf_err[512];

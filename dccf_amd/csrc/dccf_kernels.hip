@@ -1,27 +1,38 @@
 // dccf_kernels.hip — DCCF.predict / DCCF.forward+backward as hand-written gfx950 kernels.
 //
 // Reference semantics: src/models/DCCF.py:66-127.  With N rows of X, S1 = S+1 candidates per row and
-// A noise draws per candidate, the reference materialises L = N*S1*A rows of width D+F and pushes them through
-// Linear(D+F -> D).  Here the layer is split by linearity,
-//     z[l] = W_i V[cand(l)] + (W_f feat[i0(l)] + b)  +  W_f eps[l]
-//            \_________ "base": once per (n,s) ________/    \_ the only term that is different for every l _/
-// and only the last term is a real GEMM ([L,F] x [F,D]).  It runs on the fp32 MFMA (v_mfma_f32_32x32x2_f32, exact
-// fp32) with the A operand — the Gaussian noise — generated in registers by Philox4x32-10 + Box-Muller in exactly
-// the lane layout the MFMA wants, so the [L,F] noise tensor never exists in memory.  The backward needs the same
-// eps for dW_f = dz^T eps; it is regenerated from the same counters (again directly as an MFMA operand).
+// A noise draws per candidate, the reference materialises L = N*S1*A rows x[l] = [V[cand(l)] ; feat[i0(l)] + eps[l]] of
+// width D+F and pushes them through Linear(D+F -> D): z = x W^T + b.  Here the rows are never materialised:
 //
-// HBM data layout (all fp32 row-major): U [user_num,D], V [item_num,D], W [D,D+F], b [D], feat [item_num,F],
-// expo [user_num,item_num].  Workspace (per call, in the ctx slab): cand int32 [N,S1]; WT [(D+FP),DP] = W transposed
-// and zero padded (DP = D rounded to 32, FP = F rounded to 128); base [N*S1,DP]; h [L,DP] (overwritten by dz in the
-// backward); m [L]; dmns [N*S1]; dzn [N,DP].
+//   forward  (k_noise_fwd)  Z = X W^T on the fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32).  A workgroup owns 32 rows l;
+//            wave w < NC owns the 128-wide feature chunk w of K and keeps its slice of W_f in registers; its A operand
+//            feat + eps is produced in registers (Philox4x32-10 + Box-Muller, in the lane layout the MFMA wants); one more
+//            wave owns the item part of K (V[cand] rows, W_i in registers).  Partials meet in LDS; the epilogue adds b,
+//            applies relu + dropout, stores h [L,D] and the row dot m[l] = <U[u], h[l]>.
+//   epilogue (k_pair_epilogue)  softmax over the candidates of Expo[u, cand] (one lane per candidate), prediction,
+//            BPR / MSE loss and d loss / d m.
+//   backward (k_bwd_misc)   three role waves per 32 rows: dW_i += dz^T V[cand] (MFMA), dV[cand] += dz W_i (MFMA, rows
+//            leave through 128-B float-atomic segments, the A noise copies summed in registers first), and a streaming
+//            wave for dU[u] += dm h (row-run reduction before the atomic), db and the dz rows.
+//            (k_noise_bwd)  dW_f += dz^T (feat + eps): eps is REGENERATED from the same counters directly as the MFMA
+//            B operand; 32x32 accumulators stay in registers over the workgroup's whole row range.
+//
+// HBM layout (fp32 row-major): U [user_num,D], V [item_num,D], W [D,D+F], b [D], feat [item_num,F], expo [user_num,
+// item_num].  Workspace per call (ctx slab): cand int32 [N,S1]; WT [(D+FP),DP] = W transposed, zero padded (DP = D
+// rounded to 32/64, FP = F rounded to 128); h [L,DP]; dz [L,DP]; m [L]; dmns [N*S1]; it0 int32 [L] (true item per row).
 #include "common.hpp"
 
+// No implicit FMA contraction in this file: a*b+c written as two operations stays two roundings (explicit fmaf() calls
+// are still FMAs).  It keeps "fused draws == injected draws" bit for bit and the optimizer in torch's op order.
+#pragma clang fp contract(off)
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 struct Lay {
   int DP, FP, NC, S1, ND, GY;
   int64_t N, L, NS;
-  size_t cand, WT, base, h, m, dmns, dzn, total;
+  size_t cand, WT, h, dz, m, dmns, it0, total;
 };
 
 static Lay make_layout(int64_t N, int D, int F, int S, int A) {
@@ -38,11 +49,11 @@ static Lay make_layout(int64_t N, int D, int F, int S, int A) {
   size_t o = 0;
   y.cand = o;  o += align_up((size_t)y.NS * 4, 256);
   y.WT = o;    o += align_up((size_t)(D + y.FP) * y.DP * 4, 256);
-  y.base = o;  o += align_up((size_t)y.NS * y.DP * 4, 256);
   y.h = o;     o += align_up((size_t)y.L * y.DP * 4, 256);
+  y.dz = o;    o += align_up((size_t)y.L * y.DP * 4, 256);
   y.m = o;     o += align_up((size_t)y.L * 4, 256);
   y.dmns = o;  o += align_up((size_t)y.NS * 4, 256);
-  y.dzn = o;   o += align_up((size_t)N * y.DP * 4, 256);
+  y.it0 = o;   o += align_up((size_t)y.L * 4, 256);
   y.total = o;
   return y;
 }
@@ -83,112 +94,90 @@ __global__ void k_prep(const float* __restrict__ W, float* __restrict__ WT, int 
   }
 }
 
-// ================================================================================================ K1: base
-// base[(n,s)][d] = sum_k W_i[d][k] V[cand[n,s]][k] + ( b[d] + sum_f W_f[d][f] feat[i0(n)][f] )
-// One block = RB batch rows; the K range is split over the 256/DP thread groups and reduced through LDS.
-#define BASE_RB 4
-__global__ __launch_bounds__(256) void k_base(const float* __restrict__ WT, const float* __restrict__ bias,
-                                              const float* __restrict__ V, const float* __restrict__ feat,
-                                              const int64_t* __restrict__ X, const int* __restrict__ cand,
-                                              float* __restrict__ base, int64_t N, int S1, int D, int F, int DP) {
-  extern __shared__ float sm[];
-  float* xf = sm;                               // [RB][F]
-  float* xv = xf + BASE_RB * F;                 // [RB*S1][D]
-  float* gp = xv + BASE_RB * S1 * D;            // [G][RB][DP]  partial G sums
-  const int G = 256 / DP;                       // thread groups
-  const int grp = threadIdx.x / DP, d = threadIdx.x % DP;
-  const int64_t ngroups = (N + BASE_RB - 1) / BASE_RB;
-  for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
-    const int64_t n0 = g * BASE_RB;
-    const int nr = (int)min((int64_t)BASE_RB, N - n0);
-    for (int i = threadIdx.x; i < nr * F; i += 256) {
-      const int r = i / F, f = i % F;
-      xf[i] = feat[X[2 * (n0 + r) + 1] * F + f];
-    }
-    for (int i = threadIdx.x; i < nr * S1 * D; i += 256) {
-      const int j = i / D, k = i % D;
-      xv[i] = V[(int64_t)cand[n0 * S1 + j] * D + k];
-    }
-    __syncthreads();
-    {   // G part: this group's slice of f
-      float acc[BASE_RB];
-#pragma unroll
-      for (int r = 0; r < BASE_RB; ++r) acc[r] = 0.f;
-      const int f0 = (int)((int64_t)F * grp / G), f1 = (int)((int64_t)F * (grp + 1) / G);
-      for (int f = f0; f < f1; ++f) {
-        const float w = WT[(int64_t)(D + f) * DP + d];
-#pragma unroll
-        for (int r = 0; r < BASE_RB; ++r) acc[r] = fmaf(w, xf[r * F + f], acc[r]);
-      }
-#pragma unroll
-      for (int r = 0; r < BASE_RB; ++r) gp[(grp * BASE_RB + r) * DP + d] = acc[r];
-    }
-    __syncthreads();
-    // item part + sum of the G partials (fixed order -> deterministic)
-    for (int j = grp; j < nr * S1; j += G) {
-      const int r = j / S1;
-      float acc = bias[d < D ? d : 0];
-      for (int q = 0; q < G; ++q) acc += gp[(q * BASE_RB + r) * DP + d];
-      float e = 0.f;
-      for (int k = 0; k < D; ++k) e = fmaf(WT[(int64_t)k * DP + d], xv[j * D + k], e);
-      base[(n0 * S1 + j) * DP + d] = d < D ? acc + e : 0.f;
-    }
-    __syncthreads();
-  }
-}
-
-// ================================================================================================ K2: noise forward
-// Wave task = 32 rows l  x  one 128-wide f chunk (tq = wave)  x  ND*32 columns d.  The W_f chunk stays in registers for
-// the life of the block (wreg, 64*ND VGPRs); per 4 MFMA k-steps a lane makes ONE Philox call whose 4 normals are the
-// A operands of those steps:  lane (row = lane&31, h = lane>>5), step (c2, o):  f = 128*tq + (2*c2+h) + 32*o.
-// The NC chunk partials meet in LDS; the epilogue adds base, applies relu + dropout, stores h and the row dot m[l].
-template <int ND, int MODE>   // MODE 0: fused Philox, 1: injected noise
-__global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT, const float* __restrict__ base,
-                                                   const float* __restrict__ U, const int64_t* __restrict__ X,
-                                                   const float* __restrict__ noise, const uint8_t* __restrict__ keep,
-                                                   float* __restrict__ hbuf, float* __restrict__ m, int64_t L, int S1,
-                                                   int A, int D, int F, int DP, rng_key nkey, rng_key dkey,
-                                                   float nscale, uint32_t drop_thr, float kscale) {
-  extern __shared__ float zpart[];   // [NC][32][DW]
+// ================================================================================================ K1: forward
+// Workgroup = NC chunk waves + 1 item wave, one 32-row tile per iteration.
+//   chunk wave tq:  lane (row = lane&31, h = lane>>5), k-step (c2, o):  f = 128*tq + (2*c2+h) + 32*o;  ONE Philox call per
+//                   4 k-steps yields the 4 normals eps(l, f) of o = 0..3; A = feat[i0(l)][f] + eps;  B = wreg (registers).
+//   item wave:      k-step j: A = V[cand(l)][2j+h], B = W_i^T rows 2j+h (registers).
+template <int D_, int MODE>   // MODE 0: fused Philox draws, 1: injected noise / keep mask
+__global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT, const float* __restrict__ bias,
+                                                   const float* __restrict__ U, const float* __restrict__ V,
+                                                   const float* __restrict__ feat, const int64_t* __restrict__ X,
+                                                   const int* __restrict__ cand, const float* __restrict__ noise,
+                                                   const uint8_t* __restrict__ keep, float* __restrict__ hbuf,
+                                                   float* __restrict__ m, int* __restrict__ it0row, int64_t L, int S1,
+                                                   int A, int F, rng_key nkey, rng_key dkey, float nscale,
+                                                   uint32_t drop_thr, float kscale) {
+  extern __shared__ float zpart[];   // [NW][32][DW]
+  constexpr int D = D_;
+  constexpr int DP = D <= 32 ? 32 : (D + 63) / 64 * 64;
+  constexpr int ND = D <= 32 ? 1 : 2;
   constexpr int DW = ND * 32;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, NC = blockDim.x >> 6;
+  constexpr int KI = D / 2;          // k-steps of the item part
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, NW = blockDim.x >> 6, NC = NW - 1;
   const int h = lane >> 5, c31 = lane & 31;
   const int dbase = blockIdx.y * DW;
-  float wreg[16][4][ND];
+  const bool chunk = wave < NC;
+  // register-resident B operand: ONE array serves both roles (chunk: [c2][o][nt], item: [j][nt]; KI*ND <= 64*ND)
+  float breg[64 * ND];
+  if (chunk) {
 #pragma unroll
-  for (int c2 = 0; c2 < 16; ++c2)
+    for (int c2 = 0; c2 < 16; ++c2)
 #pragma unroll
-    for (int o = 0; o < 4; ++o)
+      for (int o = 0; o < 4; ++o)
 #pragma unroll
-      for (int nt = 0; nt < ND; ++nt)
-        wreg[c2][o][nt] = WT[(int64_t)(D + wave * 128 + 2 * c2 + h + 32 * o) * DP + dbase + nt * 32 + c31];
-
+        for (int nt = 0; nt < ND; ++nt)
+          breg[(c2 * 4 + o) * ND + nt] = WT[(int64_t)(D + wave * 128 + 2 * c2 + h + 32 * o) * DP + dbase + nt * 32 + c31];
+  } else {
+#pragma unroll
+    for (int j = 0; j < KI; ++j)
+#pragma unroll
+      for (int nt = 0; nt < ND; ++nt) breg[j * ND + nt] = WT[(int64_t)(2 * j + h) * DP + dbase + nt * 32 + c31];
+  }
+  const uint32_t rows_per_n = (uint32_t)(S1 * A);
   const int64_t ntiles = (L + 31) / 32;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t l = tile * 32 + c31;
+    const bool lv = l < L;
     f32x16 acc[ND];
 #pragma unroll
     for (int nt = 0; nt < ND; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    if (chunk) {
+      const int64_t it0 = lv ? X[2 * (int64_t)((uint32_t)l / rows_per_n) + 1] : 0;
+      const float* frow = feat + it0 * F;
 #pragma unroll
-    for (int c2 = 0; c2 < 16; ++c2) {
-      float a[4];
-      const int c = 2 * c2 + h;
-      if (MODE == 1) {
+      for (int c2 = 0; c2 < 16; ++c2) {
+        float a[4];
+        const int c = 2 * c2 + h;
+        if (MODE == 1) {
+#pragma unroll
+          for (int o = 0; o < 4; ++o) {
+            const int f = wave * 128 + c + 32 * o;
+            a[o] = (lv && f < F) ? noise[l * F + f] : 0.f;
+          }
+        } else {
+          noise4((uint32_t)l, (uint32_t)(wave * 32 + c), nkey, nscale, a);
+        }
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
           const int f = wave * 128 + c + 32 * o;
-          a[o] = (l < L && f < F) ? noise[l * F + f] : 0.f;
+          const float fv = (lv && f < F) ? frow[f] : 0.f;
+          a[o] = __fadd_rn(fv, a[o]);               // sample_feature_embeddings = feature + noise (DCCF.py:87); no
+                                                    // contraction with Box-Muller's multiply: fused == injected bit for bit
+#pragma unroll
+          for (int nt = 0; nt < ND; ++nt) acc[nt] = MFMA32(a[o], breg[(c2 * 4 + o) * ND + nt], acc[nt]);
         }
-      } else {
-        noise4((uint32_t)l, (uint32_t)(wave * 32 + c), nkey, nscale, a);
       }
+    } else {
+      const float* vrow = V + (int64_t)(lv ? cand[(uint32_t)l / (uint32_t)A] : 0) * D;
 #pragma unroll
-      for (int o = 0; o < 4; ++o)
+      for (int j = 0; j < KI; ++j) {
+        const float a = lv ? vrow[2 * j + h] : 0.f;
 #pragma unroll
-        for (int nt = 0; nt < ND; ++nt)
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[o], wreg[c2][o][nt], acc[nt], 0, 0, 0);
+        for (int nt = 0; nt < ND; ++nt) acc[nt] = MFMA32(a, breg[j * ND + nt], acc[nt]);
+      }
     }
 #pragma unroll
     for (int nt = 0; nt < ND; ++nt)
@@ -198,7 +187,7 @@ __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT,
         zpart[(wave * 32 + row) * DW + nt * 32 + c31] = acc[nt][r];
       }
     __syncthreads();
-    for (int row = wave; row < 32; row += NC) {
+    for (int row = wave; row < 32; row += NW) {
       const int64_t lr = tile * 32 + row;
       if (lr >= L) break;
       const int64_t ns = lr / A;
@@ -208,9 +197,9 @@ __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT,
       for (int d0 = lane; d0 < DW; d0 += 64) {
         const int d = dbase + d0;
         if (d < D) {
-          float z = 0.f;
+          float z = zpart[(NC * 32 + row) * DW + d0];        // item part first, then the feature chunks in order
           for (int w = 0; w < NC; ++w) z += zpart[(w * 32 + row) * DW + d0];
-          z += base[ns * DP + d];
+          z += bias[d];
           bool kept = true;
           if (MODE == 1) {
             if (keep) kept = keep[lr * D + d] != 0;
@@ -227,15 +216,16 @@ __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT,
       if (lane == 0) {
         if (gridDim.y == 1) m[lr] = part;
         else atomicAdd(&m[lr], part);
+        if (blockIdx.y == 0) it0row[lr] = (int)X[2 * n + 1];
       }
     }
     __syncthreads();
   }
 }
 
-// ================================================================================================ K3: pair epilogue
-// softmax over the S1 candidates of Expo[u, cand] (models/DCCF.py:98), prediction (DCCF.py:100), BPR / MSE loss and
-// d loss / d m  (DCCF.py:116-125).  One thread per pair (rank 1) or per row (rank 0 / predict).
+// ================================================================================================ K2: pair epilogue
+// One lane per candidate: softmax_s(Expo[u, cand[n,s]]) (DCCF.py:98), prediction = mean_a sum_s w m (DCCF.py:100),
+// loss and d loss / d m (DCCF.py:116-125).  A group of GS lanes serves one pair (rank 1) or one row.
 __device__ __forceinline__ float expo_at(const dccf_model_t& M, int64_t u, int64_t i) {
   if (M.expo) return M.expo[u * M.item_num + i];
   float acc = 0.f;
@@ -244,57 +234,77 @@ __device__ __forceinline__ float expo_at(const dccf_model_t& M, int64_t u, int64
   return acc / fmaxf(M.ipsProp[i], M.ipsM);
 }
 
-__device__ float row_predict(const dccf_model_t& M, const int64_t* X, const int* cand, const float* m, float* dmns,
-                             int64_t n, int S1, int A, bool train) {
+template <int GS>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = GS / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int GS>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+  for (int o = GS / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+template <int GS>
+__device__ __forceinline__ float row_predict(const dccf_model_t& M, const int64_t* X, const int* cand, const float* m,
+                                             int64_t n, int s, int S1, int A, float& w_over_A) {
+  const bool valid = s < S1;
   const int64_t u = X[2 * n];
-  float mx = -INFINITY;
-  for (int s = 0; s < S1; ++s) mx = fmaxf(mx, expo_at(M, u, cand[n * S1 + s]));
-  float den = 0.f;
-  for (int s = 0; s < S1; ++s) den += expf(expo_at(M, u, cand[n * S1 + s]) - mx);
+  const float e = valid ? expo_at(M, u, cand[n * S1 + s]) : -INFINITY;
+  const float mx = group_max<GS>(e);
+  const float ex = valid ? expf(e - mx) : 0.f;
+  const float w = ex / group_sum<GS>(ex);
   float tot = 0.f;
-  for (int a = 0; a < A; ++a) {
-    float pa = 0.f;
-    for (int s = 0; s < S1; ++s) {
-      const float w = expf(expo_at(M, u, cand[n * S1 + s]) - mx) / den;
-      pa = fmaf(w, m[(n * S1 + s) * A + a], pa);
-      if (train && a == 0) dmns[n * S1 + s] = w / (float)A;
-    }
-    tot += pa;
-  }
+  for (int a = 0; a < A; ++a) tot += group_sum<GS>(valid ? w * m[(n * S1 + s) * A + a] : 0.f);
+  w_over_A = w / (float)A;
   return tot / (float)A;
 }
 
+template <int GS>
 __global__ __launch_bounds__(256) void k_pair_epilogue(dccf_model_t M, const int64_t* __restrict__ X,
                                                        const float* __restrict__ Y, const int* __restrict__ cand,
                                                        const float* __restrict__ m, float* __restrict__ dmns,
                                                        float* __restrict__ pred, float* __restrict__ loss, int64_t N,
                                                        int rank, int train) {
   const int S1 = M.S + 1, A = M.A;
-  const int64_t units = (train && rank == 1) ? N / 2 : N;
-  float lsum = 0.f;
-  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < units; k += (int64_t)gridDim.x * blockDim.x) {
-    if (train && rank == 1) {
+  const int s = threadIdx.x % GS;
+  const int64_t gid = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / GS;
+  const int64_t ngr = (int64_t)gridDim.x * blockDim.x / GS;
+  const bool pairs = train && rank == 1;
+  const int64_t units = pairs ? N / 2 : N;
+  const int64_t rounds = (units + ngr - 1) / ngr;      // every group runs the same number of rounds (shuffles are
+  float lsum = 0.f;                                    // wave-wide: no lane may leave early)
+  for (int64_t it = 0; it < rounds; ++it) {
+    const int64_t k0 = it * ngr + gid;
+    const bool live = k0 < units;
+    const int64_t k = live ? k0 : 0;
+    if (pairs) {
       const int64_t B = N / 2;
-      const float pp = row_predict(M, X, cand, m, dmns, k, S1, A, true);
-      const float pn = row_predict(M, X, cand, m, dmns, B + k, S1, A, true);
-      pred[k] = pp;
-      pred[B + k] = pn;
+      float wp, wn;
+      const float pp = row_predict<GS>(M, X, cand, m, k, s, S1, A, wp);
+      const float pn = row_predict<GS>(M, X, cand, m, B + k, s, S1, A, wn);
       const float d = pp - pn;
       const float sg = 1.f / (1.f + expf(-d));
-      lsum += -logf(sg);
-      const float gp = -(1.f - sg);
-      for (int s = 0; s < S1; ++s) {
-        dmns[k * S1 + s] *= gp;
-        dmns[(B + k) * S1 + s] *= -gp;
+      const float gp = -(1.f - sg);                 // d loss / d pos = -sigmoid(neg - pos)
+      if (live && s < S1) {
+        dmns[k * S1 + s] = wp * gp;
+        dmns[(B + k) * S1 + s] = wn * (-gp);
+      }
+      if (live && s == 0) {
+        pred[k] = pp;
+        pred[B + k] = pn;
+        lsum += -logf(sg);
       }
     } else {
-      const float p = row_predict(M, X, cand, m, dmns, k, S1, A, train != 0);
-      pred[k] = p;
-      if (train) {
+      float w;
+      const float p = row_predict<GS>(M, X, cand, m, k, s, S1, A, w);
+      if (live && s == 0) pred[k] = p;
+      if (train && live) {
         const float diff = p - Y[k];
-        lsum += diff * diff / (float)N;
-        const float gp = 2.f * diff / (float)N;
-        for (int s = 0; s < S1; ++s) dmns[k * S1 + s] *= gp;
+        if (s < S1) dmns[k * S1 + s] = w * (2.f * diff / (float)N);
+        if (s == 0) lsum += diff * diff / (float)N;
       }
     }
   }
@@ -307,116 +317,164 @@ __global__ __launch_bounds__(256) void k_pair_epilogue(dccf_model_t M, const int
   }
 }
 
-// ================================================================================================ K4: small backward
-// Per batch row n (thread = (row r, column d)):  dz = dm * U[u] * [h > 0] * kscale  (written over h for K5),
-// dU[u] += sum_l dm h,  dzs[(n,s)] = sum_a dz,  dzn[n] = sum_s dzs.  Then per candidate row: dV[cand] += W_i^T dzs,
-// staged in LDS where rows of the block that hit the same item are summed first (one atomic row-add per distinct
-// item); gW_i += dzs (x) V[cand] and gb += dz accumulate in registers over the block's loop.
-__global__ __launch_bounds__(256) void k_bwd_small(const float* __restrict__ W, const float* __restrict__ U,
-                                                   const float* __restrict__ V, const int64_t* __restrict__ X,
-                                                   const int* __restrict__ cand, const float* __restrict__ dmns,
-                                                   float* __restrict__ hbuf, float* __restrict__ dzn,
-                                                   float* __restrict__ gU, float* __restrict__ gV,
-                                                   float* __restrict__ gW, float* __restrict__ gb, int64_t N, int S1,
-                                                   int A, int D, int F, int DP, float kscale) {
-  extern __shared__ float sm[];
-  const int RB = 256 / DP;
-  float* dzs = sm;                          // [RB*S1][DP]
-  float* stage = dzs + RB * S1 * DP;        // [RB*S1][DP]  dV rows
-  int* first = (int*)(stage + RB * S1 * DP);   // [RB*S1]
-  int* items = first + RB * S1;             // [RB*S1]
-  const int r = threadIdx.x / DP, d = threadIdx.x % DP;
-  const int DR = D / RB > 0 ? D / RB : 1;   // rows of gW_i this thread owns: d in [r*DR, r*DR+DR)
-  float gwi[64];                            // DR <= 64 (D=128, RB=2)
+// ================================================================================================ K3: backward, small terms
+// dz[l][d] = dm[l] * U[u(l)][d] * [h[l][d] > 0] * kscale.  Three role waves share one 32-row tile per iteration:
+//   wave 0  gW[:, 0:D] += dz^T V[cand]   (MFMA: M = d, N = d', K = rows; accumulators live over the block's tiles)
+//   wave 1  gV[cand] += dz W_i           (MFMA: M = rows, N = d', K = d; W_i in registers; the A noise copies of a
+//                                          candidate are summed in registers, rows leave as 128-B atomic segments)
+//   wave 2  gU[u] += sum dm h (run-length reduction over the rows of one batch row), gb += dz, dz rows -> workspace
+template <int D_>
+__global__ __launch_bounds__(192) void k_bwd_misc(const float* __restrict__ W, const float* __restrict__ U,
+                                                  const float* __restrict__ V, const int64_t* __restrict__ X,
+                                                  const int* __restrict__ cand, const float* __restrict__ dmns,
+                                                  const float* __restrict__ hbuf, float* __restrict__ dzbuf,
+                                                  float* __restrict__ gU, float* __restrict__ gV,
+                                                  float* __restrict__ gW, float* __restrict__ gb, int64_t L, int S1, int A,
+                                                  int F, float kscale) {
+  constexpr int D = D_;
+  constexpr int DP = D <= 32 ? 32 : (D + 63) / 64 * 64;
+  constexpr int ND = D <= 32 ? 1 : 2;     // 32-wide tiles of this block's column half
+  constexpr int DW = ND * 32;
+  constexpr int NT = (D + 31) / 32;       // 32-wide tiles over all of D
+  constexpr int KD = D / 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, c31 = lane & 31;
+  const int dbase = blockIdx.y * DW;
+  const uint32_t rows_per_n = (uint32_t)(S1 * A);
+  const int64_t ntiles = (L + 31) / 32;
+  if (wave == 0) {
+    f32x16 acc[ND][NT];
 #pragma unroll
-  for (int q = 0; q < 64; ++q) gwi[q] = 0.f;
-  float gb_acc = 0.f;
-  const int64_t ngroups = (N + RB - 1) / RB;
-  for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
-    const int64_t n = g * RB + r;
-    const bool valid = n < N && d < D;
-    const int nrows = (int)min((int64_t)RB, N - g * RB) * S1;
-    if (n < N) {
-      const int64_t u = X[2 * n];
-      const float ud = valid ? U[u * D + d] : 0.f;
-      float due = 0.f, dzn_acc = 0.f;
-      for (int s = 0; s < S1; ++s) {
-        const float dmv = dmns[n * S1 + s];
-        float dzs_acc = 0.f;
-        for (int a = 0; a < A; ++a) {
-          const int64_t l = (n * S1 + s) * A + a;
-          const float hv = valid ? hbuf[l * DP + d] : 0.f;
-          due = fmaf(dmv, hv, due);
-          const float dzv = hv > 0.f ? dmv * ud * kscale : 0.f;
-          hbuf[l * DP + d] = dzv;
-          dzs_acc += dzv;
+    for (int mt = 0; mt < ND; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+#pragma unroll 2
+      for (int j = 0; j < 16; ++j) {
+        const int64_t l = tile * 32 + 2 * j + h;
+        const bool lv = l < L;
+        const uint32_t ns = (uint32_t)l / (uint32_t)A;
+        const float dmv = lv ? dmns[ns] * kscale : 0.f;
+        const int64_t u = lv ? X[2 * (int64_t)((uint32_t)l / rows_per_n)] : 0;
+        const float* vrow = V + (int64_t)(lv ? cand[ns] : 0) * D;
+        float a[ND], b[NT];
+#pragma unroll
+        for (int mt = 0; mt < ND; ++mt) {
+          const int d = dbase + mt * 32 + c31;
+          const bool ok = lv && d < D;
+          const float hv = ok ? hbuf[l * DP + d] : 0.f;
+          const float uv = ok ? U[u * D + d] : 0.f;
+          a[mt] = hv > 0.f ? dmv * uv : 0.f;
         }
-        dzs[(r * S1 + s) * DP + d] = dzs_acc;
-        dzn_acc += dzs_acc;
-      }
-      dzn[n * DP + d] = dzn_acc;
-      gb_acc += dzn_acc;
-      if (valid) atomicAdd(&gU[u * D + d], due);
-    }
-    if (threadIdx.x < nrows) items[threadIdx.x] = cand[g * RB * S1 + threadIdx.x];
-    __syncthreads();
-    if (threadIdx.x < nrows) {   // duplicate-index detection inside the block's window
-      int f0 = threadIdx.x;
-      const int me = items[threadIdx.x];
-      for (int j = 0; j < (int)threadIdx.x; ++j)
-        if (items[j] == me) { f0 = j; break; }
-      first[threadIdx.x] = f0;
-    }
-    // dV rows into LDS + gW_i accumulation
-    for (int j = r; j < nrows; j += RB) {
-      float dv = 0.f;
-      if (d < D)
-        for (int k = 0; k < D; ++k) dv = fmaf(W[(int64_t)k * (D + F) + d], dzs[j * DP + k], dv);
-      stage[j * DP + d] = dv;
-    }
-    if (d < D) {
-      for (int j = 0; j < nrows; ++j) {
-        const float vj = V[(int64_t)items[j] * D + d];
 #pragma unroll
-        for (int q = 0; q < 64; ++q)
-          if (q < DR) gwi[q] = fmaf(dzs[j * DP + r * DR + q], vj, gwi[q]);
+        for (int nt = 0; nt < NT; ++nt) b[nt] = (lv && nt * 32 + c31 < D) ? vrow[nt * 32 + c31] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < ND; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA32(a[mt], b[nt], acc[mt][nt]);
       }
     }
-    __syncthreads();
-    for (int j = r; j < nrows; j += RB) {
-      if (first[j] != j || d >= D) continue;
-      float v = stage[j * DP + d];
-      for (int j2 = j + 1; j2 < nrows; ++j2)
-        if (first[j2] == j) v += stage[j2 * DP + d];
-      atomicAdd(&gV[(int64_t)items[j] * D + d], v);
-    }
-    __syncthreads();
-  }
-  if (d < D) {
 #pragma unroll
-    for (int q = 0; q < 64; ++q)
-      if (q < DR && r * DR + q < D) atomicAdd(&gW[(int64_t)(r * DR + q) * (D + F) + d], gwi[q]);
-  }
-  // gb: reduce the RB row-threads of a column through LDS
-  __syncthreads();
-  sm[threadIdx.x] = gb_acc;
-  __syncthreads();
-  if (threadIdx.x < DP && threadIdx.x < D) {
-    float s = 0.f;
-    for (int q = 0; q < RB; ++q) s += sm[q * DP + threadIdx.x];
-    atomicAdd(&gb[threadIdx.x], s);
+    for (int mt = 0; mt < ND; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int d = dbase + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int k = nt * 32 + c31;
+          if (d < D && k < D) atomicAdd(&gW[(int64_t)d * (D + F) + k], acc[mt][nt][r]);
+        }
+  } else if (wave == 1) {
+    float wd[KD][ND];                         // W_i rows 2j+h, this block's column half
+#pragma unroll
+    for (int j = 0; j < KD; ++j)
+#pragma unroll
+      for (int nt = 0; nt < ND; ++nt) {
+        const int dd = dbase + nt * 32 + c31;
+        wd[j][nt] = dd < D ? W[(int64_t)(2 * j + h) * (D + F) + dd] : 0.f;
+      }
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      const int64_t l = tile * 32 + c31;
+      const bool lv = l < L;
+      const float dmv = lv ? dmns[(uint32_t)l / (uint32_t)A] * kscale : 0.f;
+      const float* urow = U + (lv ? X[2 * (int64_t)((uint32_t)l / rows_per_n)] : 0) * D;
+      const float* hrow = hbuf + l * DP;
+      f32x16 acc[ND];
+#pragma unroll
+      for (int nt = 0; nt < ND; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+      for (int j = 0; j < KD; ++j) {
+        const int d = 2 * j + h;
+        const float hv = lv ? hrow[d] : 0.f;
+        const float uv = lv ? urow[d] : 0.f;
+        const float a = hv > 0.f ? dmv * uv : 0.f;
+#pragma unroll
+        for (int nt = 0; nt < ND; ++nt) acc[nt] = MFMA32(a, wd[j][nt], acc[nt]);
+      }
+      // rows of the tile -> gV[cand]; with A == 2 rows (2q, 2q+1) are one candidate and sit in adjacent registers
+#pragma unroll
+      for (int nt = 0; nt < ND; ++nt) {
+        const int dd = dbase + nt * 32 + c31;
+        if (A == 2) {
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const int64_t lr = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (lr < L && dd < D) atomicAdd(&gV[(int64_t)cand[lr >> 1] * D + dd], acc[nt][r] + acc[nt][r + 1]);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t lr = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (lr < L && dd < D) atomicAdd(&gV[(int64_t)cand[(uint32_t)lr / (uint32_t)A] * D + dd], acc[nt][r]);
+          }
+        }
+      }
+    }
+  } else {
+    float gb_acc = 0.f;
+    const int d = dbase + lane;
+    const bool dv = lane < DW && d < D;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      int64_t cur_n = -1, u = 0;
+      float ud = 0.f, due = 0.f;
+      for (int row = 0; row < 32; ++row) {
+        const int64_t l = tile * 32 + row;
+        if (l >= L) break;
+        const int64_t n = (uint32_t)l / rows_per_n;
+        if (n != cur_n) {
+          if (cur_n >= 0 && dv) atomicAdd(&gU[u * D + d], due);
+          cur_n = n;
+          u = X[2 * n];
+          ud = dv ? U[u * D + d] : 0.f;
+          due = 0.f;
+        }
+        const float dmv = dmns[(uint32_t)l / (uint32_t)A];
+        const float hv = dv ? hbuf[l * DP + d] : 0.f;
+        due = fmaf(dmv, hv, due);
+        const float dzv = hv > 0.f ? dmv * kscale * ud : 0.f;
+        if (lane < DW) dzbuf[l * DP + d] = dzv;
+        gb_acc += dzv;
+      }
+      if (cur_n >= 0 && dv) atomicAdd(&gU[u * D + d], due);
+    }
+    if (dv) atomicAdd(&gb[d], gb_acc);
   }
 }
 
-// ================================================================================================ K5: noise backward
-// gW[:, D:] += A^T B over rows:  MODE 0/1: A = dz [L,DP], B = eps [L,F] (regenerated / injected);  MODE 2: A = dzn [N,DP],
-// B = feat[X[n,1]] (the W_f feat term).  Wave task = 32 rows x one 128-wide f chunk x ND*32 rows d of gW; the
-// 32x32 accumulators (ND*4 tiles) live in registers over the block's whole row range and leave through one
+// ================================================================================================ K4: backward, dW_f
+// gW[:, D:] += dz^T (feat + eps) over the rows.  Wave task = 32 rows x one 128-wide f chunk x ND*32 rows d of gW; the
+// B operand is feat[i0(l)][f] + eps(l, f) with eps regenerated by ONE Philox call per k-step (its 4 normals are the 4
+// N-tiles).  Accumulators (ND*4 tiles of 32x32) stay in registers over the block's row range and leave through one
 // float-atomic pass shaped as two 128-B row segments per wave instruction.
 template <int ND, int MODE>
-__global__ __launch_bounds__(512) void k_noise_bwd(const float* __restrict__ Asrc, const float* __restrict__ Bsrc,
-                                                   const int64_t* __restrict__ X, float* __restrict__ gW, int64_t R,
-                                                   int D, int F, int DP, rng_key nkey, float nscale) {
+__global__ __launch_bounds__(512) void k_noise_bwd(const float* __restrict__ dzbuf, const float* __restrict__ noise,
+                                                   const float* __restrict__ feat, const int* __restrict__ it0row,
+                                                   float* __restrict__ gW, int64_t L, int D, int F, int DP, rng_key nkey,
+                                                   float nscale) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, c31 = lane & 31;
   const int dbase = blockIdx.y * ND * 32;
@@ -427,29 +485,34 @@ __global__ __launch_bounds__(512) void k_noise_bwd(const float* __restrict__ Asr
     for (int o = 0; o < 4; ++o)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][o][r] = 0.f;
-  const int64_t ntiles = (R + 31) / 32;
+  const int64_t ntiles = (L + 31) / 32;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
 #pragma unroll 2
     for (int j = 0; j < 16; ++j) {
       const int64_t l = tile * 32 + 2 * j + h;
+      const bool lv = l < L;
       float a[ND], bq[4];
 #pragma unroll
-      for (int mt = 0; mt < ND; ++mt) a[mt] = l < R ? Asrc[l * DP + dbase + mt * 32 + c31] : 0.f;
+      for (int mt = 0; mt < ND; ++mt) a[mt] = lv ? dzbuf[l * DP + dbase + mt * 32 + c31] : 0.f;
+      const float* frow = feat + (int64_t)(lv ? it0row[l] : 0) * F;
       if (MODE == 0) {
         noise4((uint32_t)l, (uint32_t)(wave * 32 + c31), nkey, nscale, bq);
       } else {
-        const int64_t row = (MODE == 2 && l < R) ? X[2 * l + 1] : l;
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
           const int f = wave * 128 + 32 * o + c31;
-          bq[o] = (l < R && f < F) ? Bsrc[row * F + f] : 0.f;
+          bq[o] = (lv && f < F) ? noise[l * F + f] : 0.f;
         }
+      }
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const int f = wave * 128 + 32 * o + c31;
+        bq[o] = __fadd_rn((lv && f < F) ? frow[f] : 0.f, bq[o]);
       }
 #pragma unroll
       for (int mt = 0; mt < ND; ++mt)
 #pragma unroll
-        for (int o = 0; o < 4; ++o)
-          acc[mt][o] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], bq[o], acc[mt][o], 0, 0, 0);
+        for (int o = 0; o < 4; ++o) acc[mt][o] = MFMA32(a[mt], bq[o], acc[mt][o]);
     }
   }
 #pragma unroll
@@ -468,14 +531,22 @@ __global__ __launch_bounds__(512) void k_noise_bwd(const float* __restrict__ Asr
 static int check_model(const dccf_model_t* M) {
   ARG_CHECK(M != nullptr, "model is NULL");
   ARG_CHECK(M->D == 16 || M->D == 32 || M->D == 64 || M->D == 128, "D must be 16, 32, 64 or 128");
-  ARG_CHECK(M->F >= 1 && M->F <= 1024, "F must be in [1, 1024]");
-  ARG_CHECK(M->S >= 0 && M->S <= 255 && M->A >= 1 && M->A <= 64, "S in [0,255], A in [1,64]");
+  ARG_CHECK(M->F >= 1 && M->F <= 896, "F must be in [1, 896] (7 feature-chunk waves + 1 item wave per workgroup)");
+  ARG_CHECK(M->S >= 0 && M->S <= 63 && M->A >= 1 && M->A <= 64, "S in [0,63], A in [1,64]");
   ARG_CHECK(M->user_num > 0 && M->item_num > 0 && M->item_num < 2147483647LL, "bad user_num / item_num");
   ARG_CHECK(M->U && M->V && M->W && M->b && M->feat, "NULL parameter / feature pointer");
   ARG_CHECK(M->expo || (M->ipsP && M->ipsQ && M->ipsBu && M->ipsBi && M->ipsProp && M->ipsD > 0),
             "need expo or the IPS factors");
   return 0;
 }
+
+#define BY_D(D, CALL)              \
+  switch (D) {                     \
+    case 16: { CALL(16); } break;  \
+    case 32: { CALL(32); } break;  \
+    case 64: { CALL(64); } break;  \
+    default: { CALL(128); } break; \
+  }
 
 static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd, const int64_t* X, const float* Y,
                     int64_t N, int rank, float dropout, const dccf_grads_t* G, float* pred, float* loss, bool train,
@@ -492,7 +563,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     ARG_CHECK(G && G->gU && G->gV && G->gW && G->gb && loss, "NULL gradient / loss pointer");
     ARG_CHECK(rank == 0 || rank == 1, "rank must be 0 or 1");
     if (rank == 1) ARG_CHECK(N % 2 == 0, "rank==1 needs [positives ; negatives] (even N)");
-    if (rank == 0) ARG_CHECK(Y != nullptr, "rank==0 needs Y");
+    if (rank == 0) ARG_CHECK(Y != nullptr || N == 0, "rank==0 needs Y");
   }
   if (N == 0) {
     if (train) HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), st));
@@ -504,11 +575,11 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
   char* ws = ctx->ws;
   int* cand = (int*)(ws + y.cand);
   float* WT = (float*)(ws + y.WT);
-  float* base = (float*)(ws + y.base);
   float* hbuf = (float*)(ws + y.h);
+  float* dzbuf = (float*)(ws + y.dz);
   float* m = (float*)(ws + y.m);
   float* dmns = (float*)(ws + y.dmns);
-  float* dzn = (float*)(ws + y.dzn);
+  int* it0row = (int*)(ws + y.it0);
 
   const rng_key ckey = make_key(rnd->seed, STREAM_CAND, rnd->step);
   const rng_key nkey = make_key(rnd->seed, STREAM_NOISE, rnd->step);
@@ -516,6 +587,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
   const float nscale = -2.0f * 0.69314718055994530942f * M->std * M->std;
   const float kscale = dropout > 0.f ? 1.0f / (float)(1.0 - (double)dropout) : 1.0f;
   const uint32_t thr = dropout > 0.f ? drop_threshold(dropout) : 0u;
+  const int64_t ntiles = (y.L + 31) / 32;
 
   {
     const int64_t total = (int64_t)(D + y.FP) * y.DP + y.NS + (y.GY > 1 ? y.L : 0) + 1;
@@ -526,64 +598,55 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     prof_end(ctx, 0, st);
   }
   {
-    const int64_t ng = (N + BASE_RB - 1) / BASE_RB;
-    const int grid = (int)min((int64_t)2048, ng);
-    const size_t smem = ((size_t)BASE_RB * F + (size_t)BASE_RB * S1 * D + (size_t)256 * BASE_RB) * 4;
-    ARG_CHECK(smem <= 160 * 1024, "S too large for the base kernel's LDS tile");
+    const dim3 grid((unsigned)min((int64_t)1024, ntiles), y.GY), block(64 * (y.NC + 1));
+    const size_t smem = (size_t)(y.NC + 1) * 32 * y.ND * 32 * 4;
     prof_begin(ctx, st);
-    hipLaunchKernelGGL(k_base, dim3(grid), dim3(256), smem, st, WT, M->b, M->V, M->feat, X, cand, base, N, S1, D, F,
-                       y.DP);
-    prof_end(ctx, 1, st);
-  }
-  {
-    const int64_t ntiles = (y.L + 31) / 32;
-    const dim3 grid((unsigned)min((int64_t)1024, ntiles), y.GY), block(64 * y.NC);
-    const size_t smem = (size_t)y.NC * 32 * y.ND * 32 * 4;
-#define LAUNCH_FWD(ND_, MODE_)                                                                                      \
-  hipLaunchKernelGGL((k_noise_fwd<ND_, MODE_>), grid, block, smem, st, WT, base, M->U, X, rnd->noise, rnd->keep, hbuf, \
-                     m, y.L, S1, A, D, F, y.DP, nkey, dkey, nscale, thr, kscale)
-    prof_begin(ctx, st);
-    if (y.ND == 1) { if (fused) LAUNCH_FWD(1, 0); else LAUNCH_FWD(1, 1); }
-    else           { if (fused) LAUNCH_FWD(2, 0); else LAUNCH_FWD(2, 1); }
-    prof_end(ctx, 2, st);
+#define LAUNCH_FWD(D_)                                                                                               \
+  if (fused)                                                                                                         \
+    hipLaunchKernelGGL((k_noise_fwd<D_, 0>), grid, block, smem, st, WT, M->b, M->U, M->V, M->feat, X, cand, rnd->noise, \
+                       rnd->keep, hbuf, m, it0row, y.L, S1, A, F, nkey, dkey, nscale, thr, kscale);                  \
+  else                                                                                                               \
+    hipLaunchKernelGGL((k_noise_fwd<D_, 1>), grid, block, smem, st, WT, M->b, M->U, M->V, M->feat, X, cand, rnd->noise, \
+                       rnd->keep, hbuf, m, it0row, y.L, S1, A, F, nkey, dkey, nscale, thr, kscale);
+    BY_D(D, LAUNCH_FWD)
 #undef LAUNCH_FWD
+    prof_end(ctx, 2, st);
   }
   {
     const int64_t units = (train && rank == 1) ? N / 2 : N;
-    const int grid = (int)min((int64_t)2048, (units + 255) / 256);
+    const int GS = S1 <= 16 ? 16 : (S1 <= 32 ? 32 : 64);
+    const int grid = (int)min((int64_t)2048, (units * GS + 255) / 256);
     prof_begin(ctx, st);
-    hipLaunchKernelGGL(k_pair_epilogue, dim3(grid), dim3(256), 0, st, *M, X, Y, cand, m, dmns, pred, loss, N, rank,
-                       train ? 1 : 0);
+#define LAUNCH_PE(GS_)                                                                                              \
+  hipLaunchKernelGGL((k_pair_epilogue<GS_>), dim3(grid), dim3(256), 0, st, *M, X, Y, cand, m, dmns, pred, loss, N, rank, \
+                     train ? 1 : 0)
+    if (GS == 16) LAUNCH_PE(16); else if (GS == 32) LAUNCH_PE(32); else LAUNCH_PE(64);
+#undef LAUNCH_PE
     prof_end(ctx, 3, st);
   }
   if (train) {
     {
-      const int RB = 256 / y.DP;
-      const int64_t ng = (N + RB - 1) / RB;
-      const int grid = (int)min((int64_t)512, ng);
-      const size_t smem = (size_t)RB * S1 * y.DP * 4 * 2 + (size_t)RB * S1 * 4 * 2;
-      ARG_CHECK(smem <= 160 * 1024, "S too large for the backward kernel's LDS tile");
+      const dim3 grid((unsigned)min((int64_t)512, ntiles), y.GY);
       prof_begin(ctx, st);
-      hipLaunchKernelGGL(k_bwd_small, dim3(grid), dim3(256), max(smem, (size_t)1024), st, M->W, M->U, M->V, X, cand,
-                         dmns, hbuf, dzn, G->gU, G->gV, G->gW, G->gb, N, S1, A, D, F, y.DP, kscale);
+#define LAUNCH_MISC(D_)                                                                                             \
+  hipLaunchKernelGGL((k_bwd_misc<D_>), grid, dim3(192), 0, st, M->W, M->U, M->V, X, cand, dmns, hbuf, dzbuf, G->gU, G->gV, \
+                     G->gW, G->gb, y.L, S1, A, F, kscale);
+      BY_D(D, LAUNCH_MISC)
+#undef LAUNCH_MISC
       prof_end(ctx, 4, st);
     }
     {
-      const int64_t ntiles = (y.L + 31) / 32;
-      const dim3 grid((unsigned)min((int64_t)256, ntiles), y.GY), block(64 * y.NC);
-#define LAUNCH_BWD(ND_, MODE_, A_, B_, R_, G_)                                                                    \
-  hipLaunchKernelGGL((k_noise_bwd<ND_, MODE_>), G_, block, 0, st, A_, B_, X, G->gW, R_, D, F, y.DP, nkey, nscale)
+      // row-splits of the reduction: every block ends with ND*4*16*64*4 B of float atomics per wave, so few blocks
+      // with >= 2 tiles each when the batch is small, one block per CU when it is large
+      const int64_t gx = min((int64_t)256, max(min(ntiles, (int64_t)64), ntiles / 2));
+      const dim3 grid((unsigned)gx, y.GY), block(64 * y.NC);
       prof_begin(ctx, st);
-      if (y.ND == 1) { if (fused) LAUNCH_BWD(1, 0, hbuf, nullptr, y.L, grid); else LAUNCH_BWD(1, 1, hbuf, rnd->noise, y.L, grid); }
-      else           { if (fused) LAUNCH_BWD(2, 0, hbuf, nullptr, y.L, grid); else LAUNCH_BWD(2, 1, hbuf, rnd->noise, y.L, grid); }
-      prof_end(ctx, 5, st);
-      const int64_t ntn = (N + 31) / 32;
-      const dim3 gridn((unsigned)min((int64_t)256, ntn), y.GY);
-      prof_begin(ctx, st);
-      if (y.ND == 1) LAUNCH_BWD(1, 2, dzn, M->feat, N, gridn);
-      else           LAUNCH_BWD(2, 2, dzn, M->feat, N, gridn);
-      prof_end(ctx, 6, st);
+#define LAUNCH_BWD(ND_, MODE_) \
+  hipLaunchKernelGGL((k_noise_bwd<ND_, MODE_>), grid, block, 0, st, dzbuf, rnd->noise, M->feat, it0row, G->gW, y.L, D, F, y.DP, nkey, nscale)
+      if (y.ND == 1) { if (fused) LAUNCH_BWD(1, 0); else LAUNCH_BWD(1, 1); }
+      else           { if (fused) LAUNCH_BWD(2, 0); else LAUNCH_BWD(2, 1); }
 #undef LAUNCH_BWD
+      prof_end(ctx, 5, st);
     }
   }
   HIP_TRY(hipGetLastError());
@@ -609,7 +672,7 @@ extern "C" int dccf_ctx_reserve(dccf_ctx* ctx, int64_t max_rows, int32_t D, int3
 
 // ================================================================================================ debug: workspace
 // Copies one workspace array of the LAST call with these shapes to `dst` (device) — for the parity tests only.
-// which: 0 cand(int32 [N*S1]) 1 WT 2 base [N*S1,DP] 3 h/dz [L,DP] 4 m [L] 5 dmns [N*S1] 6 dzn [N,DP]; info[0..3] = DP, FP, count, elem size
+// which: 0 cand(int32 [N*S1]) 1 WT 3 h [L,DP] 4 m [L] 5 dmns [N*S1] 6 dz [L,DP] 7 it0(int32 [L]); info = DP, FP, count, 4
 extern "C" int dccf_debug_workspace(dccf_ctx* ctx, int64_t N, int32_t D, int32_t F, int32_t S, int32_t A, int32_t which,
                                     void* dst, int64_t* info, void* stream) {
   ARG_CHECK(ctx && info, "NULL argument");
@@ -619,11 +682,11 @@ extern "C" int dccf_debug_workspace(dccf_ctx* ctx, int64_t N, int32_t D, int32_t
   switch (which) {
     case 0: off = y.cand; cnt = (size_t)y.NS; break;
     case 1: off = y.WT; cnt = (size_t)(D + y.FP) * y.DP; break;
-    case 2: off = y.base; cnt = (size_t)y.NS * y.DP; break;
     case 3: off = y.h; cnt = (size_t)y.L * y.DP; break;
     case 4: off = y.m; cnt = (size_t)y.L; break;
     case 5: off = y.dmns; cnt = (size_t)y.NS; break;
-    case 6: off = y.dzn; cnt = (size_t)N * y.DP; break;
+    case 6: off = y.dz; cnt = (size_t)y.L * y.DP; break;
+    case 7: off = y.it0; cnt = (size_t)y.L; break;
     default: return dccf_fail(-1, "argument error: unknown workspace array");
   }
   info[0] = y.DP; info[1] = y.FP; info[2] = (int64_t)cnt; info[3] = 4;

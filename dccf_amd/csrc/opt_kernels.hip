@@ -9,6 +9,10 @@
 // 32 B per parameter (28 B without the fused zero_grad).
 #include "common.hpp"
 
+// No implicit FMA contraction in this file: a*b+c written as two operations stays two roundings (explicit fmaf() calls
+// are still FMAs).  It keeps "fused draws == injected draws" bit for bit and the optimizer in torch's op order.
+#pragma clang fp contract(off)
+
 thread_local char g_dccf_err[512] = "";
 
 extern "C" const char* dccf_last_error(void) { return g_dccf_err; }
