@@ -276,9 +276,9 @@ def debug_keep(L, D, dropout, seed, step, device):
 
 
 def debug_workspace(ctx, N, D, F, S, A, which, device):
-    """Workspace array `which` of the last call (tests only): 0 cand 1 WT 3 h 4 m 5 dmns 6 dz 7 it0."""
+    """Workspace array `which` of the last call (tests only): 0 cand 1 WT 3 h 4 m 5 dmns."""
     info = (C.c_int64 * 4)()
     check(load().dccf_debug_workspace(ctx.h, N, D, F, S, A, which, None, info, stream()))
-    out = torch.empty(info[2], dtype=torch.int32 if which in (0, 7) else torch.float32, device=device)
+    out = torch.empty(info[2], dtype=torch.int32 if which == 0 else torch.float32, device=device)
     check(load().dccf_debug_workspace(ctx.h, N, D, F, S, A, which, ptr(out), info, stream()))
     return out, int(info[0]), int(info[1])

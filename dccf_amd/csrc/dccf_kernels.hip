@@ -11,15 +11,14 @@
 //            applies relu + dropout, stores h [L,D] and the row dot m[l] = <U[u], h[l]>.
 //   epilogue (k_pair_epilogue)  softmax over the candidates of Expo[u, cand] (one lane per candidate), prediction,
 //            BPR / MSE loss and d loss / d m.
-//   backward (k_bwd_misc)   three role waves per 32 rows: dW_i += dz^T V[cand] (MFMA), dV[cand] += dz W_i (MFMA, rows
-//            leave through 128-B float-atomic segments, the A noise copies summed in registers first), and a streaming
-//            wave for dU[u] += dm h (row-run reduction before the atomic), db and the dz rows.
-//            (k_noise_bwd)  dW_f += dz^T (feat + eps): eps is REGENERATED from the same counters directly as the MFMA
-//            B operand; 32x32 accumulators stay in registers over the workgroup's whole row range.
+//   backward (k_bwd)  one barrier-free kernel of role waves that walk the batch rows: dW_f += dz^T eps with eps
+//            REGENERATED from the same counters directly as the MFMA B operand (+ one k-step per batch row for the
+//            feature term), dW_i += dz^T V[cand], dV[cand] += dz W_i, dU, db; 32x32 accumulators stay in registers over
+//            the workgroup's whole range and leave through one shaped float-atomic pass.
 //
 // HBM layout (fp32 row-major): U [user_num,D], V [item_num,D], W [D,D+F], b [D], feat [item_num,F], expo [user_num,
 // item_num].  Workspace per call (ctx slab): cand int32 [N,S1]; WT [(D+FP),DP] = W transposed, zero padded (DP = D
-// rounded to 32/64, FP = F rounded to 128); h [L,DP]; dz [L,DP]; m [L]; dmns [N*S1]; it0 int32 [L] (true item per row).
+// rounded to 32/64, FP = F rounded to 128); h [L,DP]; m [L]; dmns [N*S1].
 #include "common.hpp"
 
 // No implicit FMA contraction in this file: a*b+c written as two operations stays two roundings (explicit fmaf() calls
@@ -28,11 +27,14 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+// Pins a loaded value as "used here": hipcc otherwise sinks a load into the only branch that consumes it
+// (`cond ? f(load) : 0` becomes s_cbranch_execz + load + s_waitcnt vmcnt(0)), serialising a k-loop on memory latency.
+#define KEEP(x) asm volatile("" ::"v"(x))
 
 struct Lay {
   int DP, FP, NC, S1, ND, GY;
   int64_t N, L, NS;
-  size_t cand, WT, h, dz, m, dmns, it0, total;
+  size_t cand, WT, h, m, dmns, total;
 };
 
 static Lay make_layout(int64_t N, int D, int F, int S, int A) {
@@ -50,10 +52,8 @@ static Lay make_layout(int64_t N, int D, int F, int S, int A) {
   y.cand = o;  o += align_up((size_t)y.NS * 4, 256);
   y.WT = o;    o += align_up((size_t)(D + y.FP) * y.DP * 4, 256);
   y.h = o;     o += align_up((size_t)y.L * y.DP * 4, 256);
-  y.dz = o;    o += align_up((size_t)y.L * y.DP * 4, 256);
   y.m = o;     o += align_up((size_t)y.L * 4, 256);
   y.dmns = o;  o += align_up((size_t)y.NS * 4, 256);
-  y.it0 = o;   o += align_up((size_t)y.L * 4, 256);
   y.total = o;
   return y;
 }
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT,
                                                    const float* __restrict__ feat, const int64_t* __restrict__ X,
                                                    const int* __restrict__ cand, const float* __restrict__ noise,
                                                    const uint8_t* __restrict__ keep, float* __restrict__ hbuf,
-                                                   float* __restrict__ m, int* __restrict__ it0row, int64_t L, int S1,
+                                                   float* __restrict__ m, int64_t L, int S1,
                                                    int A, int F, rng_key nkey, rng_key dkey, float nscale,
                                                    uint32_t drop_thr, float kscale) {
   extern __shared__ float zpart[];   // [NW][32][DW]
@@ -144,37 +144,40 @@ __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT,
     for (int nt = 0; nt < ND; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    // NOTE: no load sits inside a conditional expression: hipcc branches around such a load and waits vmcnt(0) for it,
+    // which serialises the k-steps.  Rows past L read row L-1 (their results are never stored); columns past F read
+    // column F-1 (their W rows are zero).
+    const int64_t lc = lv ? l : L - 1;
     if (chunk) {
-      const int64_t it0 = lv ? X[2 * (int64_t)((uint32_t)l / rows_per_n) + 1] : 0;
+      const int64_t it0 = X[2 * (int64_t)((uint32_t)lc / rows_per_n) + 1];
       const float* frow = feat + it0 * F;
-#pragma unroll
+      const float* nrow = MODE == 1 ? noise + lc * F : nullptr;
+      int fbase = wave * 128 + h;
+      asm volatile("" : "+v"(fbase));               // opaque per tile: the 64 clamped offsets below must not be hoisted
+#pragma unroll                                      // out of the tile loop and kept live (they would spill the W slice)
       for (int c2 = 0; c2 < 16; ++c2) {
-        float a[4];
+        float a[4], fv[4];
         const int c = 2 * c2 + h;
-        if (MODE == 1) {
-#pragma unroll
-          for (int o = 0; o < 4; ++o) {
-            const int f = wave * 128 + c + 32 * o;
-            a[o] = (lv && f < F) ? noise[l * F + f] : 0.f;
-          }
-        } else {
-          noise4((uint32_t)l, (uint32_t)(wave * 32 + c), nkey, nscale, a);
-        }
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-          const int f = wave * 128 + c + 32 * o;
-          const float fv = (lv && f < F) ? frow[f] : 0.f;
-          a[o] = __fadd_rn(fv, a[o]);               // sample_feature_embeddings = feature + noise (DCCF.py:87); no
-                                                    // contraction with Box-Muller's multiply: fused == injected bit for bit
+          const int f = min(fbase + 2 * c2 + 32 * o, F - 1);
+          fv[o] = frow[f];
+          if (MODE == 1) a[o] = nrow[f];
+        }
+        if (MODE == 0) noise4((uint32_t)l, (uint32_t)(wave * 32 + c), nkey, nscale, a);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          a[o] = fv[o] + a[o];                      // sample_feature_embeddings = feature + noise (DCCF.py:87)
 #pragma unroll
           for (int nt = 0; nt < ND; ++nt) acc[nt] = MFMA32(a[o], breg[(c2 * 4 + o) * ND + nt], acc[nt]);
         }
+        __builtin_amdgcn_sched_barrier(0);          // keep the next group's loads from being hoisted (register budget)
       }
     } else {
-      const float* vrow = V + (int64_t)(lv ? cand[(uint32_t)l / (uint32_t)A] : 0) * D;
+      const float* vrow = V + (int64_t)cand[(uint32_t)lc / (uint32_t)A] * D;
 #pragma unroll
       for (int j = 0; j < KI; ++j) {
-        const float a = lv ? vrow[2 * j + h] : 0.f;
+        const float a = vrow[2 * j + h];
 #pragma unroll
         for (int nt = 0; nt < ND; ++nt) acc[nt] = MFMA32(a, breg[j * ND + nt], acc[nt]);
       }
@@ -216,7 +219,6 @@ __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT,
       if (lane == 0) {
         if (gridDim.y == 1) m[lr] = part;
         else atomicAdd(&m[lr], part);
-        if (blockIdx.y == 0) it0row[lr] = (int)X[2 * n + 1];
       }
     }
     __syncthreads();
@@ -317,214 +319,269 @@ __global__ __launch_bounds__(256) void k_pair_epilogue(dccf_model_t M, const int
   }
 }
 
-// ================================================================================================ K3: backward, small terms
-// dz[l][d] = dm[l] * U[u(l)][d] * [h[l][d] > 0] * kscale.  Three role waves share one 32-row tile per iteration:
-//   wave 0  gW[:, 0:D] += dz^T V[cand]   (MFMA: M = d, N = d', K = rows; accumulators live over the block's tiles)
-//   wave 1  gV[cand] += dz W_i           (MFMA: M = rows, N = d', K = d; W_i in registers; the A noise copies of a
-//                                          candidate are summed in registers, rows leave as 128-B atomic segments)
-//   wave 2  gU[u] += sum dm h (run-length reduction over the rows of one batch row), gb += dz, dz rows -> workspace
-template <int D_>
-__global__ __launch_bounds__(192) void k_bwd_misc(const float* __restrict__ W, const float* __restrict__ U,
-                                                  const float* __restrict__ V, const int64_t* __restrict__ X,
-                                                  const int* __restrict__ cand, const float* __restrict__ dmns,
-                                                  const float* __restrict__ hbuf, float* __restrict__ dzbuf,
-                                                  float* __restrict__ gU, float* __restrict__ gV,
-                                                  float* __restrict__ gW, float* __restrict__ gb, int64_t L, int S1, int A,
-                                                  int F, float kscale) {
-  constexpr int D = D_;
+// ================================================================================================ K3: backward
+// dz[l][d] = dm[l] * U[u(l)][d] * [h[l][d] > 0] * kscale is never stored: every role rebuilds the operand it needs from
+// h, dm and the user row.  grid = (row splits, roles x column halves); a workgroup has ONE role and 4 waves that split
+// the batch rows n of its row split (rpn = S1*A consecutive rows l per n):
+//   role tq < NC    gW[:, D+128tq ..] += dz^T eps   MFMA, M = d, N = f (4 tiles), K = the rows of n, two rows per k-step; eps
+//                   is REGENERATED by one Philox call per k-step directly as the B operand (its 4 normals = the 4 N
+//                   tiles).  The feature term dz^T feat costs ONE more k-step per n: A = sum of the n's dz rows (kept in
+//                   a register while walking them), B = feat[i0(n)].  Role 0 also emits gU[u] += sum dm h (one atomic
+//                   row add per batch row) and gb += sum dz — by-products of building A.
+//   role NC         gW[:, 0:D] += dz^T V[cand]      same A operand, B = candidate rows.
+//   role NC+1       gV[cand] += dz W_i              MFMA, M = rows, N = d', K = d; W_i in registers; the A noise copies
+//                   of a candidate are summed in registers and rows leave as 128-B float-atomic segments.
+// Float atomics issue at about one 256-B wave instruction per 50 ns PER CU (MI355X_MICROARCH.md), so what a workgroup
+// may dump is small: the 4 waves' 32x32 accumulators are first summed through LDS and each CU then emits 32 KB, shaped
+// as two 128-B row segments per wave instruction.
+struct BwdArgs {
+  const float *W, *U, *V, *feat;
+  const int64_t* X;
+  const int* cand;
+  const float *dmns, *hbuf, *noise;
+  float *gU, *gV, *gW, *gb;
+  int64_t N;
+  int S1, A, F, NC;
+  float kscale, nscale;
+  rng_key nkey;
+};
+
+// roles "feature chunk" (CHUNK) and "item": A = dz^T for the rows of n, B = eps (regenerated / injected) or V[cand]
+template <int D, int MODE, bool CHUNK>
+__device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int role, int dbase) {
   constexpr int DP = D <= 32 ? 32 : (D + 63) / 64 * 64;
-  constexpr int ND = D <= 32 ? 1 : 2;     // 32-wide tiles of this block's column half
-  constexpr int DW = ND * 32;
-  constexpr int NT = (D + 31) / 32;       // 32-wide tiles over all of D
-  constexpr int KD = D / 2;
+  constexpr int ND = D <= 32 ? 1 : 2;
+  constexpr int NT = (D + 31) / 32;
+  constexpr int NB = CHUNK ? 4 : NT;      // N tiles of this role
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, c31 = lane & 31;
-  const int dbase = blockIdx.y * DW;
-  const uint32_t rows_per_n = (uint32_t)(S1 * A);
-  const int64_t ntiles = (L + 31) / 32;
-  if (wave == 0) {
-    f32x16 acc[ND][NT];
+  const int S1 = p.S1, A = p.A, F = p.F;
+  const int rpn = S1 * A;
+  const int KS = (rpn + 1) / 2;
+  const int64_t n0 = (int64_t)blockIdx.x * 4 + wave, nstride = (int64_t)gridDim.x * 4;
+  f32x16 acc[ND][NB];
 #pragma unroll
-    for (int mt = 0; mt < ND; ++mt)
+  for (int mt = 0; mt < ND; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
+    for (int o = 0; o < NB; ++o)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-#pragma unroll 2
-      for (int j = 0; j < 16; ++j) {
-        const int64_t l = tile * 32 + 2 * j + h;
-        const bool lv = l < L;
-        const uint32_t ns = (uint32_t)l / (uint32_t)A;
-        const float dmv = lv ? dmns[ns] * kscale : 0.f;
-        const int64_t u = lv ? X[2 * (int64_t)((uint32_t)l / rows_per_n)] : 0;
-        const float* vrow = V + (int64_t)(lv ? cand[ns] : 0) * D;
-        float a[ND], b[NT];
+      for (int r = 0; r < 16; ++r) acc[mt][o][r] = 0.f;
+  float gb_acc[ND];
+  bool dok[ND];
+#pragma unroll
+  for (int mt = 0; mt < ND; ++mt) {
+    gb_acc[mt] = 0.f;
+    dok[mt] = dbase + mt * 32 + c31 < D;
+  }
+  for (int64_t n = n0; n < p.N; n += nstride) {
+    const int64_t u = p.X[2 * n];
+    const float* frow = p.feat + p.X[2 * n + 1] * F;
+    float uv[ND], asum[ND], due[ND], fb[NB];
+#pragma unroll
+    for (int mt = 0; mt < ND; ++mt) {
+      const float ux = p.U[u * D + min(dbase + mt * 32 + c31, D - 1)];
+      KEEP(ux);
+      uv[mt] = dok[mt] ? ux : 0.f;
+      asum[mt] = 0.f;
+      due[mt] = 0.f;
+    }
+    if (CHUNK) {
+#pragma unroll
+      for (int o = 0; o < NB; ++o) fb[o] = frow[min(role * 128 + 32 * o + c31, F - 1)];   // columns >= F are never stored
+    }
+    for (int j0 = 0; j0 < KS; j0 += 4) {
+      float hv[4][ND], dmv[4], bq[4][NB];
+      int64_t lrow[4];
+      bool lvv[4];
+      // the loads of four k-steps are issued together; every load is unconditional from a clamped address (rows past
+      // the n read its last row and are zeroed through dm) — a load inside `cond ? load : 0` makes hipcc branch around it
+      // and wait vmcnt(0), which serialises the k-steps
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int r = 2 * (j0 + jj) + h;
+        const bool lv = r < rpn;
+        const int rc = lv ? r : rpn - 1;
+        lrow[jj] = n * rpn + rc;
+        const int64_t ns = n * S1 + rc / A;
+        dmv[jj] = p.dmns[ns];
+        lvv[jj] = lv;
+#pragma unroll
+        for (int mt = 0; mt < ND; ++mt) hv[jj][mt] = p.hbuf[lrow[jj] * DP + dbase + mt * 32 + c31];
+        if (!CHUNK) {
+          const float* vrow = p.V + (int64_t)p.cand[ns] * D;
+#pragma unroll
+          for (int nt = 0; nt < NB; ++nt) bq[jj][nt] = vrow[min(nt * 32 + c31, D - 1)];
+        } else if (MODE == 1) {
+#pragma unroll
+          for (int o = 0; o < NB; ++o) bq[jj][o] = p.noise[lrow[jj] * F + min(role * 128 + 32 * o + c31, F - 1)];
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {              // pin the batch (one wait), then mask
+        KEEP(dmv[jj]);
+#pragma unroll
+        for (int mt = 0; mt < ND; ++mt) KEEP(hv[jj][mt]);
+        if (!CHUNK || MODE == 1) {
+#pragma unroll
+          for (int o = 0; o < NB; ++o) KEEP(bq[jj][o]);
+        }
+        dmv[jj] = lvv[jj] ? dmv[jj] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < ND; ++mt) hv[jj][mt] = dok[mt] ? hv[jj][mt] : 0.f;
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        if (CHUNK && MODE == 0) noise4((uint32_t)lrow[jj], (uint32_t)(role * 32 + c31), p.nkey, p.nscale, bq[jj]);
+        float a[ND];
 #pragma unroll
         for (int mt = 0; mt < ND; ++mt) {
-          const int d = dbase + mt * 32 + c31;
-          const bool ok = lv && d < D;
-          const float hv = ok ? hbuf[l * DP + d] : 0.f;
-          const float uv = ok ? U[u * D + d] : 0.f;
-          a[mt] = hv > 0.f ? dmv * uv : 0.f;
+          a[mt] = hv[jj][mt] > 0.f ? (dmv[jj] * uv[mt]) * p.kscale : 0.f;     // 0 for the k-steps past KS (dm = 0)
+          asum[mt] += a[mt];
+          due[mt] = fmaf(dmv[jj], hv[jj][mt], due[mt]);
         }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b[nt] = (lv && nt * 32 + c31 < D) ? vrow[nt * 32 + c31] : 0.f;
 #pragma unroll
         for (int mt = 0; mt < ND; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA32(a[mt], b[nt], acc[mt][nt]);
+          for (int o = 0; o < NB; ++o) acc[mt][o] = MFMA32(a[mt], bq[jj][o], acc[mt][o]);
       }
     }
+    float tot[ND];
+#pragma unroll
+    for (int mt = 0; mt < ND; ++mt) tot[mt] = asum[mt] + __shfl_xor(asum[mt], 32, 64);
+    if (CHUNK) {       // feature term: one k-step, A = sum of the n's dz rows (k = 0 half only), B = feat[i0(n)]
+#pragma unroll
+      for (int mt = 0; mt < ND; ++mt) {
+        const float a2 = h == 0 ? tot[mt] : 0.f;
+#pragma unroll
+        for (int o = 0; o < NB; ++o) acc[mt][o] = MFMA32(a2, fb[o], acc[mt][o]);
+      }
+    }
+    if (CHUNK && role == 0) {
+#pragma unroll
+      for (int mt = 0; mt < ND; ++mt) {
+        const float dt = due[mt] + __shfl_xor(due[mt], 32, 64);
+        if (h == 0 && dok[mt]) {
+          atomicAdd(&p.gU[u * D + dbase + mt * 32 + c31], dt);
+          gb_acc[mt] += tot[mt];
+        }
+      }
+    }
+  }
+  // sum the 4 waves' accumulators through LDS, then each wave emits a quarter of the tile set
+  constexpr int NQ = ND * NB * 16;        // accumulator registers per lane
+#pragma unroll
+  for (int mt = 0; mt < ND; ++mt)
+#pragma unroll
+    for (int o = 0; o < NB; ++o)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(wave * NQ + (mt * NB + o) * 16 + r) * 64 + lane] = acc[mt][o][r];
+  __syncthreads();
+  for (int q = wave; q < NQ; q += 4) {
+    const int mt = q / (NB * 16), o = (q / 16) % NB, r = q % 16;
+    const float v = red[(0 * NQ + q) * 64 + lane] + red[(1 * NQ + q) * 64 + lane] + red[(2 * NQ + q) * 64 + lane] +
+                    red[(3 * NQ + q) * 64 + lane];
+    const int d = dbase + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    const int col = CHUNK ? D + role * 128 + 32 * o + c31 : o * 32 + c31;
+    const bool ok = d < D && (CHUNK ? (role * 128 + 32 * o + c31 < F) : (col < D));
+    if (ok) atomicAdd(&p.gW[(int64_t)d * (D + F) + col], v);
+  }
+  if (CHUNK && role == 0 && h == 0) {
 #pragma unroll
     for (int mt = 0; mt < ND; ++mt)
+      if (dok[mt]) atomicAdd(&p.gb[dbase + mt * 32 + c31], gb_acc[mt]);
+  }
+}
+
+// role "dx": gV[cand] += dz W_i   (MFMA: M = rows of n, N = d', K = d)
+template <int D>
+__device__ __forceinline__ void bwd_dx_role(const BwdArgs& p, int dbase) {
+  constexpr int DP = D <= 32 ? 32 : (D + 63) / 64 * 64;
+  constexpr int ND = D <= 32 ? 1 : 2;
+  constexpr int KD = D / 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, c31 = lane & 31;
+  const int S1 = p.S1, A = p.A, F = p.F;
+  const int rpn = S1 * A;
+  const int64_t n0 = (int64_t)blockIdx.x * 4 + wave, nstride = (int64_t)gridDim.x * 4;
+  float wd[KD][ND];                         // W_i rows 2j+h, this block's column half
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
+  for (int j = 0; j < KD; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int d = dbase + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const int k = nt * 32 + c31;
-          if (d < D && k < D) atomicAdd(&gW[(int64_t)d * (D + F) + k], acc[mt][nt][r]);
-        }
-  } else if (wave == 1) {
-    float wd[KD][ND];                         // W_i rows 2j+h, this block's column half
-#pragma unroll
-    for (int j = 0; j < KD; ++j)
-#pragma unroll
-      for (int nt = 0; nt < ND; ++nt) {
-        const int dd = dbase + nt * 32 + c31;
-        wd[j][nt] = dd < D ? W[(int64_t)(2 * j + h) * (D + F) + dd] : 0.f;
-      }
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-      const int64_t l = tile * 32 + c31;
-      const bool lv = l < L;
-      const float dmv = lv ? dmns[(uint32_t)l / (uint32_t)A] * kscale : 0.f;
-      const float* urow = U + (lv ? X[2 * (int64_t)((uint32_t)l / rows_per_n)] : 0) * D;
-      const float* hrow = hbuf + l * DP;
+    for (int nt = 0; nt < ND; ++nt) {
+      const int dd = dbase + nt * 32 + c31;
+      const float wx = p.W[(int64_t)(2 * j + h) * (D + F) + min(dd, D - 1)];
+      wd[j][nt] = dd < D ? wx : 0.f;
+    }
+  const int RT = (rpn + 31) / 32;
+  for (int64_t n = n0; n < p.N; n += nstride) {
+    const float* urow = p.U + p.X[2 * n] * D;
+    for (int t = 0; t < RT; ++t) {
+      const int rr = t * 32 + c31;
+      const bool lv = rr < rpn;
+      const int rc = lv ? rr : rpn - 1;             // clamped: loads are unconditional, dm zeroes the row
+      const int64_t l = n * rpn + rc;
+      const float dm0 = p.dmns[n * S1 + rc / A];
+      KEEP(dm0);
+      const float dmv = lv ? dm0 : 0.f;
+      const float* hrow = p.hbuf + l * DP;
       f32x16 acc[ND];
 #pragma unroll
       for (int nt = 0; nt < ND; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+      constexpr int JB = KD < 8 ? KD : 8;           // k-steps per load batch
 #pragma unroll
-      for (int j = 0; j < KD; ++j) {
-        const int d = 2 * j + h;
-        const float hv = lv ? hrow[d] : 0.f;
-        const float uv = lv ? urow[d] : 0.f;
-        const float a = hv > 0.f ? dmv * uv : 0.f;
+      for (int j0 = 0; j0 < KD; j0 += JB) {
+        float hvv[JB], uxx[JB];
 #pragma unroll
-        for (int nt = 0; nt < ND; ++nt) acc[nt] = MFMA32(a, wd[j][nt], acc[nt]);
+        for (int jj = 0; jj < JB; ++jj) {           // issue the batch's loads ...
+          hvv[jj] = hrow[2 * (j0 + jj) + h];
+          uxx[jj] = urow[2 * (j0 + jj) + h];
+        }
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj) {           // ... then pin them (one wait for the batch)
+          KEEP(hvv[jj]);
+          KEEP(uxx[jj]);
+        }
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj) {
+          const float a = hvv[jj] > 0.f ? (dmv * uxx[jj]) * p.kscale : 0.f;
+#pragma unroll
+          for (int nt = 0; nt < ND; ++nt) acc[nt] = MFMA32(a, wd[j0 + jj][nt], acc[nt]);
+        }
       }
-      // rows of the tile -> gV[cand]; with A == 2 rows (2q, 2q+1) are one candidate and sit in adjacent registers
+      // rows -> gV[cand]; with A == 2 rows (2q, 2q+1) are one candidate and sit in adjacent registers
 #pragma unroll
       for (int nt = 0; nt < ND; ++nt) {
         const int dd = dbase + nt * 32 + c31;
         if (A == 2) {
 #pragma unroll
           for (int r = 0; r < 16; r += 2) {
-            const int64_t lr = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (lr < L && dd < D) atomicAdd(&gV[(int64_t)cand[lr >> 1] * D + dd], acc[nt][r] + acc[nt][r + 1]);
+            const int ro = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (ro < rpn && dd < D) atomicAdd(&p.gV[(int64_t)p.cand[n * S1 + (ro >> 1)] * D + dd], acc[nt][r] + acc[nt][r + 1]);
           }
         } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int64_t lr = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (lr < L && dd < D) atomicAdd(&gV[(int64_t)cand[(uint32_t)lr / (uint32_t)A] * D + dd], acc[nt][r]);
+            const int ro = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (ro < rpn && dd < D) atomicAdd(&p.gV[(int64_t)p.cand[n * S1 + ro / A] * D + dd], acc[nt][r]);
           }
         }
       }
     }
-  } else {
-    float gb_acc = 0.f;
-    const int d = dbase + lane;
-    const bool dv = lane < DW && d < D;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-      int64_t cur_n = -1, u = 0;
-      float ud = 0.f, due = 0.f;
-      for (int row = 0; row < 32; ++row) {
-        const int64_t l = tile * 32 + row;
-        if (l >= L) break;
-        const int64_t n = (uint32_t)l / rows_per_n;
-        if (n != cur_n) {
-          if (cur_n >= 0 && dv) atomicAdd(&gU[u * D + d], due);
-          cur_n = n;
-          u = X[2 * n];
-          ud = dv ? U[u * D + d] : 0.f;
-          due = 0.f;
-        }
-        const float dmv = dmns[(uint32_t)l / (uint32_t)A];
-        const float hv = dv ? hbuf[l * DP + d] : 0.f;
-        due = fmaf(dmv, hv, due);
-        const float dzv = hv > 0.f ? dmv * kscale * ud : 0.f;
-        if (lane < DW) dzbuf[l * DP + d] = dzv;
-        gb_acc += dzv;
-      }
-      if (cur_n >= 0 && dv) atomicAdd(&gU[u * D + d], due);
-    }
-    if (dv) atomicAdd(&gb[d], gb_acc);
   }
 }
 
-// ================================================================================================ K4: backward, dW_f
-// gW[:, D:] += dz^T (feat + eps) over the rows.  Wave task = 32 rows x one 128-wide f chunk x ND*32 rows d of gW; the
-// B operand is feat[i0(l)][f] + eps(l, f) with eps regenerated by ONE Philox call per k-step (its 4 normals are the 4
-// N-tiles).  Accumulators (ND*4 tiles of 32x32) stay in registers over the block's row range and leave through one
-// float-atomic pass shaped as two 128-B row segments per wave instruction.
-template <int ND, int MODE>
-__global__ __launch_bounds__(512) void k_noise_bwd(const float* __restrict__ dzbuf, const float* __restrict__ noise,
-                                                   const float* __restrict__ feat, const int* __restrict__ it0row,
-                                                   float* __restrict__ gW, int64_t L, int D, int F, int DP, rng_key nkey,
-                                                   float nscale) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int h = lane >> 5, c31 = lane & 31;
-  const int dbase = blockIdx.y * ND * 32;
-  f32x16 acc[ND][4];
-#pragma unroll
-  for (int mt = 0; mt < ND; ++mt)
-#pragma unroll
-    for (int o = 0; o < 4; ++o)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][o][r] = 0.f;
-  const int64_t ntiles = (L + 31) / 32;
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-#pragma unroll 2
-    for (int j = 0; j < 16; ++j) {
-      const int64_t l = tile * 32 + 2 * j + h;
-      const bool lv = l < L;
-      float a[ND], bq[4];
-#pragma unroll
-      for (int mt = 0; mt < ND; ++mt) a[mt] = lv ? dzbuf[l * DP + dbase + mt * 32 + c31] : 0.f;
-      const float* frow = feat + (int64_t)(lv ? it0row[l] : 0) * F;
-      if (MODE == 0) {
-        noise4((uint32_t)l, (uint32_t)(wave * 32 + c31), nkey, nscale, bq);
-      } else {
-#pragma unroll
-        for (int o = 0; o < 4; ++o) {
-          const int f = wave * 128 + 32 * o + c31;
-          bq[o] = (lv && f < F) ? noise[l * F + f] : 0.f;
-        }
-      }
-#pragma unroll
-      for (int o = 0; o < 4; ++o) {
-        const int f = wave * 128 + 32 * o + c31;
-        bq[o] = __fadd_rn((lv && f < F) ? frow[f] : 0.f, bq[o]);
-      }
-#pragma unroll
-      for (int mt = 0; mt < ND; ++mt)
-#pragma unroll
-        for (int o = 0; o < 4; ++o) acc[mt][o] = MFMA32(a[mt], bq[o], acc[mt][o]);
-    }
-  }
-#pragma unroll
-  for (int mt = 0; mt < ND; ++mt)
-#pragma unroll
-    for (int o = 0; o < 4; ++o)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int d = dbase + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int f = wave * 128 + 32 * o + c31;
-        if (d < D && f < F) atomicAdd(&gW[(int64_t)d * (D + F) + D + f], acc[mt][o][r]);
-      }
+template <int D_, int MODE>
+__global__ __launch_bounds__(256) void k_bwd(BwdArgs p) {
+  extern __shared__ float red[];          // [4 waves][<= 128 regs][64 lanes]
+  constexpr int DW = (D_ <= 32 ? 1 : 2) * 32;
+  constexpr int GY = D_ <= 64 ? 1 : D_ / 64;
+  const int role = blockIdx.y / GY;
+  const int dbase = (blockIdx.y % GY) * DW;
+  if (role < p.NC) bwd_col_role<D_, MODE, true>(p, red, role, dbase);
+  else if (role == p.NC) bwd_col_role<D_, MODE, false>(p, red, role, dbase);
+  else bwd_dx_role<D_>(p, dbase);
 }
 
 // ================================================================================================ host side
@@ -576,10 +633,8 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
   int* cand = (int*)(ws + y.cand);
   float* WT = (float*)(ws + y.WT);
   float* hbuf = (float*)(ws + y.h);
-  float* dzbuf = (float*)(ws + y.dz);
   float* m = (float*)(ws + y.m);
   float* dmns = (float*)(ws + y.dmns);
-  int* it0row = (int*)(ws + y.it0);
 
   const rng_key ckey = make_key(rnd->seed, STREAM_CAND, rnd->step);
   const rng_key nkey = make_key(rnd->seed, STREAM_NOISE, rnd->step);
@@ -604,10 +659,10 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
 #define LAUNCH_FWD(D_)                                                                                               \
   if (fused)                                                                                                         \
     hipLaunchKernelGGL((k_noise_fwd<D_, 0>), grid, block, smem, st, WT, M->b, M->U, M->V, M->feat, X, cand, rnd->noise, \
-                       rnd->keep, hbuf, m, it0row, y.L, S1, A, F, nkey, dkey, nscale, thr, kscale);                  \
+                       rnd->keep, hbuf, m, y.L, S1, A, F, nkey, dkey, nscale, thr, kscale);                  \
   else                                                                                                               \
     hipLaunchKernelGGL((k_noise_fwd<D_, 1>), grid, block, smem, st, WT, M->b, M->U, M->V, M->feat, X, cand, rnd->noise, \
-                       rnd->keep, hbuf, m, it0row, y.L, S1, A, F, nkey, dkey, nscale, thr, kscale);
+                       rnd->keep, hbuf, m, y.L, S1, A, F, nkey, dkey, nscale, thr, kscale);
     BY_D(D, LAUNCH_FWD)
 #undef LAUNCH_FWD
     prof_end(ctx, 2, st);
@@ -625,29 +680,28 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     prof_end(ctx, 3, st);
   }
   if (train) {
-    {
-      const dim3 grid((unsigned)min((int64_t)512, ntiles), y.GY);
-      prof_begin(ctx, st);
-#define LAUNCH_MISC(D_)                                                                                             \
-  hipLaunchKernelGGL((k_bwd_misc<D_>), grid, dim3(192), 0, st, M->W, M->U, M->V, X, cand, dmns, hbuf, dzbuf, G->gU, G->gV, \
-                     G->gW, G->gb, y.L, S1, A, F, kscale);
-      BY_D(D, LAUNCH_MISC)
-#undef LAUNCH_MISC
-      prof_end(ctx, 4, st);
-    }
-    {
-      // row-splits of the reduction: every block ends with ND*4*16*64*4 B of float atomics per wave, so few blocks
-      // with >= 2 tiles each when the batch is small, one block per CU when it is large
-      const int64_t gx = min((int64_t)256, max(min(ntiles, (int64_t)64), ntiles / 2));
-      const dim3 grid((unsigned)gx, y.GY), block(64 * y.NC);
-      prof_begin(ctx, st);
-#define LAUNCH_BWD(ND_, MODE_) \
-  hipLaunchKernelGGL((k_noise_bwd<ND_, MODE_>), grid, block, 0, st, dzbuf, rnd->noise, M->feat, it0row, G->gW, y.L, D, F, y.DP, nkey, nscale)
-      if (y.ND == 1) { if (fused) LAUNCH_BWD(1, 0); else LAUNCH_BWD(1, 1); }
-      else           { if (fused) LAUNCH_BWD(2, 0); else LAUNCH_BWD(2, 1); }
+    // roles x column halves on grid.y, row splits on grid.x: about one workgroup per CU in total, 4 batch rows (one per
+    // wave) per workgroup at least
+    const int roles = (y.NC + 2) * y.GY;
+    const int64_t gx = max((int64_t)1, min((N + 3) / 4, (int64_t)max(1, 256 / roles)));
+    const dim3 grid((unsigned)gx, (unsigned)roles);
+    const size_t smem = (size_t)4 * 128 * 64 * 4;
+    prof_begin(ctx, st);
+#define LAUNCH_BWD(D_)                                                                                              \
+  if (fused) {                                                                                                      \
+    HIP_TRY(hipFuncSetAttribute((const void*)k_bwd<D_, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+    hipLaunchKernelGGL((k_bwd<D_, 0>), grid, dim3(256), smem, st, ba);                                              \
+  } else {                                                                                                          \
+    HIP_TRY(hipFuncSetAttribute((const void*)k_bwd<D_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+    hipLaunchKernelGGL((k_bwd<D_, 1>), grid, dim3(256), smem, st, ba);                                              \
+  }
+    BwdArgs ba;
+    ba.W = M->W; ba.U = M->U; ba.V = M->V; ba.feat = M->feat; ba.X = X; ba.cand = cand; ba.dmns = dmns; ba.hbuf = hbuf;
+    ba.noise = rnd->noise; ba.gU = G->gU; ba.gV = G->gV; ba.gW = G->gW; ba.gb = G->gb; ba.N = N; ba.S1 = S1; ba.A = A;
+    ba.F = F; ba.NC = y.NC; ba.kscale = kscale; ba.nscale = nscale; ba.nkey = nkey;
+    BY_D(D, LAUNCH_BWD)
 #undef LAUNCH_BWD
-      prof_end(ctx, 5, st);
-    }
+    prof_end(ctx, 5, st);
   }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -672,7 +726,7 @@ extern "C" int dccf_ctx_reserve(dccf_ctx* ctx, int64_t max_rows, int32_t D, int3
 
 // ================================================================================================ debug: workspace
 // Copies one workspace array of the LAST call with these shapes to `dst` (device) — for the parity tests only.
-// which: 0 cand(int32 [N*S1]) 1 WT 3 h [L,DP] 4 m [L] 5 dmns [N*S1] 6 dz [L,DP] 7 it0(int32 [L]); info = DP, FP, count, 4
+// which: 0 cand(int32 [N*S1]) 1 WT 3 h [L,DP] 4 m [L] 5 dmns [N*S1]; info = DP, FP, count, 4
 extern "C" int dccf_debug_workspace(dccf_ctx* ctx, int64_t N, int32_t D, int32_t F, int32_t S, int32_t A, int32_t which,
                                     void* dst, int64_t* info, void* stream) {
   ARG_CHECK(ctx && info, "NULL argument");
@@ -685,8 +739,6 @@ extern "C" int dccf_debug_workspace(dccf_ctx* ctx, int64_t N, int32_t D, int32_t
     case 3: off = y.h; cnt = (size_t)y.L * y.DP; break;
     case 4: off = y.m; cnt = (size_t)y.L; break;
     case 5: off = y.dmns; cnt = (size_t)y.NS; break;
-    case 6: off = y.dz; cnt = (size_t)y.L * y.DP; break;
-    case 7: off = y.it0; cnt = (size_t)y.L; break;
     default: return dccf_fail(-1, "argument error: unknown workspace array");
   }
   info[0] = y.DP; info[1] = y.FP; info[2] = (int64_t)cnt; info[3] = 4;

@@ -145,7 +145,7 @@ int dccf_debug_noise(int64_t L, int32_t F, float std, uint64_t seed, uint64_t st
 int dccf_debug_keep(int64_t L, int32_t D, float dropout, uint64_t seed, uint64_t step, uint8_t* out, void* stream);
 
 /* Copies one workspace array of the last call with these shapes to dst (device; NULL = only fill info[4] =
- * {DP, FP, element count, element size}).  which: 0 cand(int32) 1 WT 3 h 4 m 5 dmns 6 dz 7 it0(int32).  Tests only. */
+ * {DP, FP, element count, element size}).  which: 0 cand(int32) 1 WT 3 h 4 m 5 dmns.  Tests only. */
 int dccf_debug_workspace(dccf_ctx* ctx, int64_t N, int32_t D, int32_t F, int32_t S, int32_t A, int32_t which, void* dst,
                          int64_t* info, void* stream);
 
