@@ -43,6 +43,7 @@ def parse():
     p.add_argument('--cpu_baseline', type=int, default=1)
     p.add_argument('--cpu_steps', type=int, default=60)
     p.add_argument('--seed', type=int, default=2019)
+    p.add_argument('--force_sharded', type=int, default=0, help='run the row-sharded pipeline even at --gpus 1')
     return p.parse_args()
 
 
@@ -89,9 +90,14 @@ def main():
                              % (args.gpus, args.gpus))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    if world > 1 or args.force_sharded:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        if world == 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29618')
+            dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group('nccl', device_id=dev)
         from dccf_amd import sharded
         return sharded.bench_main(args, rank, world, dev)
 

@@ -165,7 +165,11 @@ def model_struct(U, V, W, b, feat, expo, S, A, std, ips=None):
 
 def rand_struct(sample_item=None, noise=None, keep=None, seed=None, step=0):
     r = RandT()
-    if seed is not None:
+    if seed is not None and sample_item is not None:      # candidates injected, noise / dropout fused
+        r.mode, r.seed, r.step = 2, int(seed) & 0xFFFFFFFFFFFFFFFF, int(step)
+        r.sample_item = ptr(sample_item, torch.int64)
+        r._refs = (sample_item,)
+    elif seed is not None:
         r.mode, r.seed, r.step = 1, int(seed) & 0xFFFFFFFFFFFFFFFF, int(step)
     else:
         r.mode = 0

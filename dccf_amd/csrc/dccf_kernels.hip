@@ -613,9 +613,11 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
   ARG_CHECK(N >= 0 && N * (int64_t)(M->S + 1) * M->A < 4294967296LL, "N*(S+1)*A must be < 2^32");
   ARG_CHECK(rnd != nullptr && (N == 0 || (X != nullptr && pred != nullptr)), "NULL rnd / X / prediction");
   ARG_CHECK(dropout >= 0.f && dropout < 1.f, "dropout must be in [0,1)");
-  const bool fused = rnd->mode == 1;
-  ARG_CHECK(rnd->mode == 0 || rnd->mode == 1, "rnd.mode must be 0 or 1");
-  if (!fused && N > 0) ARG_CHECK((M->S == 0 || rnd->sample_item) && rnd->noise, "injected mode needs sample_item and noise");
+  const bool fused = rnd->mode != 0;            // noise + dropout drawn on device
+  const bool fused_cand = rnd->mode == 1;       // candidates drawn on device
+  ARG_CHECK(rnd->mode >= 0 && rnd->mode <= 2, "rnd.mode must be 0, 1 or 2");
+  if (!fused && N > 0) ARG_CHECK(rnd->noise != nullptr, "injected mode needs noise");
+  if (!fused_cand && N > 0) ARG_CHECK(M->S == 0 || rnd->sample_item, "injected candidates need sample_item");
   if (train) {
     ARG_CHECK(G && G->gU && G->gV && G->gW && G->gb && loss, "NULL gradient / loss pointer");
     ARG_CHECK(rank == 0 || rank == 1, "rank must be 0 or 1");
@@ -649,7 +651,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     const int grid = (int)min((int64_t)2048, (total + 255) / 256);
     prof_begin(ctx, st);
     hipLaunchKernelGGL(k_prep, dim3(grid), dim3(256), 0, st, M->W, WT, D, F, y.DP, y.FP, X, rnd->sample_item, cand, N,
-                       M->S, M->item_num, fused ? 1 : 0, ckey, m, y.GY > 1 ? y.L : (int64_t)0, train ? loss : nullptr);
+                       M->S, M->item_num, fused_cand ? 1 : 0, ckey, m, y.GY > 1 ? y.L : (int64_t)0, train ? loss : nullptr);
     prof_end(ctx, 0, st);
   }
   {

@@ -68,7 +68,8 @@ typedef struct {
 
 /* ---- the random draws of DCCF.predict (src/models/DCCF.py:72,87,94) ---------------------------------------- */
 typedef struct {
-  int32_t mode;                /* 0 = injected ("golden"): use the three arrays; 1 = fused: Philox4x32-10(seed, step) */
+  int32_t mode;                /* 0 = injected ("golden"): use the three arrays; 1 = fused: Philox4x32-10(seed, step); */
+                               /* 2 = candidates injected (sample_item), noise + dropout fused (row-sharded path)   */
   int32_t reserved;
   const int64_t* sample_item;  /* [N, S]      candidates as torch.randint would return them                      */
   const float*   noise;        /* [N*(S+1)*A, F]  N(0, std^2) draws (already scaled by std)                       */

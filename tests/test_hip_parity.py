@@ -374,3 +374,41 @@ def test_large_batch_properties(L, ctx):
     assert torch.equal(head, a[:4096])
     # Monte-Carlo consistency: the mean over many noise draws approaches the noise-free score's neighbourhood
     close(a.mean().reshape(1), c.mean().reshape(1).cpu().numpy(), 5e-2, 1e-3, 'step-to-step mean')
+
+
+def test_sharded_trainer_with_hip_backend_world1(L):
+    """dccf_amd/sharded.py with the real HIP backend over RCCL at world size 1 (the routing at world size 2 is covered
+    on CPU by tests/test_sharded_gloo.py): two steps must equal the oracle on the same counter-based draws."""
+    import os
+    import torch.distributed as dist
+    from dccf_amd.sharded import ShardedDCCF, HipBackend
+    from test_sharded_gloo import make_world, expo_from_ips, CFG, KEYS
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29617')
+    if not dist.is_initialized():
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev())
+    try:
+        c = dict(CFG)
+        P, feat, ips, X = make_world(c)
+        ips_t = dict(P=T(ips['P']), bu=T(ips['bu']), Q=T(ips['Q']), bi=T(ips['bi']), prop=T(ips['prop']), b0=0.1, M=0.1)
+        tr = ShardedDCCF(0, 1, c['U'], c['I'], c['D'], c['S'], c['A'], c['std'], c['dropout'], c['lr'], c['l2'], c['seed'],
+                         HipBackend(dev()), dev(), T(feat), ips_t)
+        tr.set_global_params(T(P[KEYS[0]]), T(P[KEYS[1]]), T(P[KEYS[2]]), T(P[KEYS[3]]))
+        expo = expo_from_ips(ips)
+        opt = O.DenseOptimizer('adam', c['lr'], c['l2'])
+        N, Ld = 2 * c['B'], 2 * c['B'] * (c['S'] + 1) * c['A']
+        Y = np.concatenate([np.ones(c['B'], np.float32), np.zeros(c['B'], np.float32)])
+        for step in range(c['steps']):
+            x = X[step][:1]                                  # rank 0's batch only (world size 1)
+            pred, loss = tr.train_step(T(x), step)
+            cand = PH.candidates(c['seed'], step, N, c['S'], c['I'])
+            noise = L.debug_noise(Ld, c['F'], c['std'], c['seed'], step, dev()).cpu().numpy()
+            keep = PH.dropout_keep(c['seed'], step, Ld, c['D'], float(np.float32(c['dropout'])))
+            fw = O.dccf_forward(P, feat, expo, x[0], cand, noise, keep, c['dropout'], c['A'])
+            close(pred, fw['prediction'], FWD_RTOL, FWD_ATOL, 'sharded pred')
+            _, dpred = O.loss_and_dpred(fw['prediction'], Y, 1)
+            P, _ = O.train_step(P, opt, c['l2'], O.dccf_backward(P, fw, dpred, c['A']))
+        for k, t in zip(KEYS, (tr.U, tr.V, tr.W, tr.b)):
+            close(t, P[k], PARAM_RTOL, PARAM_ATOL + STEP_FRAC * c['lr'], 'sharded param ' + k)
+    finally:
+        dist.destroy_process_group()

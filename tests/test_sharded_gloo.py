@@ -1,0 +1,126 @@
+# coding=utf-8
+"""CPU, world_size 2, gloo: the row-sharded training step (dccf_amd/sharded.py) must equal ONE step on the union of
+the ranks' batches.  The local compute is played by the oracle (numpy) with the same counter-based draws the HIP
+backend uses, so this checks the partitioning, the routing of rows / gradient rows and the dense all-reduce."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import dccf_oracle as O
+from oracle import philox as PH
+
+KEYS = ['uid_embeddings.weight', 'iid_embeddings.weight', 'mlp.0.weight', 'mlp.0.bias']
+CFG = dict(U=37, I=53, D=16, F=32, Dq=8, S=4, A=2, std=0.1, dropout=0.2, lr=0.01, l2=1e-3, seed=77, B=5, steps=2)
+
+
+def expo_from_ips(ips):
+    e = ips['P'] @ ips['Q'].T + ips['bu'][:, None] + ips['bi'][None, :] + np.float32(ips['b0'])
+    return (e / np.maximum(ips['prop'], np.float32(ips['M']))[None, :]).astype(np.float32)
+
+
+class OracleBackend(object):
+    """Stands in for HipBackend: same interface, numpy arithmetic, the same Philox streams."""
+
+    def candidates(self, n_rows, S, item_num, seed, step):
+        return torch.from_numpy(PH.candidates(seed, step, n_rows, S, item_num))
+
+    def local_step(self, Uc, Vc, W, b, featc, ips, Xc, cand_c, Y, S, A, std, dropout, seed, step, gU, gV, gW, gb):
+        P = {KEYS[0]: Uc.numpy(), KEYS[1]: Vc.numpy(), KEYS[2]: W.numpy(), KEYS[3]: b.numpy()}
+        ipn = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in ips.items()}
+        expo = expo_from_ips(ipn)
+        N = Xc.shape[0]
+        L = N * (S + 1) * A
+        noise = PH.noise(seed, step, L, featc.shape[1], std)
+        keep = PH.dropout_keep(seed, step, L, Uc.shape[1], float(np.float32(dropout)))
+        fw = O.dccf_forward(P, featc.numpy(), expo, Xc.numpy(), cand_c.numpy(), noise, keep, dropout, A)
+        loss, dpred = O.loss_and_dpred(fw['prediction'], Y.numpy(), 1)
+        g = O.dccf_backward(P, fw, dpred, A)
+        gU += torch.from_numpy(g[KEYS[0]])
+        gV += torch.from_numpy(g[KEYS[1]])
+        gW += torch.from_numpy(g[KEYS[2]])
+        gb += torch.from_numpy(g[KEYS[3]])
+        return torch.from_numpy(fw['prediction']), torch.tensor([float(loss)])
+
+    def opt_step(self, p, g, s1, s2, lr, l2, t):
+        if not hasattr(self, 'opt'):
+            self.opt = O.DenseOptimizer('adam', lr, l2)
+        P, _ = O.train_step({'p': p.numpy().copy()}, self.opt, l2, {'p': g.numpy()})
+        p.copy_(torch.from_numpy(P['p']))
+        g.zero_()
+
+
+def make_world(c):
+    rng = np.random.RandomState(5)
+    P = {KEYS[0]: (rng.randn(c['U'], c['D']) * 0.3).astype(np.float32), KEYS[1]: (rng.randn(c['I'], c['D']) * 0.3).astype(np.float32),
+         KEYS[2]: (rng.randn(c['D'], c['D'] + c['F']) * 0.1).astype(np.float32), KEYS[3]: (rng.randn(c['D']) * 0.1).astype(np.float32)}
+    feat = (rng.randn(c['I'], c['F']) * 0.5).astype(np.float32)
+    ips = dict(P=(rng.randn(c['U'], c['Dq']) * 0.3).astype(np.float32), Q=(rng.randn(c['I'], c['Dq']) * 0.3).astype(np.float32),
+               bu=(rng.randn(c['U']) * 0.1).astype(np.float32), bi=(rng.randn(c['I']) * 0.1).astype(np.float32),
+               prop=rng.rand(c['I']).astype(np.float32), b0=0.1, M=0.1)
+    G, B = 2, c['B']
+    X = []
+    for _ in range(c['steps']):
+        xs = []
+        for _r in range(G):
+            u = rng.randint(0, c['U'], B)
+            xs.append(np.concatenate([np.stack([u, rng.randint(0, c['I'], B)], 1), np.stack([u, rng.randint(0, c['I'], B)], 1)]))
+        X.append(np.stack(xs).astype(np.int64))
+    return P, feat, ips, X
+
+
+def worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from dccf_amd.sharded import ShardedDCCF
+    c = CFG
+    P, feat, ips, X = make_world(c)
+    T = torch.from_numpy
+    ips_loc = dict(P=T(ips['P'][rank::world].copy()), bu=T(ips['bu'][rank::world].copy()), Q=T(ips['Q'][rank::world].copy()),
+                   bi=T(ips['bi'][rank::world].copy()), prop=T(ips['prop'][rank::world].copy()), b0=0.1, M=0.1)
+    tr = ShardedDCCF(rank, world, c['U'], c['I'], c['D'], c['S'], c['A'], c['std'], c['dropout'], c['lr'], c['l2'], c['seed'],
+                     OracleBackend(), torch.device('cpu'), T(feat[rank::world].copy()), ips_loc)
+    tr.set_global_params(T(P[KEYS[0]]), T(P[KEYS[1]]), T(P[KEYS[2]]), T(P[KEYS[3]]))
+    preds = []
+    for step in range(c['steps']):
+        pred, loss = tr.train_step(T(X[step]), step)
+        preds.append(pred.numpy().copy())
+    np.savez(os.path.join(out, 'rank%d.npz' % rank), U=tr.U.numpy(), V=tr.V.numpy(), W=tr.W.numpy(), b=tr.b.numpy(),
+             preds=np.stack(preds))
+    dist.destroy_process_group()
+
+
+def test_sharded_step_equals_union_batch(tmp_path):
+    world = 2
+    port = 29000 + os.getpid() % 2000
+    mp.spawn(worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    c = CFG
+    P, feat, ips, X = make_world(c)
+    expo = expo_from_ips(ips)
+    opt = O.DenseOptimizer('adam', c['lr'], c['l2'])
+    N, L = 2 * c['B'], 2 * c['B'] * (c['S'] + 1) * c['A']
+    Y = np.concatenate([np.ones(c['B'], np.float32), np.zeros(c['B'], np.float32)])
+    res = [dict(np.load(os.path.join(str(tmp_path), 'rank%d.npz' % r))) for r in range(world)]
+    for step in range(c['steps']):
+        cand = PH.candidates(c['seed'], step, world * N, c['S'], c['I']).reshape(world, N, c['S'])
+        total = {k: np.zeros_like(v) for k, v in P.items()}
+        for r in range(world):
+            noise = PH.noise(c['seed'], step * world + r, L, c['F'], c['std'])
+            keep = PH.dropout_keep(c['seed'], step * world + r, L, c['D'], float(np.float32(c['dropout'])))
+            fw = O.dccf_forward(P, feat, expo, X[step][r], cand[r], noise, keep, c['dropout'], c['A'])
+            assert np.allclose(res[r]['preds'][step], fw['prediction'], rtol=1e-5, atol=1e-6)
+            _, dpred = O.loss_and_dpred(fw['prediction'], Y, 1)
+            g = O.dccf_backward(P, fw, dpred, c['A'])
+            for k in total:
+                total[k] += g[k]
+        P, _ = O.train_step(P, opt, c['l2'], total)
+    for r in range(world):
+        assert np.allclose(res[r]['U'], P[KEYS[0]][r::world], rtol=1e-5, atol=1e-6)
+        assert np.allclose(res[r]['V'], P[KEYS[1]][r::world], rtol=1e-5, atol=1e-6)
+        assert np.allclose(res[r]['W'], P[KEYS[2]], rtol=1e-5, atol=1e-6)
+        assert np.allclose(res[r]['b'], P[KEYS[3]], rtol=1e-5, atol=1e-6)
+    assert np.allclose(res[0]['W'], res[1]['W'])        # replicas stay identical
