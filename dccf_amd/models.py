@@ -346,7 +346,7 @@ class DCCF(DMF):
             self.expo_prob = torch.empty(e.shape, dtype=torch.float32, device=self.device)
             rows = max(1, (256 << 20) // (4 * e.shape[1]))          # stream the U x I matrix to HBM in 256 MiB slabs
             for r0 in range(0, e.shape[0], rows):
-                self.expo_prob[r0:r0 + rows].copy_(torch.from_numpy(np.ascontiguousarray(e[r0:r0 + rows], dtype=np.float32)))
+                self.expo_prob[r0:r0 + rows].copy_(torch.from_numpy(np.array(e[r0:r0 + rows], dtype=np.float32)))
         D, F = self.ui_vector_size, self.feature_embedding.shape[1]
         self._declare('uid_embeddings.weight', (self.user_num, D), 'embedding')
         self._declare('iid_embeddings.weight', (self.item_num, D), 'embedding')

@@ -406,6 +406,54 @@ def gen_metrics(outdir):
     print('wrote metrics', dict(zip(metrics, vals)))
 
 
+# ----------------------------------------------------------------------------- G5: end to end
+E2E = dict(user_num=800, item_num=600, n_draws=16000, feat_dim=64, data_seed=11, epochs=4, seeds=[2019, 2020, 2021, 2022, 2023],
+           D=32, test_neg_n=100, lr=0.001, batch_size=128)
+
+
+def gen_e2e(outdir):
+    """The reference's own main.py (src/main.py) on a small synthetic dataset: per-epoch validation / test metrics for
+    several seeds — the statistical target of tests/test_e2e_gpu.py (evaluation is stochastic)."""
+    import re
+    import io
+    import logging
+    import contextlib
+    from dccf_amd import synth
+    import main as ref_main
+    c = E2E
+    rec = {k: np.array(v) for k, v in c.items()}
+    cwd = os.getcwd()
+    for seed in c['seeds']:
+        tmp = tempfile.mkdtemp()
+        try:
+            os.makedirs(os.path.join(tmp, 'src'))
+            os.makedirs(os.path.join(tmp, 'result'))
+            synth.write_dataset(os.path.join(tmp, 'dataset'), 'toy', c['user_num'], c['item_num'], c['n_draws'],
+                                feat_dim=c['feat_dim'], seed=c['data_seed'])
+            os.chdir(os.path.join(tmp, 'src'))
+            sys.argv = ['main.py', '--rank', '1', '--model_name', 'DCCF', '--optimizer', 'Adam', '--lr', str(c['lr']),
+                        '--dataset', 'toy', '--path', '../dataset/', '--metric', 'ndcg@5,recall@5,precision@5', '--gpu', '',
+                        '--epoch', str(c['epochs']), '--test_neg_n', str(c['test_neg_n']), '--u_vector_size', str(c['D']),
+                        '--i_vector_size', str(c['D']), '--random_seed', str(seed), '--batch_size', str(c['batch_size']),
+                        '--check_epoch', '0']
+            ref_main.main()
+            logf = [os.path.join(r, f) for r, _, fs in os.walk(os.path.join(tmp, 'log')) for f in fs][0]
+            txt = open(logf).read()
+            ep = re.findall(r'Epoch\s+(\d+) \[[\d.]+ s\]\s+train= ([\d.,-]+) validation= ([\d.,-]+) test= ([\d.,-]+)', txt)
+            init = re.search(r'Init: \s+train= ([\d.,-]+) validation= ([\d.,-]+) test= ([\d.,-]+)', txt)
+            rec['seed%d/init_valid' % seed] = np.array([float(x) for x in init.group(2).split(',')])
+            rec['seed%d/init_test' % seed] = np.array([float(x) for x in init.group(3).split(',')])
+            rec['seed%d/valid' % seed] = np.array([[float(x) for x in e[2].split(',')] for e in ep])
+            rec['seed%d/test' % seed] = np.array([[float(x) for x in e[3].split(',')] for e in ep])
+            print('seed', seed, 'valid ndcg@5 per epoch', rec['seed%d/valid' % seed][:, 0], flush=True)
+        finally:
+            os.chdir(cwd)
+            for h in logging.root.handlers[:]:
+                logging.root.removeHandler(h)
+            shutil.rmtree(tmp)
+    np.savez_compressed(os.path.join(outdir, 'e2e.npz'), **rec)
+
+
 if __name__ == '__main__':
     install_shims()
     which = sys.argv[1:] or ['dccf', 'mf', 'opt', 'batches', 'metrics']
@@ -421,3 +469,5 @@ if __name__ == '__main__':
         gen_batches(HERE)
     if 'metrics' in which:
         gen_metrics(HERE)
+    if 'e2e' in which:
+        gen_e2e(HERE)

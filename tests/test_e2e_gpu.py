@@ -1,0 +1,91 @@
+# coding=utf-8
+"""GPU end to end: the CLI mirror (dccf_amd.main) on the small synthetic dataset the reference's own main.py was run on
+(tests/golden/make_golden.py e2e -> tests/golden/e2e.npz).  Evaluation is stochastic in the reference itself (fresh
+candidates and noise on every predict), so parity here is statistical: seed-averaged NDCG@5 per epoch."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def run_cli(tmp, argv):
+    from dccf_amd import main as M
+    cwd = os.getcwd()
+    os.makedirs(os.path.join(tmp, 'src'), exist_ok=True)
+    os.chdir(os.path.join(tmp, 'src'))
+    try:
+        return M.main(argv)
+    finally:
+        os.chdir(cwd)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(GOLDEN, 'e2e.npz')), reason='e2e golden not generated')
+def test_cli_training_matches_reference_statistically(tmp_path):
+    from dccf_amd import synth
+    g = load_golden('e2e')
+    tmp = str(tmp_path)
+    synth.write_dataset(os.path.join(tmp, 'dataset'), 'toy', int(g['user_num']), int(g['item_num']), int(g['n_draws']),
+                        feat_dim=int(g['feat_dim']), seed=int(g['data_seed']))
+    seeds = [int(s) for s in g['seeds']]
+    ref_valid = np.stack([g['seed%d/valid' % s][:, 0] for s in seeds])         # [seeds, epochs] ndcg@5
+    ref_init = np.array([g['seed%d/init_valid' % s][0] for s in seeds])
+    mine, mine_init = [], []
+    for seed in seeds:
+        runner = run_cli(tmp, ['--rank', '1', '--model_name', 'DCCF', '--optimizer', 'Adam', '--lr', str(float(g['lr'])),
+                               '--dataset', 'toy', '--path', '../dataset/', '--metric', 'ndcg@5,recall@5,precision@5',
+                               '--epoch', str(int(g['epochs'])), '--test_neg_n', str(int(g['test_neg_n'])),
+                               '--u_vector_size', str(int(g['D'])), '--i_vector_size', str(int(g['D'])),
+                               '--random_seed', str(seed), '--batch_size', str(int(g['batch_size'])), '--check_epoch', '0'])
+        mine.append([v[0] for v in runner.valid_results])
+    mine = np.array(mine)
+    assert mine.shape == ref_valid.shape
+    # training must move NDCG well above the untrained level, as it does in the reference
+    assert mine[:, -1].mean() > ref_init.mean() + 0.5 * (ref_valid[:, -1].mean() - ref_init.mean())
+    # seed-averaged NDCG@5 per epoch: within 3 standard errors of the two seed-means + 2e-3
+    for e in range(mine.shape[1]):
+        se = np.sqrt(ref_valid[:, e].var(ddof=1) / len(seeds) + mine[:, e].var(ddof=1) / len(seeds))
+        assert abs(mine[:, e].mean() - ref_valid[:, e].mean()) <= 3 * se + 2e-3, \
+            'epoch %d: mine %.4f vs reference %.4f (se %.4f)' % (e + 1, mine[:, e].mean(), ref_valid[:, e].mean(), se)
+    # artefacts with the reference's names and formats
+    ds = os.path.join(tmp, 'dataset', 'toy')
+    assert os.path.exists(os.path.join(ds, 'rank.csv'))
+    header = open(os.path.join(ds, 'rank.csv')).readline().strip().split('\t')
+    assert header == ['uid', 'iid', 'score', 'label']
+    results = [f for f in os.listdir(os.path.join(tmp, 'result')) if f.endswith('.npy')]
+    assert results and np.load(os.path.join(tmp, 'result', results[0])).ndim == 1
+    pts = [os.path.join(r, f) for r, _, fs in os.walk(os.path.join(tmp, 'model')) for f in fs if f.endswith('.pt')]
+    sd = torch.load(pts[0], map_location='cpu')
+    assert list(sd.keys()) == ['uid_embeddings.weight', 'iid_embeddings.weight', 'mlp.0.weight', 'mlp.0.bias']
+    assert tuple(sd['mlp.0.weight'].shape) == (int(g['D']), int(g['D']) + int(g['feat_dim']))
+
+
+def test_exposure_pipeline_ipsbiasedmf_then_dccf(tmp_path):
+    """README.md:28-30: train IPSBiasedMF, save the full predicted matrix as <ds>.ips_expo_prob.npy, train DCCF on it.
+    Also covers the reference host sampling path (--fused_sampling 0) and checkpoint reload."""
+    from dccf_amd import synth
+    tmp = str(tmp_path)
+    synth.write_dataset(os.path.join(tmp, 'dataset'), 'toy', 300, 200, 5000, feat_dim=32, seed=3, write_expo=False)
+    common = ['--rank', '1', '--dataset', 'toy', '--path', '../dataset/', '--metric', 'ndcg@5,recall@5', '--test_neg_n', '50',
+              '--u_vector_size', '16', '--i_vector_size', '16', '--check_epoch', '0', '--optimizer', 'Adam', '--lr', '0.01']
+    r = run_cli(tmp, ['--model_name', 'IPSBiasedMF', '--epoch', '3'] + common)
+    assert r.valid_results[-1][0] > 0
+    # rebuild the trained model from its checkpoint and write the exposure matrix
+    from dccf_amd.models import IPSBiasedMF
+    pts = [os.path.join(rt, f) for rt, _, fs in os.walk(os.path.join(tmp, 'model', 'IPSBiasedMF')) for f in fs]
+    m = IPSBiasedMF(path=os.path.join(tmp, 'dataset', 'toy'), dataset='toy', M=0.1, label_min=0, label_max=1, feature_num=0,
+                    user_num=300, item_num=200, u_vector_size=16, i_vector_size=16, random_seed=2019, model_path=pts[0])
+    m.load_model()
+    full = m.full_matrix()
+    X = torch.tensor([[5, 7], [299, 199], [0, 0]], dtype=torch.int64, device=full.device)
+    pair = m.predict({'X': X})['prediction']
+    assert torch.allclose(full[X[:, 0], X[:, 1]], pair, rtol=1e-5, atol=1e-6)
+    np.save(os.path.join(tmp, 'dataset', 'toy', 'toy.ips_expo_prob.npy'), full.cpu().numpy())
+    r2 = run_cli(tmp, ['--model_name', 'DCCF', '--epoch', '2', '--fused_sampling', '0', '--model_path', '../model/DCCF/x.pt'] + common)
+    assert len(r2.valid_results) == 2 and np.isfinite(r2.valid_results[-1][0])
+    r3 = run_cli(tmp, ['--model_name', 'DCCF', '--epoch', '1', '--load', '1', '--model_path', '../model/DCCF/x.pt'] + common)
+    assert np.isfinite(r3.valid_results[-1][0])
