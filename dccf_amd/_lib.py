@@ -13,7 +13,8 @@ LIB_PATH = os.path.join(HERE, 'lib', 'libdccf_hip.so')
 EXPORTS = ['dccf_ctx_create', 'dccf_ctx_destroy', 'dccf_ctx_reserve', 'dccf_last_error', 'dccf_abi_version',
            'dccf_predict', 'dccf_train_fwdbwd', 'dccf_dense_opt_step', 'dccf_sumsq', 'mf_predict', 'mf_train_fwdbwd',
            'mf_predict_full', 'dccf_sample_train_negatives', 'dccf_debug_candidates', 'dccf_debug_noise',
-           'dccf_debug_keep', 'dccf_debug_workspace', 'dccf_profile', 'dccf_profile_read']
+           'dccf_debug_keep', 'dccf_debug_workspace', 'dccf_profile', 'dccf_profile_read',
+           'shard_pack_rows', 'shard_unpack_rows', 'shard_scatter_add']
 
 OPT_KIND = {'gd': 0, 'adagrad': 1, 'adam': 2}
 MF_KIND = {'RecModel': 0, 'BiasedMF': 1, 'IPSBiasedMF': 2}
@@ -81,6 +82,9 @@ def load():
         'dccf_debug_noise': [i64, i32, f32, u64, u64, vp, vp],
         'dccf_debug_keep': [i64, i32, f32, u64, u64, vp, vp],
         'dccf_debug_workspace': [vp, i64, i32, i32, i32, i32, i32, vp, C.POINTER(C.c_int64), vp],
+        'shard_pack_rows': [vp, i64, C.POINTER(vp), C.POINTER(i32), i32, vp, vp],
+        'shard_unpack_rows': [vp, i64, vp, C.POINTER(vp), C.POINTER(i32), i32, vp],
+        'shard_scatter_add': [vp, i64, vp, i32, vp, vp],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)
@@ -286,3 +290,26 @@ def debug_workspace(ctx, N, D, F, S, A, which, device):
     out = torch.empty(info[2], dtype=torch.int32 if which == 0 else torch.float32, device=device)
     check(load().dccf_debug_workspace(ctx.h, N, D, F, S, A, which, ptr(out), info, stream()))
     return out, int(info[0]), int(info[1])
+
+
+def _table_args(tables):
+    n = len(tables)
+    ptrs = (C.c_void_p * n)(*[ptr(t, torch.float32) for t in tables])
+    widths = (C.c_int32 * n)(*[int(t.shape[1]) if t.dim() == 2 else 1 for t in tables])
+    return ptrs, widths, n
+
+
+def shard_pack_rows(idx, n, tables, out):
+    """out[j] = [T0[idx[j]] | T1[idx[j]] | ...] for j < n (idx int32 in HBM)."""
+    ptrs, widths, k = _table_args(tables)
+    check(load().shard_pack_rows(ptr(idx, torch.int32), int(n), ptrs, widths, k, ptr(out, torch.float32), stream()))
+
+
+def shard_unpack_rows(payload, n, dst, tables):
+    ptrs, widths, k = _table_args(tables)
+    check(load().shard_unpack_rows(ptr(payload, torch.float32), int(n), ptr(dst, torch.int32), ptrs, widths, k, stream()))
+
+
+def shard_scatter_add(idx, n, rows, g):
+    check(load().shard_scatter_add(ptr(idx, torch.int32), int(n), ptr(rows, torch.float32), int(g.shape[1]),
+                                   ptr(g, torch.float32), stream()))

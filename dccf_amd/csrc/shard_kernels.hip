@@ -1,0 +1,99 @@
+// shard_kernels.hip — row movers of the row-sharded multi-GPU path (dccf_amd/sharded.py): pack the rows a peer needs
+// into an all-to-all payload, unpack a received payload into the compact per-step tables, add received gradient rows
+// into the local gradient shard.  Pure HBM byte movers: one payload row per wave, lanes walk the columns (coalesced
+// 256-B segments); the scatter-add issues one shaped float-atomic wave instruction per 64 columns of a row.
+#include "common.hpp"
+
+#define SHARD_MAX_TABLES 4
+struct TableSet {
+  float* t[SHARD_MAX_TABLES];
+  int w[SHARD_MAX_TABLES];      // row width (floats) of each table
+  int n;
+  int total;
+};
+
+// out[j, :] = [T0[idx[j], :] | T1[idx[j], :] | ...]
+__global__ __launch_bounds__(256) void k_pack(const int* __restrict__ idx, int64_t n, TableSet ts, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t j = wave; j < n; j += nw) {
+    const int64_t r = idx[j];
+    int off = 0;
+    for (int q = 0; q < ts.n; ++q) {
+      for (int c = lane; c < ts.w[q]; c += 64) out[j * ts.total + off + c] = ts.t[q][r * ts.w[q] + c];
+      off += ts.w[q];
+    }
+  }
+}
+
+// Tq[dst[j] (or j), :] = in[j, off_q : off_q + w_q]
+__global__ __launch_bounds__(256) void k_unpack(const float* __restrict__ in, int64_t n, const int* __restrict__ dst,
+                                                TableSet ts) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t j = wave; j < n; j += nw) {
+    const int64_t r = dst ? dst[j] : j;
+    int off = 0;
+    for (int q = 0; q < ts.n; ++q) {
+      for (int c = lane; c < ts.w[q]; c += 64) ts.t[q][r * ts.w[q] + c] = in[j * ts.total + off + c];
+      off += ts.w[q];
+    }
+  }
+}
+
+// g[idx[j], :] += rows[j, :]
+__global__ __launch_bounds__(256) void k_scatter_add(const int* __restrict__ idx, int64_t n, const float* __restrict__ rows,
+                                                     int width, float* __restrict__ g) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t j = wave; j < n; j += nw) {
+    const int64_t r = idx[j];
+    for (int c = lane; c < width; c += 64) atomicAdd(&g[r * width + c], rows[j * width + c]);
+  }
+}
+
+static int make_set(TableSet& ts, float* const* tables, const int32_t* widths, int32_t ntables) {
+  ARG_CHECK(tables && widths && ntables >= 1 && ntables <= SHARD_MAX_TABLES, "1..4 tables");
+  ts.n = ntables;
+  ts.total = 0;
+  for (int q = 0; q < ntables; ++q) {
+    ARG_CHECK(tables[q] != nullptr && widths[q] > 0, "NULL table or non-positive width");
+    ts.t[q] = tables[q];
+    ts.w[q] = widths[q];
+    ts.total += widths[q];
+  }
+  return 0;
+}
+
+extern "C" int shard_pack_rows(const int32_t* idx, int64_t n, const float* const* tables, const int32_t* widths,
+                               int32_t ntables, float* out, void* stream) {
+  TableSet ts;
+  if (int e = make_set(ts, (float* const*)tables, widths, ntables)) return e;
+  ARG_CHECK(n >= 0 && (n == 0 || (idx && out)), "NULL idx / out");
+  if (n == 0) return 0;
+  const int grid = (int)min((int64_t)2048, (n + 3) / 4);
+  hipLaunchKernelGGL(k_pack, dim3(grid), dim3(256), 0, (hipStream_t)stream, idx, n, ts, out);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int shard_unpack_rows(const float* in, int64_t n, const int32_t* dst, float* const* tables,
+                                 const int32_t* widths, int32_t ntables, void* stream) {
+  TableSet ts;
+  if (int e = make_set(ts, tables, widths, ntables)) return e;
+  ARG_CHECK(n >= 0 && (n == 0 || in), "NULL payload");
+  if (n == 0) return 0;
+  const int grid = (int)min((int64_t)2048, (n + 3) / 4);
+  hipLaunchKernelGGL(k_unpack, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, n, dst, ts);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int shard_scatter_add(const int32_t* idx, int64_t n, const float* rows, int32_t width, float* g, void* stream) {
+  ARG_CHECK(n >= 0 && width > 0 && (n == 0 || (idx && rows && g)), "bad arguments");
+  if (n == 0) return 0;
+  const int grid = (int)min((int64_t)2048, (n + 3) / 4);
+  hipLaunchKernelGGL(k_scatter_add, dim3(grid), dim3(256), 0, (hipStream_t)stream, idx, n, rows, width, g);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}

@@ -398,10 +398,12 @@ def test_sharded_trainer_with_hip_backend_world1(L):
         opt = O.DenseOptimizer('adam', c['lr'], c['l2'])
         N, Ld = 2 * c['B'], 2 * c['B'] * (c['S'] + 1) * c['A']
         Y = np.concatenate([np.ones(c['B'], np.float32), np.zeros(c['B'], np.float32)])
+        tr.begin_epoch(T(np.stack([x[:1] for x in X])), 3)     # rank 0's batches only (world size 1), epoch 3
+        cand_all = PH.candidates(c['seed'], 3, c['steps'] * N, c['S'], c['I']).reshape(c['steps'], N, c['S'])
         for step in range(c['steps']):
-            x = X[step][:1]                                  # rank 0's batch only (world size 1)
-            pred, loss = tr.train_step(T(x), step)
-            cand = PH.candidates(c['seed'], step, N, c['S'], c['I'])
+            x = X[step][:1]
+            pred, loss = tr.train_step(step)
+            cand = cand_all[step]
             noise = L.debug_noise(Ld, c['F'], c['std'], c['seed'], step, dev()).cpu().numpy()
             keep = PH.dropout_keep(c['seed'], step, Ld, c['D'], float(np.float32(c['dropout'])))
             fw = O.dccf_forward(P, feat, expo, x[0], cand, noise, keep, c['dropout'], c['A'])

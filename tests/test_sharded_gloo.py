@@ -28,6 +28,21 @@ class OracleBackend(object):
     def candidates(self, n_rows, S, item_num, seed, step):
         return torch.from_numpy(PH.candidates(seed, step, n_rows, S, item_num))
 
+    def pack_rows(self, idx, n, tables, out):
+        if n:
+            out[:n] = torch.cat([t[idx[:n].long()].view(n, -1) for t in tables], 1)
+
+    def unpack_rows(self, payload, n, dst, tables):
+        rows = torch.arange(n) if dst is None else dst[:n].long()
+        o = 0
+        for t in tables:
+            t[rows] = payload[:n, o:o + t.shape[1]]
+            o += t.shape[1]
+
+    def scatter_add(self, idx, n, rows, g):
+        if n:
+            g.index_add_(0, idx[:n].long(), rows[:n])
+
     def local_step(self, Uc, Vc, W, b, featc, ips, Xc, cand_c, Y, S, A, std, dropout, seed, step, gU, gV, gW, gb):
         P = {KEYS[0]: Uc.numpy(), KEYS[1]: Vc.numpy(), KEYS[2]: W.numpy(), KEYS[3]: b.numpy()}
         ipn = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in ips.items()}
@@ -86,8 +101,9 @@ def worker(rank, world, port, out):
                      OracleBackend(), torch.device('cpu'), T(feat[rank::world].copy()), ips_loc)
     tr.set_global_params(T(P[KEYS[0]]), T(P[KEYS[1]]), T(P[KEYS[2]]), T(P[KEYS[3]]))
     preds = []
+    tr.begin_epoch(T(np.stack(X)), 3)                       # [steps, G, 2B, 2], epoch 3
     for step in range(c['steps']):
-        pred, loss = tr.train_step(T(X[step]), step)
+        pred, loss = tr.train_step(step)
         preds.append(pred.numpy().copy())
     np.savez(os.path.join(out, 'rank%d.npz' % rank), U=tr.U.numpy(), V=tr.V.numpy(), W=tr.W.numpy(), b=tr.b.numpy(),
              preds=np.stack(preds))
@@ -105,8 +121,9 @@ def test_sharded_step_equals_union_batch(tmp_path):
     N, L = 2 * c['B'], 2 * c['B'] * (c['S'] + 1) * c['A']
     Y = np.concatenate([np.ones(c['B'], np.float32), np.zeros(c['B'], np.float32)])
     res = [dict(np.load(os.path.join(str(tmp_path), 'rank%d.npz' % r))) for r in range(world)]
+    cand_all = PH.candidates(c['seed'], 3, c['steps'] * world * N, c['S'], c['I']).reshape(c['steps'], world, N, c['S'])
     for step in range(c['steps']):
-        cand = PH.candidates(c['seed'], step, world * N, c['S'], c['I']).reshape(world, N, c['S'])
+        cand = cand_all[step]
         total = {k: np.zeros_like(v) for k, v in P.items()}
         for r in range(world):
             noise = PH.noise(c['seed'], step * world + r, L, c['F'], c['std'])
