@@ -170,7 +170,9 @@ def main():
     L_rows = 2 * B * (S + 1) * A
     # algorithmic work per launch: dense Adam 28 B/param; noise GEMMs 2*L*F*D flop each
     cand = {
-        'dense_adam': dict(bound='hbm', work=28.0 * n_params / 1e9, unit='GB/s', peak=HBM_PEAK_GBS),
+        # dense Adam: p, m, v read + written = 24 B per parameter; the gradient is touched only for the rows the step
+        # reached (SURVEY.md §8d prices a gradient-streaming Adam at 28 B/param; the row-aware step moves less)
+        'dense_adam': dict(bound='hbm', work=24.0 * n_params / 1e9, unit='GB/s', peak=HBM_PEAK_GBS),
         'noise_fwd': dict(bound='mfma', work=2.0 * L_rows * F * D / 1e12, unit='TFLOP/s', peak=MFMA_F32_PEAK_TFLOPS),
         'noise_bwd_eps': dict(bound='mfma', work=2.0 * L_rows * F * D / 1e12, unit='TFLOP/s', peak=MFMA_F32_PEAK_TFLOPS),
     }

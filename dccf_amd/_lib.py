@@ -14,7 +14,7 @@ EXPORTS = ['dccf_ctx_create', 'dccf_ctx_destroy', 'dccf_ctx_reserve', 'dccf_last
            'dccf_predict', 'dccf_train_fwdbwd', 'dccf_dense_opt_step', 'dccf_sumsq', 'mf_predict', 'mf_train_fwdbwd',
            'mf_predict_full', 'dccf_sample_train_negatives', 'dccf_debug_candidates', 'dccf_debug_noise',
            'dccf_debug_keep', 'dccf_debug_workspace', 'dccf_profile', 'dccf_profile_read',
-           'shard_pack_rows', 'shard_unpack_rows', 'shard_scatter_add']
+           'shard_pack_rows', 'shard_unpack_rows', 'shard_scatter_add', 'dccf_dense_opt_step_rows']
 
 OPT_KIND = {'gd': 0, 'adagrad': 1, 'adam': 2}
 MF_KIND = {'RecModel': 0, 'BiasedMF': 1, 'IPSBiasedMF': 2}
@@ -36,7 +36,7 @@ class RandT(C.Structure):
 
 
 class GradsT(C.Structure):
-    _fields_ = [('gU', _f), ('gV', _f), ('gW', _f), ('gb', _f)]
+    _fields_ = [('gU', _f), ('gV', _f), ('gW', _f), ('gb', _f), ('touchedU', _f), ('touchedV', _f)]
 
 
 class MFModelT(C.Structure):
@@ -73,6 +73,8 @@ def load():
         'dccf_predict': [vp, C.POINTER(ModelT), C.POINTER(RandT), vp, i64, f32, vp, vp],
         'dccf_train_fwdbwd': [vp, C.POINTER(ModelT), C.POINTER(RandT), vp, vp, i64, i32, f32, C.POINTER(GradsT), vp, vp, vp],
         'dccf_dense_opt_step': [i32, vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, i32, vp],
+        'dccf_dense_opt_step_rows': [i32, vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, i32, C.POINTER(i64), C.POINTER(i64),
+                                     C.POINTER(i32), C.POINTER(vp), vp],
         'dccf_sumsq': [vp, i64, vp, vp],
         'mf_predict': [C.POINTER(MFModelT), vp, i64, vp, vp],
         'mf_train_fwdbwd': [vp, C.POINTER(MFModelT), vp, vp, i64, i32, C.POINTER(MFGradsT), vp, vp, vp],
@@ -192,13 +194,13 @@ def dccf_predict(ctx, m, r, X, dropout, out=None):
     return out
 
 
-def dccf_train_fwdbwd(ctx, m, r, X, Y, rank, dropout, gU, gV, gW, gb, pred=None, loss=None):
+def dccf_train_fwdbwd(ctx, m, r, X, Y, rank, dropout, gU, gV, gW, gb, pred=None, loss=None, touchedU=None, touchedV=None):
     N = X.shape[0]
     if pred is None:
         pred = torch.empty(N, dtype=torch.float32, device=X.device)
     if loss is None:
         loss = torch.empty(1, dtype=torch.float32, device=X.device)
-    g = GradsT(ptr(gU), ptr(gV), ptr(gW), ptr(gb))
+    g = GradsT(ptr(gU), ptr(gV), ptr(gW), ptr(gb), ptr(touchedU, torch.uint8), ptr(touchedV, torch.uint8))
     check(load().dccf_train_fwdbwd(ctx.h, C.byref(m), C.byref(r), ptr(X, torch.int64), ptr(Y), N, int(rank),
                                    float(dropout), C.byref(g), ptr(pred), ptr(loss), stream()))
     return pred, loss
@@ -208,6 +210,18 @@ def dense_opt_step(kind, p, g, s1, s2, lr, wd, l2, clip, step, zero_grad=True):
     check(load().dccf_dense_opt_step(OPT_KIND[kind.lower()], ptr(p, torch.float32), ptr(g, torch.float32), ptr(s1),
                                      ptr(s2), p.numel(), float(lr), float(wd), float(l2), float(clip), int(step),
                                      1 if zero_grad else 0, stream()))
+
+
+def dense_opt_step_rows(kind, p, g, s1, s2, lr, wd, l2, clip, step, segments):
+    """segments: list of (begin element, rows, row width, touched uint8 tensor) — see dccf_dense_opt_step_rows."""
+    n = len(segments)
+    beg = (C.c_int64 * n)(*[int(s[0]) for s in segments])
+    rows = (C.c_int64 * n)(*[int(s[1]) for s in segments])
+    wid = (C.c_int32 * n)(*[int(s[2]) for s in segments])
+    fl = (C.c_void_p * n)(*[ptr(s[3], torch.uint8) for s in segments])
+    check(load().dccf_dense_opt_step_rows(OPT_KIND[kind.lower()], ptr(p, torch.float32), ptr(g, torch.float32), ptr(s1),
+                                          ptr(s2), p.numel(), float(lr), float(wd), float(l2), float(clip), int(step), n,
+                                          beg, rows, wid, fl, stream()))
 
 
 def sumsq(p):

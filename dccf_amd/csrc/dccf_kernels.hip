@@ -340,6 +340,7 @@ struct BwdArgs {
   const int* cand;
   const float *dmns, *hbuf, *noise;
   float *gU, *gV, *gW, *gb;
+  uint8_t *touchedU, *touchedV;
   int64_t N;
   int S1, A, F, NC;
   float kscale, nscale;
@@ -465,6 +466,7 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
           gb_acc[mt] += tot[mt];
         }
       }
+      if (p.touchedU && lane == 0) p.touchedU[u] = 1;
     }
   }
   // sum the 4 waves' accumulators through LDS, then each wave emits a quarter of the tile set
@@ -558,13 +560,21 @@ __device__ __forceinline__ void bwd_dx_role(const BwdArgs& p, int dbase) {
 #pragma unroll
           for (int r = 0; r < 16; r += 2) {
             const int ro = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (ro < rpn && dd < D) atomicAdd(&p.gV[(int64_t)p.cand[n * S1 + (ro >> 1)] * D + dd], acc[nt][r] + acc[nt][r + 1]);
+            if (ro < rpn && dd < D) {
+              const int64_t ci = p.cand[n * S1 + (ro >> 1)];
+              atomicAdd(&p.gV[ci * D + dd], acc[nt][r] + acc[nt][r + 1]);
+              if (p.touchedV && c31 == 0 && nt == 0) p.touchedV[ci] = 1;
+            }
           }
         } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int ro = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (ro < rpn && dd < D) atomicAdd(&p.gV[(int64_t)p.cand[n * S1 + ro / A] * D + dd], acc[nt][r]);
+            if (ro < rpn && dd < D) {
+              const int64_t ci = p.cand[n * S1 + ro / A];
+              atomicAdd(&p.gV[ci * D + dd], acc[nt][r]);
+              if (p.touchedV && c31 == 0 && nt == 0) p.touchedV[ci] = 1;
+            }
           }
         }
       }
@@ -699,7 +709,8 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
   }
     BwdArgs ba;
     ba.W = M->W; ba.U = M->U; ba.V = M->V; ba.feat = M->feat; ba.X = X; ba.cand = cand; ba.dmns = dmns; ba.hbuf = hbuf;
-    ba.noise = rnd->noise; ba.gU = G->gU; ba.gV = G->gV; ba.gW = G->gW; ba.gb = G->gb; ba.N = N; ba.S1 = S1; ba.A = A;
+    ba.noise = rnd->noise; ba.gU = G->gU; ba.gV = G->gV; ba.gW = G->gW; ba.gb = G->gb;
+    ba.touchedU = G->touchedU; ba.touchedV = G->touchedV; ba.N = N; ba.S1 = S1; ba.A = A;
     ba.F = F; ba.NC = y.NC; ba.kscale = kscale; ba.nscale = nscale; ba.nkey = nkey;
     BY_D(D, LAUNCH_BWD)
 #undef LAUNCH_BWD

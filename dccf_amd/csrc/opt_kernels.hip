@@ -150,6 +150,102 @@ __global__ __launch_bounds__(256) void k_dense_opt(float* __restrict__ p, float*
   }
 }
 
+// Row-aware variant: g of a row whose "touched" byte is 0 is all zeros by construction -> not read, not re-zeroed.
+// A wave handles 64 consecutive float4 = 256 consecutive floats = whole rows (row widths 16..128 divide 256 and segments
+// start on a 256-float boundary), so every lane of a row sees the byte before the row's first lane clears it.
+struct RowSegs {
+  int64_t begin[4], end[4];
+  int width[4];
+  uint8_t* flags[4];
+  int n;
+};
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k_dense_opt_rows(float* __restrict__ p, float* __restrict__ g, float* __restrict__ s1,
+                                                        float* __restrict__ s2, int64_t n, OptArgs a, RowSegs sg) {
+  const int64_t n4 = n / 4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const int64_t e = i * 4;
+    bool touched = true;
+    uint8_t* fl = nullptr;
+    bool first = false;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (q < sg.n && e >= sg.begin[q] && e < sg.end[q]) {
+        const int64_t off = e - sg.begin[q];
+        fl = sg.flags[q] + off / sg.width[q];
+        first = off % sg.width[q] == 0;
+      }
+    if (fl) touched = *fl != 0;
+    float4 pv = reinterpret_cast<float4*>(p)[i];
+    float4 gv = make_float4(0, 0, 0, 0);
+    if (touched) gv = reinterpret_cast<float4*>(g)[i];
+    float4 av = make_float4(0, 0, 0, 0), bv = make_float4(0, 0, 0, 0);
+    if (KIND != DCCF_OPT_GD) av = reinterpret_cast<float4*>(s1)[i];
+    if (KIND == DCCF_OPT_ADAM) bv = reinterpret_cast<float4*>(s2)[i];
+    opt_elem<KIND>(pv.x, gv.x, av.x, bv.x, a);
+    opt_elem<KIND>(pv.y, gv.y, av.y, bv.y, a);
+    opt_elem<KIND>(pv.z, gv.z, av.z, bv.z, a);
+    opt_elem<KIND>(pv.w, gv.w, av.w, bv.w, a);
+    reinterpret_cast<float4*>(p)[i] = pv;
+    if (touched) reinterpret_cast<float4*>(g)[i] = make_float4(0, 0, 0, 0);
+    if (KIND != DCCF_OPT_GD) reinterpret_cast<float4*>(s1)[i] = av;
+    if (KIND == DCCF_OPT_ADAM) reinterpret_cast<float4*>(s2)[i] = bv;
+    if (fl && touched && first) *fl = 0;
+  }
+  for (int64_t i = n4 * 4 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) {   // dense tail
+    float pv = p[i], gv = g[i], av = 0.f, bv = 0.f;
+    if (KIND != DCCF_OPT_GD) av = s1[i];
+    if (KIND == DCCF_OPT_ADAM) bv = s2[i];
+    opt_elem<KIND>(pv, gv, av, bv, a);
+    p[i] = pv;
+    g[i] = 0.f;
+    if (KIND != DCCF_OPT_GD) s1[i] = av;
+    if (KIND == DCCF_OPT_ADAM) s2[i] = bv;
+  }
+}
+
+extern "C" int dccf_dense_opt_step_rows(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t n, float lr,
+                                        float wd, float l2, float clip, int64_t step, int32_t nseg, const int64_t* seg_begin,
+                                        const int64_t* seg_rows, const int32_t* seg_width, uint8_t* const* seg_flags,
+                                        void* stream) {
+  ARG_CHECK(p && g && n >= 0 && step >= 1, "NULL p/g, n < 0 or step < 1");
+  ARG_CHECK(kind == DCCF_OPT_GD || kind == DCCF_OPT_ADAGRAD || kind == DCCF_OPT_ADAM, "unknown optimizer kind");
+  ARG_CHECK(kind == DCCF_OPT_GD || s1, "optimizer state s1 is NULL");
+  ARG_CHECK(kind != DCCF_OPT_ADAM || s2, "optimizer state s2 is NULL");
+  ARG_CHECK(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && (!s1 || (uintptr_t)s1 % 16 == 0) &&
+                (!s2 || (uintptr_t)s2 % 16 == 0),
+            "buffers must be 16-byte aligned");
+  ARG_CHECK(nseg >= 0 && nseg <= 4 && (nseg == 0 || (seg_begin && seg_rows && seg_width && seg_flags)), "bad segments");
+  RowSegs sg;
+  sg.n = nseg;
+  for (int q = 0; q < nseg; ++q) {
+    const int w = seg_width[q];
+    ARG_CHECK(w == 16 || w == 32 || w == 64 || w == 128, "segment row width must be 16, 32, 64 or 128");
+    ARG_CHECK(seg_begin[q] % 256 == 0 && seg_rows[q] >= 0 && seg_begin[q] + seg_rows[q] * w <= n && seg_flags[q],
+              "segment must start on a 256-float boundary, lie inside the buffer and have flags");
+    sg.begin[q] = seg_begin[q];
+    sg.end[q] = seg_begin[q] + seg_rows[q] * w;
+    sg.width[q] = w;
+    sg.flags[q] = seg_flags[q];
+  }
+  if (n == 0) return 0;
+  OptArgs a;
+  a.lr = lr; a.wd = wd; a.l2 = l2; a.clip = clip; a.zero_grad = 1;
+  const double bc1 = 1.0 - pow(0.9, (double)step), bc2 = 1.0 - pow(0.999, (double)step);
+  a.step_size_neg = (float)(-((double)lr / bc1));
+  a.bc2_sqrt = (float)sqrt(bc2);
+  const int64_t work = (n + 3) / 4;
+  const int grid = (int)min((int64_t)(256 * 16), (work + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+  if (kind == DCCF_OPT_GD) hipLaunchKernelGGL(k_dense_opt_rows<DCCF_OPT_GD>, dim3(grid), dim3(256), 0, st, p, g, s1, s2, n, a, sg);
+  else if (kind == DCCF_OPT_ADAGRAD) hipLaunchKernelGGL(k_dense_opt_rows<DCCF_OPT_ADAGRAD>, dim3(grid), dim3(256), 0, st, p, g, s1, s2, n, a, sg);
+  else hipLaunchKernelGGL(k_dense_opt_rows<DCCF_OPT_ADAM>, dim3(grid), dim3(256), 0, st, p, g, s1, s2, n, a, sg);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 extern "C" int dccf_dense_opt_step(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t n, float lr, float wd,
                                    float l2, float clip, int64_t step, int32_t zero_grad, void* stream) {
   ARG_CHECK(p && g && n >= 0 && step >= 1, "NULL p/g, n < 0 or step < 1");

@@ -46,8 +46,13 @@ class FusedOptimizer(object):
     def step(self):
         self.t += 1
         m = self.model
-        _lib.dense_opt_step(self.name, m.flat_p, m.flat_g, self.s1, self.s2, self.lr, self.l2, self.l2, self.clip, self.t,
-                            zero_grad=True)
+        segs = getattr(m, 'row_segments', None)
+        if segs:     # g of rows the backward did not touch is zero by construction: not read, not re-zeroed
+            _lib.dense_opt_step_rows(self.name, m.flat_p, m.flat_g, self.s1, self.s2, self.lr, self.l2, self.l2, self.clip,
+                                     self.t, segs)
+        else:
+            _lib.dense_opt_step(self.name, m.flat_p, m.flat_g, self.s1, self.s2, self.lr, self.l2, self.l2, self.clip, self.t,
+                                zero_grad=True)
 
 
 class BaseModel(object):
@@ -98,14 +103,15 @@ class BaseModel(object):
 
     def _allocate(self):
         sizes = [int(np.prod(s)) if len(s) else 1 for s, _ in self._specs.values()]
-        pads = [(n + 3) // 4 * 4 for n in sizes]
+        pads = [(n + 255) // 256 * 256 for n in sizes]      # every parameter starts on a 256-float boundary
         self.flat_p = torch.zeros(sum(pads), dtype=torch.float32, device=self.device)
         self.flat_g = torch.zeros_like(self.flat_p)
-        self.params, self.grads = OrderedDict(), OrderedDict()
+        self.params, self.grads, self.offsets = OrderedDict(), OrderedDict(), OrderedDict()
         o = 0
         for (name, (shape, init)), n, pd in zip(self._specs.items(), sizes, pads):
             self.params[name] = self.flat_p[o:o + n].view(shape)
             self.grads[name] = self.flat_g[o:o + n].view(shape)
+            self.offsets[name] = o
             o += pd
             t = self.params[name]
             # torch defaults of the layers the reference builds, overwritten by main.py's model.apply(init_paras)
@@ -358,6 +364,12 @@ class DCCF(DMF):
         p = self.params
         self._modules = [_ParamModule('embedding', p['uid_embeddings.weight']), _ParamModule('embedding', p['iid_embeddings.weight']),
                          _ParamModule('linear', p['mlp.0.weight'], p['mlp.0.bias'])]
+        # one "touched" byte per embedding row, set by the backward, consumed by the row-aware dense optimizer step
+        self.touchedU = torch.zeros(self.user_num, dtype=torch.uint8, device=self.device)
+        self.touchedV = torch.zeros(self.item_num, dtype=torch.uint8, device=self.device)
+        D = self.ui_vector_size
+        self.row_segments = [(self.offsets['uid_embeddings.weight'], self.user_num, D, self.touchedU),
+                             (self.offsets['iid_embeddings.weight'], self.item_num, D, self.touchedV)]
 
     def _struct(self):
         """The C view of the model; parameter storage never moves, so it is built once."""
@@ -393,5 +405,5 @@ class DCCF(DMF):
         pred, loss = _lib.dccf_train_fwdbwd(self.ctx, ms, self._rand(feed_dict), feed_dict['X'].contiguous(),
                                             feed_dict['Y'], feed_dict['rank'], feed_dict['dropout'],
                                             g['uid_embeddings.weight'], g['iid_embeddings.weight'], g['mlp.0.weight'],
-                                            g['mlp.0.bias'], loss=self._loss)
+                                            g['mlp.0.bias'], loss=self._loss, touchedU=self.touchedU, touchedV=self.touchedV)
         return {'prediction': pred, 'check': [('prediction', pred)], 'loss': loss[0]}

@@ -83,6 +83,8 @@ typedef struct {             /* dense-shaped gradients of the LOSS term, accumul
   float* gV;                 /* [item_num, D]   */
   float* gW;                 /* [D, D+F]        */
   float* gb;                 /* [D]             */
+  uint8_t* touchedU;         /* optional [user_num]: set to 1 for every row of gU this call adds to (NULL = not kept)   */
+  uint8_t* touchedV;         /* optional [item_num]: same for gV; consumed by dccf_dense_opt_step_rows                  */
 } dccf_grads_t;
 
 /* DCCF.predict (src/models/DCCF.py:66-107): X int64 [N,2] -> prediction fp32 [N].  `dropout` is feed_dict['dropout']. */
@@ -106,6 +108,14 @@ int dccf_train_fwdbwd(dccf_ctx* ctx, const dccf_model_t* model, const dccf_rand_
 #define DCCF_OPT_ADAM 2
 int dccf_dense_opt_step(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t n, float lr, float wd,
                         float l2, float clip, int64_t step, int32_t zero_grad, void* stream);
+/* Same step for a flat buffer whose first part is row-structured: segment q covers elements [seg_begin[q], seg_begin[q] +
+ * seg_rows[q]*seg_width[q]) as rows of seg_width[q] floats (16, 32, 64 or 128; seg_begin a multiple of 256) with one
+ * "touched" byte per row (dccf_grads_t.touchedU/V).  A row whose byte is 0 has an all-zero gradient by construction, so
+ * g is neither read nor re-zeroed for it (24 instead of 32 B/param of traffic); touched rows are read, zeroed and their
+ * byte cleared.  Elements outside the segments are treated densely.  seg_* are HOST arrays, nseg <= 4. */
+int dccf_dense_opt_step_rows(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t n, float lr, float wd,
+                             float l2, float clip, int64_t step, int32_t nseg, const int64_t* seg_begin,
+                             const int64_t* seg_rows, const int32_t* seg_width, uint8_t* const* seg_flags, void* stream);
 /* BaseModel.l2 (src/models/BaseModel.py:179-187): out[0] += sum p^2  (out must be zeroed by the caller). */
 int dccf_sumsq(const float* p, int64_t n, float* out, void* stream);
 

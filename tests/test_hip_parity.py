@@ -414,3 +414,44 @@ def test_sharded_trainer_with_hip_backend_world1(L):
             close(t, P[k], PARAM_RTOL, PARAM_ATOL + STEP_FRAC * c['lr'], 'sharded param ' + k)
     finally:
         dist.destroy_process_group()
+
+
+def test_row_aware_optimizer_equals_dense(L, ctx):
+    """dccf_dense_opt_step_rows (skips the gradient of rows whose "touched" byte is 0) must give bit-identical
+    parameters to the dense step, over several training steps with the backward setting the bytes."""
+    rng = np.random.RandomState(12)
+    U_, I_, D, F, S, A, pairs = 700, 520, 64, 160, 10, 2, 24
+    shapes = [(U_, D), (I_, D), (D, D + F), (D,)]
+    sizes = [int(np.prod(s)) for s in shapes]
+    pads = [(n + 255) // 256 * 256 for n in sizes]
+    init = (rng.randn(sum(pads)) * 0.1).astype(np.float32)
+    feat, expo = T((rng.randn(I_, F) * 0.5).astype(np.float32)), T(rng.randn(U_, I_).astype(np.float32))
+    runs = []
+    for rows in (False, True):
+        buf = [T(init.copy()), torch.zeros(sum(pads), device=dev()), torch.zeros(sum(pads), device=dev()),
+               torch.zeros(sum(pads), device=dev())]
+        offs = np.cumsum([0] + pads[:-1])
+        v = [buf[0][o:o + n].view(s) for o, n, s in zip(offs, sizes, shapes)]
+        gv = [buf[1][o:o + n].view(s) for o, n, s in zip(offs, sizes, shapes)]
+        tU = torch.zeros(U_, dtype=torch.uint8, device=dev())
+        tV = torch.zeros(I_, dtype=torch.uint8, device=dev())
+        m = L.model_struct(v[0], v[1], v[2], v[3], feat, expo, S, A, 0.1)
+        r2 = np.random.RandomState(99)
+        for step in range(1, 5):
+            u = r2.randint(0, U_, pairs)
+            X = T(np.concatenate([np.stack([u, r2.randint(0, I_, pairs)], 1), np.stack([u, r2.randint(0, I_, pairs)], 1)]).astype(np.int64))
+            Y = torch.cat([torch.ones(pairs, device=dev()), torch.zeros(pairs, device=dev())])
+            L.dccf_train_fwdbwd(ctx, m, L.rand_struct(seed=5, step=step), X, Y, 1, 0.2, gv[0], gv[1], gv[2], gv[3],
+                                touchedU=tU if rows else None, touchedV=tV if rows else None)
+            if rows:
+                nU, nV = int(tU.sum()), int(tV.sum())
+                assert 0 < nU <= pairs and pairs <= nV <= 2 * pairs * (S + 1)
+                assert bool(((gv[0].abs().sum(1) > 0) <= (tU > 0)).all())       # a non-zero gradient row is always flagged
+                L.dense_opt_step_rows('adam', buf[0], buf[1], buf[2], buf[3], 1e-3, 1e-4, 1e-4, 50.0, step,
+                                      [(int(offs[0]), U_, D, tU), (int(offs[1]), I_, D, tV)])
+                assert int(tU.sum()) == 0 and int(tV.sum()) == 0 and float(buf[1].abs().max()) == 0.0
+            else:
+                L.dense_opt_step('adam', buf[0], buf[1], buf[2], buf[3], 1e-3, 1e-4, 1e-4, 50.0, step)
+        runs.append(buf[0].cpu().numpy())
+    # float atomics may reorder the sums inside the backward between the two runs, the optimizer itself is identical
+    close(runs[1], runs[0], 1e-6, 1e-8, 'row-aware vs dense optimizer')
