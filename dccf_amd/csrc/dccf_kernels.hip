@@ -171,7 +171,6 @@ __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT,
 #pragma unroll
           for (int nt = 0; nt < ND; ++nt) acc[nt] = MFMA32(a[o], breg[(c2 * 4 + o) * ND + nt], acc[nt]);
         }
-        __builtin_amdgcn_sched_barrier(0);          // keep the next group's loads from being hoisted (register budget)
       }
     } else {
       const float* vrow = V + (int64_t)cand[(uint32_t)lc / (uint32_t)A] * D;
