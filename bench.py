@@ -44,6 +44,8 @@ def parse():
     p.add_argument('--cpu_steps', type=int, default=60)
     p.add_argument('--seed', type=int, default=2019)
     p.add_argument('--force_sharded', type=int, default=0, help='run the row-sharded pipeline even at --gpus 1')
+    p.add_argument('--graph', type=int, default=0, help='1: each step is one hipGraph replay (device-side step counter); '
+                   'measured slower than eager launches here (132 vs 122 us/step), hence off')
     return p.parse_args()
 
 
@@ -148,22 +150,47 @@ def main():
             if events is not None:
                 events[k - k0][1].record()
 
-    full, _ = ds.epoch_batches(0, B)             # warm-up epoch: its own negatives
-    run(full, 0, args.warmup)
-    torch.cuda.synchronize()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    model.ctx.profile(True)
+    from dccf_amd.models import StepGraph
+    sg = StepGraph(model, opt, args.warmup + args.steps, 2 * B, p_drop) if args.graph else None
 
+    def epoch_tensor(e):
+        full, _ = ds.epoch_batches(e, B)
+        return full[:args.warmup + args.steps].contiguous()
+
+    if sg is not None:
+        sg.load_epoch(epoch_tensor(0))
+        for _ in range(args.warmup):
+            sg.step()
+    else:
+        full = epoch_tensor(0)
+        run(full, 0, args.warmup)
     torch.cuda.synchronize()
+
     t0 = time.perf_counter()
-    full, _ = ds.epoch_batches(1, B)             # timed: the epoch's negative sampling + batch views are inside
-    run(full, args.warmup, args.warmup + args.steps, events)
+    if sg is not None:
+        # timed: the epoch's negative sampling + batch tensor + K graph replays.  (The warm-up consumed `warmup` slots of
+        # the ring, load_epoch places the new epoch's batches where the next steps look.)
+        sg.load_epoch(epoch_tensor(1))
+        for _ in range(args.steps):
+            sg.step()
+    else:
+        full = epoch_tensor(1)
+        run(full, args.warmup, args.warmup + args.steps)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
 
+    # per-kernel durations for the roofline: an eager pass of the same steps with HIP events on the launch stream
+    # (inside a replayed graph the kernels cannot be bracketed individually); not part of the timed region
+    n_prof = min(args.steps, 100)
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_prof)]
+    model.ctx.profile(True)
+    full = epoch_tensor(2)
+    run(full, 0, n_prof, events)
+    torch.cuda.synchronize()
+    args_steps_prof = n_prof
     prof = model.ctx.profile_read()
     model.ctx.profile(False)
-    opt_ms = sum(a.elapsed_time(b) for a, b in events) / args.steps
+    opt_ms = sum(a.elapsed_time(b) for a, b in events) / args_steps_prof
     kernels = {k: v[0] / max(v[1], 1) for k, v in prof.items()}     # ms per launch
     kernels['dense_adam'] = opt_ms
     n_params = model.flat_p.numel()
@@ -199,7 +226,8 @@ def main():
         'config': {'workload': 'DCCF train step (fwd + BPR + bwd + dense l2/clip/Adam), Electronics-shaped synthetic: '
                                'user_num=%d item_num=%d D=%d F=%d S=%d A=%d, exposure=%s, fused on-device negatives'
                                % (U, I, D, F, S, A, expo_mode),
-                   'batch_size': B, 'optimizer': 'Adam lr=1e-3 l2=1e-4 dropout=0.2', 'params': n_params},
+                   'batch_size': B, 'optimizer': 'Adam lr=1e-3 l2=1e-4 dropout=0.2', 'params': n_params,
+                   'step_launch': 'hipGraph replay' if args.graph else 'eager launches'},
         'roofline': roofline,
         'kernel_ms': {k: round(v, 5) for k, v in sorted(kernels.items())},
         'embedding_fwd_bwd': {   # 4D(3+6(S+1)) + 8F + 8(S+1) + 32 algorithmic bytes per pair

@@ -14,7 +14,7 @@ EXPORTS = ['dccf_ctx_create', 'dccf_ctx_destroy', 'dccf_ctx_reserve', 'dccf_last
            'dccf_predict', 'dccf_train_fwdbwd', 'dccf_dense_opt_step', 'dccf_sumsq', 'mf_predict', 'mf_train_fwdbwd',
            'mf_predict_full', 'dccf_sample_train_negatives', 'dccf_debug_candidates', 'dccf_debug_noise',
            'dccf_debug_keep', 'dccf_debug_workspace', 'dccf_profile', 'dccf_profile_read',
-           'shard_pack_rows', 'shard_unpack_rows', 'shard_scatter_add', 'dccf_dense_opt_step_rows']
+           'shard_pack_rows', 'shard_unpack_rows', 'shard_scatter_add', 'dccf_dense_opt_step_rows', 'dccf_dense_opt_step_dev', 'dccf_advance']
 
 OPT_KIND = {'gd': 0, 'adagrad': 1, 'adam': 2}
 MF_KIND = {'RecModel': 0, 'BiasedMF': 1, 'IPSBiasedMF': 2}
@@ -32,7 +32,7 @@ class ModelT(C.Structure):
 
 class RandT(C.Structure):
     _fields_ = [('mode', C.c_int32), ('reserved', C.c_int32), ('sample_item', _f), ('noise', _f), ('keep', _f),
-                ('seed', C.c_uint64), ('step', C.c_uint64)]
+                ('seed', C.c_uint64), ('step', C.c_uint64), ('k_dev', _f), ('x_stride', C.c_int64), ('x_steps', C.c_int64)]
 
 
 class GradsT(C.Structure):
@@ -75,6 +75,9 @@ def load():
         'dccf_dense_opt_step': [i32, vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, i32, vp],
         'dccf_dense_opt_step_rows': [i32, vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, i32, C.POINTER(i64), C.POINTER(i64),
                                      C.POINTER(i32), C.POINTER(vp), vp],
+        'dccf_dense_opt_step_dev': [i32, vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, vp, i32, C.POINTER(i64), C.POINTER(i64),
+                                    C.POINTER(i32), C.POINTER(vp), vp],
+        'dccf_advance': [vp, vp],
         'dccf_sumsq': [vp, i64, vp, vp],
         'mf_predict': [C.POINTER(MFModelT), vp, i64, vp, vp],
         'mf_train_fwdbwd': [vp, C.POINTER(MFModelT), vp, vp, i64, i32, C.POINTER(MFGradsT), vp, vp, vp],
@@ -169,8 +172,11 @@ def model_struct(U, V, W, b, feat, expo, S, A, std, ips=None):
     return m
 
 
-def rand_struct(sample_item=None, noise=None, keep=None, seed=None, step=0):
+def rand_struct(sample_item=None, noise=None, keep=None, seed=None, step=0, k_dev=None, x_stride=0, x_steps=1):
     r = RandT()
+    if k_dev is not None:
+        r.k_dev, r.x_stride, r.x_steps = ptr(k_dev, torch.int64), int(x_stride), int(x_steps)
+        r._kref = k_dev
     if seed is not None and sample_item is not None:      # candidates injected, noise / dropout fused
         r.mode, r.seed, r.step = 2, int(seed) & 0xFFFFFFFFFFFFFFFF, int(step)
         r.sample_item = ptr(sample_item, torch.int64)
@@ -212,16 +218,24 @@ def dense_opt_step(kind, p, g, s1, s2, lr, wd, l2, clip, step, zero_grad=True):
                                      1 if zero_grad else 0, stream()))
 
 
-def dense_opt_step_rows(kind, p, g, s1, s2, lr, wd, l2, clip, step, segments):
-    """segments: list of (begin element, rows, row width, touched uint8 tensor) — see dccf_dense_opt_step_rows."""
+def dense_opt_step_rows(kind, p, g, s1, s2, lr, wd, l2, clip, step, segments, k_dev=None):
+    """segments: list of (begin element, rows, row width, touched uint8 tensor) — see dccf_dense_opt_step_rows.
+    With k_dev (int64 device scalar) the step is step + *k_dev (graph-replayable form)."""
     n = len(segments)
-    beg = (C.c_int64 * n)(*[int(s[0]) for s in segments])
-    rows = (C.c_int64 * n)(*[int(s[1]) for s in segments])
-    wid = (C.c_int32 * n)(*[int(s[2]) for s in segments])
-    fl = (C.c_void_p * n)(*[ptr(s[3], torch.uint8) for s in segments])
-    check(load().dccf_dense_opt_step_rows(OPT_KIND[kind.lower()], ptr(p, torch.float32), ptr(g, torch.float32), ptr(s1),
-                                          ptr(s2), p.numel(), float(lr), float(wd), float(l2), float(clip), int(step), n,
-                                          beg, rows, wid, fl, stream()))
+    beg = (C.c_int64 * max(n, 1))(*[int(s[0]) for s in segments])
+    rows = (C.c_int64 * max(n, 1))(*[int(s[1]) for s in segments])
+    wid = (C.c_int32 * max(n, 1))(*[int(s[2]) for s in segments])
+    fl = (C.c_void_p * max(n, 1))(*[ptr(s[3], torch.uint8) for s in segments])
+    a = (OPT_KIND[kind.lower()], ptr(p, torch.float32), ptr(g, torch.float32), ptr(s1), ptr(s2), p.numel(), float(lr),
+         float(wd), float(l2), float(clip), int(step))
+    if k_dev is None:
+        check(load().dccf_dense_opt_step_rows(*a, n, beg, rows, wid, fl, stream()))
+    else:
+        check(load().dccf_dense_opt_step_dev(*a, ptr(k_dev, torch.int64), n, beg, rows, wid, fl, stream()))
+
+
+def advance(k_dev):
+    check(load().dccf_advance(ptr(k_dev, torch.int64), stream()))
 
 
 def sumsq(p):

@@ -101,6 +101,22 @@ static inline rng_key make_key(uint64_t seed, uint32_t stream, uint64_t step) {
   return k;
 }
 
+// step words + k (the device-side step counter of a replayed graph)
+__device__ __forceinline__ rng_key key_plus(rng_key k, int64_t add) {
+  const uint64_t st = (((uint64_t)k.s1 << 32) | k.s0) + (uint64_t)add;
+  k.s0 = (uint32_t)st;
+  k.s1 = (uint32_t)(st >> 32);
+  return k;
+}
+struct StepRef {          // how a kernel finds "its" batch and stream counter
+  const int64_t* k_dev;
+  int64_t x_stride, x_steps;
+};
+__device__ __forceinline__ int64_t step_k(const StepRef& r) { return r.k_dev ? *r.k_dev : 0; }
+__device__ __forceinline__ const int64_t* step_X(const StepRef& r, const int64_t* X, int64_t k) {
+  return r.k_dev ? X + (k % r.x_steps) * r.x_stride : X;
+}
+
 // 23-bit uniform strictly inside (0,1), exact in fp32.
 __device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 9) + 0.5f) * 0x1p-23f; }
 

@@ -62,9 +62,14 @@ static Lay make_layout(int64_t N, int D, int F, int S, int A) {
 // WT[k][d] = W[d][k] (zero padded), cand[n][0] = true item, cand[n][s] = injected or Philox candidate
 // (models/DCCF.py:72-74), m = 0 (only when two column halves add into it), loss = 0.
 __global__ void k_prep(const float* __restrict__ W, float* __restrict__ WT, int D, int F, int DP, int FP,
-                       const int64_t* __restrict__ X, const int64_t* __restrict__ sample_item, int* __restrict__ cand,
+                       const int64_t* X, const int64_t* __restrict__ sample_item, int* __restrict__ cand,
                        int64_t N, int S, int64_t item_num, int fused, rng_key key, float* __restrict__ m, int64_t Lm,
-                       float* __restrict__ loss) {
+                       float* __restrict__ loss, StepRef sr) {
+  {
+    const int64_t k = step_k(sr);
+    X = step_X(sr, X, k);
+    key = key_plus(key, k);
+  }
   const int64_t nWT = (int64_t)(D + FP) * DP;
   const int64_t NS = N * (S + 1);
   const int64_t total = nWT + NS + Lm + 1;
@@ -102,13 +107,19 @@ __global__ void k_prep(const float* __restrict__ W, float* __restrict__ WT, int 
 template <int D_, int MODE>   // MODE 0: fused Philox draws, 1: injected noise / keep mask
 __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT, const float* __restrict__ bias,
                                                    const float* __restrict__ U, const float* __restrict__ V,
-                                                   const float* __restrict__ feat, const int64_t* __restrict__ X,
+                                                   const float* __restrict__ feat, const int64_t* X,
                                                    const int* __restrict__ cand, const float* __restrict__ noise,
                                                    const uint8_t* __restrict__ keep, float* __restrict__ hbuf,
                                                    float* __restrict__ m, int64_t L, int S1,
                                                    int A, int F, rng_key nkey, rng_key dkey, float nscale,
-                                                   uint32_t drop_thr, float kscale) {
+                                                   uint32_t drop_thr, float kscale, StepRef sr) {
   extern __shared__ float zpart[];   // [NW][32][DW]
+  {
+    const int64_t k = step_k(sr);
+    X = step_X(sr, X, k);
+    nkey = key_plus(nkey, k);
+    dkey = key_plus(dkey, k);
+  }
   constexpr int D = D_;
   constexpr int DP = D <= 32 ? 32 : (D + 63) / 64 * 64;
   constexpr int ND = D <= 32 ? 1 : 2;
@@ -264,11 +275,12 @@ __device__ __forceinline__ float row_predict(const dccf_model_t& M, const int64_
 }
 
 template <int GS>
-__global__ __launch_bounds__(256) void k_pair_epilogue(dccf_model_t M, const int64_t* __restrict__ X,
+__global__ __launch_bounds__(256) void k_pair_epilogue(dccf_model_t M, const int64_t* X,
                                                        const float* __restrict__ Y, const int* __restrict__ cand,
                                                        const float* __restrict__ m, float* __restrict__ dmns,
                                                        float* __restrict__ pred, float* __restrict__ loss, int64_t N,
-                                                       int rank, int train) {
+                                                       int rank, int train, StepRef sr) {
+  X = step_X(sr, X, step_k(sr));
   const int S1 = M.S + 1, A = M.A;
   const int s = threadIdx.x % GS;
   const int64_t gid = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / GS;
@@ -344,6 +356,7 @@ struct BwdArgs {
   int S1, A, F, NC;
   float kscale, nscale;
   rng_key nkey;
+  StepRef sr;
 };
 
 // roles "feature chunk" (CHUNK) and "item": A = dz^T for the rows of n, B = eps (regenerated / injected) or V[cand]
@@ -584,6 +597,11 @@ __device__ __forceinline__ void bwd_dx_role(const BwdArgs& p, int dbase) {
 template <int D_, int MODE>
 __global__ __launch_bounds__(256) void k_bwd(BwdArgs p) {
   extern __shared__ float red[];          // [4 waves][<= 128 regs][64 lanes]
+  {
+    const int64_t k = step_k(p.sr);
+    p.X = step_X(p.sr, p.X, k);
+    p.nkey = key_plus(p.nkey, k);
+  }
   constexpr int DW = (D_ <= 32 ? 1 : 2) * 32;
   constexpr int GY = D_ <= 64 ? 1 : D_ / 64;
   const int role = blockIdx.y / GY;
@@ -654,13 +672,17 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
   const float kscale = dropout > 0.f ? 1.0f / (float)(1.0 - (double)dropout) : 1.0f;
   const uint32_t thr = dropout > 0.f ? drop_threshold(dropout) : 0u;
   const int64_t ntiles = (y.L + 31) / 32;
+  StepRef sr;
+  sr.k_dev = rnd->k_dev;
+  sr.x_stride = rnd->x_stride;
+  sr.x_steps = rnd->x_steps > 0 ? rnd->x_steps : 1;
 
   {
     const int64_t total = (int64_t)(D + y.FP) * y.DP + y.NS + (y.GY > 1 ? y.L : 0) + 1;
     const int grid = (int)min((int64_t)2048, (total + 255) / 256);
     prof_begin(ctx, st);
     hipLaunchKernelGGL(k_prep, dim3(grid), dim3(256), 0, st, M->W, WT, D, F, y.DP, y.FP, X, rnd->sample_item, cand, N,
-                       M->S, M->item_num, fused_cand ? 1 : 0, ckey, m, y.GY > 1 ? y.L : (int64_t)0, train ? loss : nullptr);
+                       M->S, M->item_num, fused_cand ? 1 : 0, ckey, m, y.GY > 1 ? y.L : (int64_t)0, train ? loss : nullptr, sr);
     prof_end(ctx, 0, st);
   }
   {
@@ -670,10 +692,10 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
 #define LAUNCH_FWD(D_)                                                                                               \
   if (fused)                                                                                                         \
     hipLaunchKernelGGL((k_noise_fwd<D_, 0>), grid, block, smem, st, WT, M->b, M->U, M->V, M->feat, X, cand, rnd->noise, \
-                       rnd->keep, hbuf, m, y.L, S1, A, F, nkey, dkey, nscale, thr, kscale);                  \
+                       rnd->keep, hbuf, m, y.L, S1, A, F, nkey, dkey, nscale, thr, kscale, sr);                  \
   else                                                                                                               \
     hipLaunchKernelGGL((k_noise_fwd<D_, 1>), grid, block, smem, st, WT, M->b, M->U, M->V, M->feat, X, cand, rnd->noise, \
-                       rnd->keep, hbuf, m, y.L, S1, A, F, nkey, dkey, nscale, thr, kscale);
+                       rnd->keep, hbuf, m, y.L, S1, A, F, nkey, dkey, nscale, thr, kscale, sr);
     BY_D(D, LAUNCH_FWD)
 #undef LAUNCH_FWD
     prof_end(ctx, 2, st);
@@ -685,7 +707,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     prof_begin(ctx, st);
 #define LAUNCH_PE(GS_)                                                                                              \
   hipLaunchKernelGGL((k_pair_epilogue<GS_>), dim3(grid), dim3(256), 0, st, *M, X, Y, cand, m, dmns, pred, loss, N, rank, \
-                     train ? 1 : 0)
+                     train ? 1 : 0, sr)
     if (GS == 16) LAUNCH_PE(16); else if (GS == 32) LAUNCH_PE(32); else LAUNCH_PE(64);
 #undef LAUNCH_PE
     prof_end(ctx, 3, st);
@@ -700,17 +722,25 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     prof_begin(ctx, st);
 #define LAUNCH_BWD(D_)                                                                                              \
   if (fused) {                                                                                                      \
-    HIP_TRY(hipFuncSetAttribute((const void*)k_bwd<D_, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+    static bool once0 = false;                                                                                      \
+    if (!once0) {                                                                                                   \
+      HIP_TRY(hipFuncSetAttribute((const void*)k_bwd<D_, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+      once0 = true;                                                                                                 \
+    }                                                                                                               \
     hipLaunchKernelGGL((k_bwd<D_, 0>), grid, dim3(256), smem, st, ba);                                              \
   } else {                                                                                                          \
-    HIP_TRY(hipFuncSetAttribute((const void*)k_bwd<D_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+    static bool once1 = false;                                                                                      \
+    if (!once1) {                                                                                                   \
+      HIP_TRY(hipFuncSetAttribute((const void*)k_bwd<D_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+      once1 = true;                                                                                                 \
+    }                                                                                                               \
     hipLaunchKernelGGL((k_bwd<D_, 1>), grid, dim3(256), smem, st, ba);                                              \
   }
     BwdArgs ba;
     ba.W = M->W; ba.U = M->U; ba.V = M->V; ba.feat = M->feat; ba.X = X; ba.cand = cand; ba.dmns = dmns; ba.hbuf = hbuf;
     ba.noise = rnd->noise; ba.gU = G->gU; ba.gV = G->gV; ba.gW = G->gW; ba.gb = G->gb;
     ba.touchedU = G->touchedU; ba.touchedV = G->touchedV; ba.N = N; ba.S1 = S1; ba.A = A;
-    ba.F = F; ba.NC = y.NC; ba.kscale = kscale; ba.nscale = nscale; ba.nkey = nkey;
+    ba.F = F; ba.NC = y.NC; ba.kscale = kscale; ba.nscale = nscale; ba.nkey = nkey; ba.sr = sr;
     BY_D(D, LAUNCH_BWD)
 #undef LAUNCH_BWD
     prof_end(ctx, 5, st);

@@ -94,7 +94,17 @@ struct OptArgs {
   float step_size_neg;   // Adam: -(lr / (1 - beta1^t))
   float bc2_sqrt;        // Adam: sqrt(1 - beta2^t)
   int zero_grad;
+  const int64_t* k_dev;  // graph-replayable form: step = step0 + *k_dev, bias corrections computed here
+  int64_t step0;
 };
+
+__device__ __forceinline__ void opt_resolve(OptArgs& a) {
+  if (a.k_dev) {
+    const double t = (double)(a.step0 + *a.k_dev);
+    a.step_size_neg = (float)(-((double)a.lr / (1.0 - pow(0.9, t))));
+    a.bc2_sqrt = (float)sqrt(1.0 - pow(0.999, t));
+  }
+}
 
 template <int KIND>
 __device__ __forceinline__ void opt_elem(float& p, float& g, float& s1, float& s2, const OptArgs& a) {
@@ -120,6 +130,7 @@ __device__ __forceinline__ void opt_elem(float& p, float& g, float& s1, float& s
 template <int KIND>
 __global__ __launch_bounds__(256) void k_dense_opt(float* __restrict__ p, float* __restrict__ g, float* __restrict__ s1,
                                                    float* __restrict__ s2, int64_t n, OptArgs a) {
+  opt_resolve(a);
   const int64_t n4 = n / 4;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -163,6 +174,7 @@ struct RowSegs {
 template <int KIND>
 __global__ __launch_bounds__(256) void k_dense_opt_rows(float* __restrict__ p, float* __restrict__ g, float* __restrict__ s1,
                                                         float* __restrict__ s2, int64_t n, OptArgs a, RowSegs sg) {
+  opt_resolve(a);
   const int64_t n4 = n / 4;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -206,10 +218,9 @@ __global__ __launch_bounds__(256) void k_dense_opt_rows(float* __restrict__ p, f
   }
 }
 
-extern "C" int dccf_dense_opt_step_rows(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t n, float lr,
-                                        float wd, float l2, float clip, int64_t step, int32_t nseg, const int64_t* seg_begin,
-                                        const int64_t* seg_rows, const int32_t* seg_width, uint8_t* const* seg_flags,
-                                        void* stream) {
+static int opt_rows_impl(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t n, float lr, float wd, float l2,
+                         float clip, int64_t step, const int64_t* k_dev, int32_t nseg, const int64_t* seg_begin,
+                         const int64_t* seg_rows, const int32_t* seg_width, uint8_t* const* seg_flags, void* stream) {
   ARG_CHECK(p && g && n >= 0 && step >= 1, "NULL p/g, n < 0 or step < 1");
   ARG_CHECK(kind == DCCF_OPT_GD || kind == DCCF_OPT_ADAGRAD || kind == DCCF_OPT_ADAM, "unknown optimizer kind");
   ARG_CHECK(kind == DCCF_OPT_GD || s1, "optimizer state s1 is NULL");
@@ -233,6 +244,7 @@ extern "C" int dccf_dense_opt_step_rows(int32_t kind, float* p, float* g, float*
   if (n == 0) return 0;
   OptArgs a;
   a.lr = lr; a.wd = wd; a.l2 = l2; a.clip = clip; a.zero_grad = 1;
+  a.k_dev = k_dev; a.step0 = step;
   const double bc1 = 1.0 - pow(0.9, (double)step), bc2 = 1.0 - pow(0.999, (double)step);
   a.step_size_neg = (float)(-((double)lr / bc1));
   a.bc2_sqrt = (float)sqrt(bc2);
@@ -242,6 +254,31 @@ extern "C" int dccf_dense_opt_step_rows(int32_t kind, float* p, float* g, float*
   if (kind == DCCF_OPT_GD) hipLaunchKernelGGL(k_dense_opt_rows<DCCF_OPT_GD>, dim3(grid), dim3(256), 0, st, p, g, s1, s2, n, a, sg);
   else if (kind == DCCF_OPT_ADAGRAD) hipLaunchKernelGGL(k_dense_opt_rows<DCCF_OPT_ADAGRAD>, dim3(grid), dim3(256), 0, st, p, g, s1, s2, n, a, sg);
   else hipLaunchKernelGGL(k_dense_opt_rows<DCCF_OPT_ADAM>, dim3(grid), dim3(256), 0, st, p, g, s1, s2, n, a, sg);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int dccf_dense_opt_step_rows(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t n, float lr,
+                                        float wd, float l2, float clip, int64_t step, int32_t nseg, const int64_t* seg_begin,
+                                        const int64_t* seg_rows, const int32_t* seg_width, uint8_t* const* seg_flags,
+                                        void* stream) {
+  return opt_rows_impl(kind, p, g, s1, s2, n, lr, wd, l2, clip, step, nullptr, nseg, seg_begin, seg_rows, seg_width, seg_flags,
+                       stream);
+}
+
+extern "C" int dccf_dense_opt_step_dev(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t n, float lr, float wd,
+                                       float l2, float clip, int64_t step, const int64_t* k_dev, int32_t nseg,
+                                       const int64_t* seg_begin, const int64_t* seg_rows, const int32_t* seg_width,
+                                       uint8_t* const* seg_flags, void* stream) {
+  ARG_CHECK(k_dev != nullptr, "k_dev is NULL");
+  return opt_rows_impl(kind, p, g, s1, s2, n, lr, wd, l2, clip, step, k_dev, nseg, seg_begin, seg_rows, seg_width, seg_flags,
+                       stream);
+}
+
+__global__ void k_advance(int64_t* k) { *k += 1; }
+extern "C" int dccf_advance(int64_t* k_dev, void* stream) {
+  ARG_CHECK(k_dev != nullptr, "k_dev is NULL");
+  hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, k_dev);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -258,6 +295,7 @@ extern "C" int dccf_dense_opt_step(int32_t kind, float* p, float* g, float* s1, 
   if (n == 0) return 0;
   OptArgs a;
   a.lr = lr; a.wd = wd; a.l2 = l2; a.clip = clip; a.zero_grad = zero_grad;
+  a.k_dev = nullptr; a.step0 = step;
   // bias corrections in double like torch's Python scalars (torch/optim/adam.py::_single_tensor_adam)
   const double bc1 = 1.0 - pow(0.9, (double)step), bc2 = 1.0 - pow(0.999, (double)step);
   a.step_size_neg = (float)(-((double)lr / bc1));

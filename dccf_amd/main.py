@@ -114,7 +114,8 @@ def main(argv=None):
     data_processor = dp_cls(data_loader, model, rank=init_args.rank, test_neg_n=args.test_neg_n, seed=args.random_seed)
     runner = runner_cls(optimizer=args.optimizer, learning_rate=args.lr, epoch=args.epoch, batch_size=args.batch_size,
                         eval_batch_size=args.eval_batch_size, dropout=args.dropout, l2=args.l2, metrics=args.metric,
-                        check_epoch=args.check_epoch, early_stop=args.early_stop, fused_sampling=args.fused_sampling)
+                        check_epoch=args.check_epoch, early_stop=args.early_stop, fused_sampling=args.fused_sampling,
+                        use_graph=args.use_graph)
     logging.info('Test Before Training = ' + utils.format_metric(
         runner.evaluate(model, data_processor.get_test_data(), data_processor)) + ' ' + ','.join(runner.metrics))
     if args.load > 0:

@@ -407,3 +407,77 @@ class DCCF(DMF):
                                             g['uid_embeddings.weight'], g['iid_embeddings.weight'], g['mlp.0.weight'],
                                             g['mlp.0.bias'], loss=self._loss, touchedU=self.touchedU, touchedV=self.touchedV)
         return {'prediction': pred, 'check': [('prediction', pred)], 'loss': loss[0]}
+
+
+class StepGraph(object):
+    """One DCCF training step — forward + loss + backward kernels, the row-aware dense optimizer step, and the advance of
+    a device-side step counter — captured ONCE as a hipGraph and replayed for every full batch of a run.
+
+    What varies from step to step lives on the device: with k = *k_dev the kernels read batch ``full[k % nb]``, draw
+    from the Philox streams at counter ``step0 + k`` and the optimizer uses ``t = t0 + k`` (bias corrections computed in
+    the kernel), so a replay needs no parameter update and costs one host call.  The partial last batch of an epoch runs
+    eagerly through the same counter."""
+
+    def __init__(self, model, opt, nb, rows, dropout):
+        self.model, self.opt, self.nb, self.rows, self.dropout = model, opt, nb, rows, dropout
+        dev = model.device
+        self.k = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.k_host = 0
+        self.full = torch.zeros((nb, rows, 2), dtype=torch.int64, device=dev)
+        B = rows // 2
+        self.Y = torch.cat([torch.ones(B, device=dev), torch.zeros(B, device=dev)])
+        self.pred = torch.empty(rows, dtype=torch.float32, device=dev)
+        self.ms = model._struct()
+        self.step0, self.t0 = model._call + 1, opt.t + 1
+        self.rs = _lib.rand_struct(seed=model.random_seed, step=self.step0, k_dev=self.k, x_stride=rows * 2, x_steps=nb)
+        model.ctx.reserve(rows, model.ui_vector_size, model.feature_embedding.shape[1], model.sample_num, model.attribute_num)
+        self.graph = None
+
+    def _body(self, X, Y, rs, pred):
+        m, o, g = self.model, self.opt, self.model.grads
+        _lib.dccf_train_fwdbwd(m.ctx, self.ms, rs, X, Y, 1, self.dropout, g['uid_embeddings.weight'], g['iid_embeddings.weight'],
+                               g['mlp.0.weight'], g['mlp.0.bias'], pred=pred, loss=m._loss, touchedU=m.touchedU,
+                               touchedV=m.touchedV)
+        _lib.dense_opt_step_rows(o.name, m.flat_p, m.flat_g, o.s1, o.s2, o.lr, o.l2, o.l2, o.clip, self.t0, m.row_segments,
+                                 k_dev=self.k)
+        _lib.advance(self.k)
+
+    def load_epoch(self, full):
+        """Copies the epoch's [nb, 2B, 2] batches so that the j-th batch of the epoch sits where step k_host + j looks."""
+        assert tuple(full.shape) == tuple(self.full.shape)
+        slot = (self.k_host + torch.arange(self.nb, device=full.device)) % self.nb
+        self.full[slot] = full
+
+    def _count(self):
+        self.k_host += 1
+        self.model._call += 1
+        self.opt.t += 1
+
+    def step(self):
+        """The next full batch (graph replay; the very first call runs eagerly as the capture's warm-up)."""
+        if self.graph is None:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._body(self.full[0], self.Y, self.rs, self.pred)          # a real step (k = k_host), on a side stream
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._body(self.full[0], self.Y, self.rs, self.pred)
+        else:
+            self.graph.replay()
+        self._count()
+
+    def tail(self, X):
+        """A partial batch [2r, 2], eagerly, through the same device counter (so streams and Adam's t stay in step)."""
+        r = X.shape[0] // 2
+        rs = _lib.rand_struct(seed=self.model.random_seed, step=self.step0, k_dev=self.k, x_stride=0, x_steps=1)
+        Y = torch.cat([self.Y[:r], self.Y[self.rows // 2:self.rows // 2 + r]])
+        pred = torch.empty(2 * r, dtype=torch.float32, device=X.device)
+        self._body(X.contiguous(), Y, rs, pred)
+        self._count()
+        return pred
+
+    def out_dict(self):
+        return {'prediction': self.pred, 'check': [('prediction', self.pred)], 'loss': self.model._loss[0]}

@@ -32,15 +32,18 @@ class BaseRunner(object):
         parser.add_argument('--skip_eval', type=int, default=0, help='number of epochs without evaluation')
         parser.add_argument('--fused_sampling', type=int, default=1,
                             help='1: train negatives and batches stay on the GPU (Philox); 0: the reference host path')
+        parser.add_argument('--use_graph', type=int, default=0,
+                            help='1: replay each DCCF training step as one hipGraph (needs --fused_sampling 1); measured '
+                                 'slower than eager launches at batch 128 on MI355X (graph-launch floor), hence off')
         return parser
 
     def __init__(self, optimizer='GD', learning_rate=0.01, epoch=100, batch_size=128, eval_batch_size=128 * 128,
-                 dropout=0.2, l2=1e-5, metrics='RMSE', check_epoch=10, early_stop=1, fused_sampling=1):
+                 dropout=0.2, l2=1e-5, metrics='RMSE', check_epoch=10, early_stop=1, fused_sampling=1, use_graph=0):
         self.optimizer_name, self.learning_rate, self.epoch = optimizer, learning_rate, epoch
         self.batch_size, self.eval_batch_size = batch_size, eval_batch_size
         self.dropout, self.no_dropout, self.l2_weight = dropout, 0.0, l2
         self.metrics = metrics.lower().split(',')
-        self.check_epoch, self.early_stop, self.fused_sampling = check_epoch, early_stop, fused_sampling
+        self.check_epoch, self.early_stop, self.fused_sampling, self.use_graph = check_epoch, early_stop, fused_sampling, use_graph
         self.time = None
         self.train_results, self.valid_results, self.test_results = [], [], []
 
@@ -91,6 +94,21 @@ class BaseRunner(object):
         if self.fused_sampling and data_processor.rank == 1:
             full, tail = data_processor.device_epoch(max(epoch, 0), self.batch_size)
             B = self.batch_size
+            if self.use_graph and getattr(model, 'kind', '') == 'DCCF' and full.shape[0] > 0:
+                # the whole step (5 kernels + dense optimizer) is one hipGraph replay per batch
+                sg = getattr(model, '_step_graph', None)
+                if sg is None or sg.nb != full.shape[0] or sg.rows != 2 * B:
+                    from dccf_amd.models import StepGraph
+                    sg = model._step_graph = StepGraph(model, model.optimizer, full.shape[0], 2 * B, self.dropout)
+                sg.load_epoch(full)
+                for _ in range(full.shape[0]):
+                    sg.step()
+                out = sg.out_dict()
+                if tail is not None:
+                    pred = sg.tail(tail)
+                    out = {'prediction': pred, 'check': [('prediction', pred)], 'loss': model._loss[0]}
+                model.eval()
+                return out
             y = torch.cat([torch.ones(B, device=full.device), torch.zeros(B, device=full.device)])
             batch = {'Y': y, 'rank': 1, 'train': True, 'dropout': self.dropout, utils.REAL_BATCH_SIZE: B}
             for k in range(full.shape[0]):

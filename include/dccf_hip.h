@@ -76,6 +76,11 @@ typedef struct {
   const uint8_t* keep;         /* [N*(S+1)*A, D]  dropout keep mask (1 = kept) or NULL = keep all                 */
   uint64_t seed;               /* fused mode: stream key                                                        */
   uint64_t step;               /* fused mode: call counter (one value per forward)                              */
+  /* Optional device-side step counter, so that one captured hipGraph can be replayed for every step of a run: with
+   * k = *k_dev the call uses X + (k % x_steps) * x_stride (int64 elements) and the stream counter step + k. */
+  const int64_t* k_dev;
+  int64_t x_stride;
+  int64_t x_steps;
 } dccf_rand_t;
 
 typedef struct {             /* dense-shaped gradients of the LOSS term, accumulated (+=) — zero them first     */
@@ -116,6 +121,13 @@ int dccf_dense_opt_step(int32_t kind, float* p, float* g, float* s1, float* s2, 
 int dccf_dense_opt_step_rows(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t n, float lr, float wd,
                              float l2, float clip, int64_t step, int32_t nseg, const int64_t* seg_begin,
                              const int64_t* seg_rows, const int32_t* seg_width, uint8_t* const* seg_flags, void* stream);
+/* Graph-replayable form of the two calls above: the 1-based step is step + *k_dev (bias corrections computed on the
+ * device); dccf_advance adds 1 to *k_dev (last node of a captured step). */
+int dccf_dense_opt_step_dev(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t n, float lr, float wd,
+                            float l2, float clip, int64_t step, const int64_t* k_dev, int32_t nseg,
+                            const int64_t* seg_begin, const int64_t* seg_rows, const int32_t* seg_width,
+                            uint8_t* const* seg_flags, void* stream);
+int dccf_advance(int64_t* k_dev, void* stream);
 /* BaseModel.l2 (src/models/BaseModel.py:179-187): out[0] += sum p^2  (out must be zeroed by the caller). */
 int dccf_sumsq(const float* p, int64_t n, float* out, void* stream);
 

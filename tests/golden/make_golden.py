@@ -407,7 +407,8 @@ def gen_metrics(outdir):
 
 
 # ----------------------------------------------------------------------------- G5: end to end
-E2E = dict(user_num=800, item_num=600, n_draws=16000, feat_dim=64, data_seed=11, epochs=4, seeds=[2019, 2020, 2021, 2022, 2023],
+E2E = dict(user_num=800, item_num=600, n_draws=16000, feat_dim=64, data_seed=11, epochs=4,
+           seeds=[int(x) for x in os.environ.get('E2E_SEEDS', '2019,2020,2021,2022,2023').split(',')],
            D=32, test_neg_n=100, lr=0.001, batch_size=128)
 
 
@@ -451,7 +452,7 @@ def gen_e2e(outdir):
             for h in logging.root.handlers[:]:
                 logging.root.removeHandler(h)
             shutil.rmtree(tmp)
-    np.savez_compressed(os.path.join(outdir, 'e2e.npz'), **rec)
+    np.savez_compressed(os.path.join(outdir, os.environ.get('E2E_OUT', 'e2e.npz')), **rec)
 
 
 if __name__ == '__main__':

@@ -455,3 +455,48 @@ def test_row_aware_optimizer_equals_dense(L, ctx):
         runs.append(buf[0].cpu().numpy())
     # float atomics may reorder the sums inside the backward between the two runs, the optimizer itself is identical
     close(runs[1], runs[0], 1e-6, 1e-8, 'row-aware vs dense optimizer')
+
+
+def test_graph_replayed_steps_equal_eager_steps(L):
+    """StepGraph (device-side step counter, one hipGraph replay per step, eager partial tail) must train exactly like the
+    eager step-by-step path: same batches, same Philox counters, same Adam step numbers."""
+    from dccf_amd.models import DCCF, FusedOptimizer, StepGraph
+    rng = np.random.RandomState(21)
+    U_, I_, D, F, B, nb = 400, 300, 64, 160, 16, 5
+    feat = T((rng.randn(I_, F) * 0.5).astype(np.float32))
+    expo = T(rng.randn(U_, I_).astype(np.float32))
+    full_np = np.zeros((2, nb, 2 * B, 2), dtype=np.int64)               # two epochs
+    for e in range(2):
+        for k in range(nb):
+            u = rng.randint(0, U_, B)
+            full_np[e, k] = np.concatenate([np.stack([u, rng.randint(0, I_, B)], 1), np.stack([u, rng.randint(0, I_, B)], 1)])
+    tail_np = full_np[0, 0, [0, 1, 2, B, B + 1, B + 2]]                     # a 3-pair partial batch
+    results = []
+    for use_graph in (False, True):
+        m = DCCF(path=None, dataset=None, sentence_model=None, sample_num=10, attribute_num=2, std=0.1, label_min=0,
+                 label_max=1, feature_num=0, user_num=U_, item_num=I_, u_vector_size=D, i_vector_size=D, n_layers=1,
+                 random_seed=2019, model_path='/tmp/x.pt', feature_embedding=feat, expo_prob=expo)
+        torch.manual_seed(1)
+        m.apply(m.init_paras)
+        opt = FusedOptimizer(m, 'adam', 1e-3, 1e-4)
+        m.optimizer = opt
+        m.train()
+        if use_graph:
+            sg = StepGraph(m, opt, nb, 2 * B, 0.2)
+            for e in range(2):
+                sg.load_epoch(T(full_np[e]))
+                for _ in range(nb):
+                    sg.step()
+                sg.tail(T(tail_np))
+        else:
+            y = torch.cat([torch.ones(B, device=dev()), torch.zeros(B, device=dev())])
+            for e in range(2):
+                for k in range(nb):
+                    m({'X': T(full_np[e, k]), 'Y': y, 'rank': 1, 'train': True, 'dropout': 0.2})
+                    opt.step()
+                m({'X': T(tail_np), 'Y': torch.cat([y[:3], y[B:B + 3]]), 'rank': 1, 'train': True, 'dropout': 0.2})
+                opt.step()
+        assert m._call == 2 * (nb + 1) and opt.t == 2 * (nb + 1)
+        results.append(m.flat_p.cpu().numpy().copy())
+    # float atomics reorder sums inside the backward; Adam turns that into <= a fraction of one step (see STEP_FRAC)
+    close(results[1], results[0], PARAM_RTOL, PARAM_ATOL + STEP_FRAC * 1e-3, 'graph vs eager parameters')
