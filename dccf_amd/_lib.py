@@ -87,8 +87,8 @@ def load():
         'dccf_debug_noise': [i64, i32, f32, u64, u64, vp, vp],
         'dccf_debug_keep': [i64, i32, f32, u64, u64, vp, vp],
         'dccf_debug_workspace': [vp, i64, i32, i32, i32, i32, i32, vp, C.POINTER(C.c_int64), vp],
-        'shard_pack_rows': [vp, i64, C.POINTER(vp), C.POINTER(i32), i32, vp, vp],
-        'shard_unpack_rows': [vp, i64, vp, C.POINTER(vp), C.POINTER(i32), i32, vp],
+        'shard_pack_rows': [vp, vp, i64, C.POINTER(vp), C.POINTER(i32), i32, vp, i32, vp],
+        'shard_unpack_rows': [vp, i32, i64, vp, C.POINTER(vp), C.POINTER(i32), i32, vp],
         'shard_scatter_add': [vp, i64, vp, i32, vp, vp],
     }
     for name, args in sig.items():
@@ -327,15 +327,17 @@ def _table_args(tables):
     return ptrs, widths, n
 
 
-def shard_pack_rows(idx, n, tables, out):
-    """out[j] = [T0[idx[j]] | T1[idx[j]] | ...] for j < n (idx int32 in HBM)."""
+def shard_pack_rows(idx, dst, n, tables, out):
+    """out[dst[j] or j, :w] = [T0[idx[j]] | T1[idx[j]] | ...] for j < n (idx, dst int32 in HBM; out rows may be wider)."""
     ptrs, widths, k = _table_args(tables)
-    check(load().shard_pack_rows(ptr(idx, torch.int32), int(n), ptrs, widths, k, ptr(out, torch.float32), stream()))
+    check(load().shard_pack_rows(ptr(idx, torch.int32), ptr(dst, torch.int32), int(n), ptrs, widths, k,
+                                 ptr(out, torch.float32), int(out.shape[1]), stream()))
 
 
 def shard_unpack_rows(payload, n, dst, tables):
     ptrs, widths, k = _table_args(tables)
-    check(load().shard_unpack_rows(ptr(payload, torch.float32), int(n), ptr(dst, torch.int32), ptrs, widths, k, stream()))
+    check(load().shard_unpack_rows(ptr(payload, torch.float32), int(payload.shape[1]), int(n), ptr(dst, torch.int32), ptrs,
+                                   widths, k, stream()))
 
 
 def shard_scatter_add(idx, n, rows, g):

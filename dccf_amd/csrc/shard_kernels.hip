@@ -12,30 +12,32 @@ struct TableSet {
   int total;
 };
 
-// out[j, :] = [T0[idx[j], :] | T1[idx[j], :] | ...]
-__global__ __launch_bounds__(256) void k_pack(const int* __restrict__ idx, int64_t n, TableSet ts, float* __restrict__ out) {
+// out[dst[j] (or j), 0:total] = [T0[idx[j], :] | T1[idx[j], :] | ...]; out rows are `ld` floats apart (ld >= total)
+__global__ __launch_bounds__(256) void k_pack(const int* __restrict__ idx, const int* __restrict__ dst, int64_t n, TableSet ts,
+                                              float* __restrict__ out, int ld) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t j = wave; j < n; j += nw) {
     const int64_t r = idx[j];
+    const int64_t o = dst ? dst[j] : j;
     int off = 0;
     for (int q = 0; q < ts.n; ++q) {
-      for (int c = lane; c < ts.w[q]; c += 64) out[j * ts.total + off + c] = ts.t[q][r * ts.w[q] + c];
+      for (int c = lane; c < ts.w[q]; c += 64) out[o * ld + off + c] = ts.t[q][r * ts.w[q] + c];
       off += ts.w[q];
     }
   }
 }
 
-// Tq[dst[j] (or j), :] = in[j, off_q : off_q + w_q]
+// Tq[dst[j] (or j), :] = in[j, off_q : off_q + w_q]; payload rows are `ld` floats apart
 __global__ __launch_bounds__(256) void k_unpack(const float* __restrict__ in, int64_t n, const int* __restrict__ dst,
-                                                TableSet ts) {
+                                                TableSet ts, int ld) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t j = wave; j < n; j += nw) {
     const int64_t r = dst ? dst[j] : j;
     int off = 0;
     for (int q = 0; q < ts.n; ++q) {
-      for (int c = lane; c < ts.w[q]; c += 64) ts.t[q][r * ts.w[q] + c] = in[j * ts.total + off + c];
+      for (int c = lane; c < ts.w[q]; c += 64) ts.t[q][r * ts.w[q] + c] = in[j * ld + off + c];
       off += ts.w[q];
     }
   }
@@ -65,26 +67,26 @@ static int make_set(TableSet& ts, float* const* tables, const int32_t* widths, i
   return 0;
 }
 
-extern "C" int shard_pack_rows(const int32_t* idx, int64_t n, const float* const* tables, const int32_t* widths,
-                               int32_t ntables, float* out, void* stream) {
+extern "C" int shard_pack_rows(const int32_t* idx, const int32_t* dst, int64_t n, const float* const* tables,
+                               const int32_t* widths, int32_t ntables, float* out, int32_t ld, void* stream) {
   TableSet ts;
   if (int e = make_set(ts, (float* const*)tables, widths, ntables)) return e;
-  ARG_CHECK(n >= 0 && (n == 0 || (idx && out)), "NULL idx / out");
+  ARG_CHECK(n >= 0 && (n == 0 || (idx && out)) && ld >= ts.total, "NULL idx / out or ld < row width");
   if (n == 0) return 0;
   const int grid = (int)min((int64_t)2048, (n + 3) / 4);
-  hipLaunchKernelGGL(k_pack, dim3(grid), dim3(256), 0, (hipStream_t)stream, idx, n, ts, out);
+  hipLaunchKernelGGL(k_pack, dim3(grid), dim3(256), 0, (hipStream_t)stream, idx, dst, n, ts, out, (int)ld);
   HIP_TRY(hipGetLastError());
   return 0;
 }
 
-extern "C" int shard_unpack_rows(const float* in, int64_t n, const int32_t* dst, float* const* tables,
+extern "C" int shard_unpack_rows(const float* in, int32_t ld, int64_t n, const int32_t* dst, float* const* tables,
                                  const int32_t* widths, int32_t ntables, void* stream) {
   TableSet ts;
   if (int e = make_set(ts, tables, widths, ntables)) return e;
-  ARG_CHECK(n >= 0 && (n == 0 || in), "NULL payload");
+  ARG_CHECK(n >= 0 && (n == 0 || in) && ld >= ts.total, "NULL payload or ld < row width");
   if (n == 0) return 0;
   const int grid = (int)min((int64_t)2048, (n + 3) / 4);
-  hipLaunchKernelGGL(k_unpack, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, n, dst, ts);
+  hipLaunchKernelGGL(k_unpack, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, n, dst, ts, (int)ld);
   HIP_TRY(hipGetLastError());
   return 0;
 }

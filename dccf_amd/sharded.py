@@ -9,10 +9,11 @@ index = row div G; the frozen per-item tables (768-d features, IPS factors that 
 a dense U x I matrix is impossible at 10M x 1M) live with the item shard, the per-user ones with the user shard.  The
 dense ``W, b`` are replicated.  Optimizer state lives with the shard, so the dense regularised Adam pass is local.
 
-Exchange per step — the path's only real exchange steps, 6 collectives:
-  * all-to-all x3 (rows): the user / candidate-item / true-item-feature rows this rank's pairs touch;
-  * all-to-all x2 (gradient rows): per-slot gradient rows back to their owners, summed there with float atomics;
-  * all-reduce x1 of the contiguous ``[dW | db]`` slice of the flat gradient buffer (213 KB at D=64: latency-bound).
+Exchange per step — the path's only real exchange steps, 4 collectives:
+  * all-to-all (rows): the user and candidate-item rows this rank's pairs touch, as ONE payload (both kinds are
+    ``[embedding | IPS factor | bias | propensity]`` rows), and a second all-to-all for the 768-d true-item feature rows;
+  * all-to-all (gradient rows): per-slot gradient rows back to their owners, summed there with float atomics;
+  * all-reduce of the contiguous ``[dW | db]`` slice of the flat gradient buffer (213 KB at D=64: latency-bound).
 There is NO id exchange: the train set is replicated (16 B per interaction), negatives and the shuffle are
 deterministic functions of (seed, epoch), candidates are a counter-based Philox stream of (seed, epoch, global row) —
 so every rank computes every rank's batches and knows which of its rows each peer needs, in a canonical slot order.
@@ -36,8 +37,8 @@ class HipBackend(object):
     def candidates(self, n_rows, S, item_num, seed, step):
         return self.L.debug_candidates(n_rows, S, item_num, seed, step, self.device)
 
-    def pack_rows(self, idx, n, tables, out):
-        self.L.shard_pack_rows(idx, n, tables, out)
+    def pack_rows(self, idx, dst, n, tables, out):
+        self.L.shard_pack_rows(idx, dst, n, tables, out)
 
     def unpack_rows(self, payload, n, dst, tables):
         self.L.shard_unpack_rows(payload, n, dst, tables)
@@ -54,23 +55,39 @@ class HipBackend(object):
         self.L.dense_opt_step('adam', p, g, s1, s2, lr, l2, l2, 50.0, t, zero_grad=True)
 
 
-class _Route(object):
-    """Routing of one kind of slot (users / candidate items / true-item features) for every step of an epoch."""
+def _first_n(mask, values, nmax):
+    """Per row of `mask` [nb, M]: the `values` of the True entries in order, left-aligned and padded to nmax."""
+    order = torch.argsort((~mask).to(torch.int8), dim=1, stable=True)[:, :nmax]
+    return [torch.gather(v, 1, order).to(torch.int32).contiguous() for v in values]
 
-    def __init__(self, ids, me, G):
+
+class _Route(object):
+    """Routing of one payload kind for every step of an epoch.  A kind is a list of T slots per rank whose first
+    `n_a` slots index table A (users) and the rest table B (items) — or a single table when n_a == T."""
+
+    def __init__(self, ids, n_a, row_off_b, me, G):
         nb, _, T = ids.shape                                   # ids: int64 [nb, G, T], identical on every rank
-        owner = ids % G
-        mine = (owner == me).reshape(nb, G * T)                # slots of rank q (row-major q, t) whose rows I own
-        order = torch.argsort((~mine).to(torch.int8), dim=1, stable=True)
-        counts = (owner == me).sum(2)                          # [nb, G] rows I send to q
-        self.send_max = max(1, int(counts.sum(1).max()))
-        self.send_idx = torch.gather((ids // G).reshape(nb, G * T), 1, order)[:, :self.send_max].to(torch.int32).contiguous()
-        self.send_splits = counts.tolist()
-        self.send_n = counts.sum(1).tolist()
+        dev = ids.device
+        owner, lidx = ids % G, ids // G
+        is_a = (torch.arange(T, device=dev) < n_a).expand(nb, G, T)
+        mine = owner == me                                     # slots of rank q (row-major q, t) whose rows I own
+        mf = mine.reshape(nb, G * T)
+        pos = (torch.cumsum(mf, 1) - 1)                        # position of a sent row in my send buffer: (q, t) order
+        lf, af = lidx.reshape(nb, G * T), is_a.reshape(nb, G * T)
+        counts = mine.sum(2)                                   # [nb, G] rows I send to q
+        self.send_splits, self.send_n = counts.tolist(), counts.sum(1).tolist()
+        self.send_max = max(1, max(self.send_n))
+        na, nbb = (mf & af).sum(1), (mf & ~af).sum(1)
+        self.na, self.nb_ = na.tolist(), nbb.tolist()
+        self.a_src, self.a_dst = _first_n(mf & af, [lf, pos], max(1, int(na.max())))
+        self.b_src, self.b_dst = _first_n(mf & ~af, [lf, pos], max(1, int(nbb.max())))
+        # where a returned gradient row (send order) lands in the flat gradient buffer viewed as rows of width D
+        (self.g_row,) = _first_n(mf, [torch.where(af, lf, lf + row_off_b)], self.send_max)
         my_owner = owner[:, me, :]                             # [nb, T]
         perm = torch.argsort(my_owner, dim=1, stable=True)     # receive position j holds my slot perm[j]
+        self.perm = perm
         self.inv = torch.empty_like(perm)
-        self.inv.scatter_(1, perm, torch.arange(T, device=ids.device).expand(nb, T))    # slot t sits at inv[t]
+        self.inv.scatter_(1, perm, torch.arange(T, device=dev).expand(nb, T))    # slot t sits at inv[t]
         self.recv_splits = torch.stack([(my_owner == o).sum(1) for o in range(G)], 1).tolist()
         self.T = T
 
@@ -89,8 +106,8 @@ class ShardedDCCF(object):
         self.nI = (item_num + world - 1 - rank) // world if item_num > rank else 0
         self.feat, self.ips = feat_local.contiguous(), ips_local
         sizes = [self.nU * D, self.nI * D, D * (D + self.F), D]
-        pads = [(n + 3) // 4 * 4 for n in sizes]
-        assert pads[2] == sizes[2], 'W must end on a 4-float boundary so that [dW | db] is one contiguous slice'
+        pads = [(n + 255) // 256 * 256 for n in sizes[:2]] + [sizes[2], (D + 3) // 4 * 4]   # tables start on 256-float bounds
+        assert sizes[2] % 4 == 0 and 256 % D == 0
         f32 = torch.float32
         self.flat_p = torch.zeros(sum(pads), dtype=f32, device=device)
         self.flat_g = torch.zeros_like(self.flat_p)
@@ -103,7 +120,10 @@ class ShardedDCCF(object):
             o += pd
         self.U, self.V, self.W, self.b = views
         self.gU, self.gV, self.gW, self.gb = gviews
+        self.g_rows = self.flat_g[:pads[0] + pads[1]].view(-1, D)          # [dU ; dV] shards as rows of width D
+        self.row_off_v = pads[0] // D
         self.g_dense = self.flat_g[pads[0] + pads[1]:pads[0] + pads[1] + sizes[2] + D]      # [dW | db], contiguous
+        self.user_pad = torch.ones((max(self.nU, 1), 1), dtype=f32, device=device)           # the "prop" column of user rows
         self.t = 0
         self.plan = None
 
@@ -133,68 +153,58 @@ class ShardedDCCF(object):
         cand = self.be.candidates(nb * G * N, S, self.item_num, self.seed, epoch).view(nb, G, N, S)
         users = X_sched[:, :, :B, 0]                                                   # rows k and B+k share the user
         items = torch.cat([X_sched[:, :, :, 1:2], cand], 3).reshape(nb, G, N * S1)       # candidate slots (n, s)
-        feats = X_sched[:, :, :, 1]                                                    # true items
+        feats = X_sched[:, :, :, 1].contiguous()                                       # true items
         me = self.rank
-        ru, ri, rf = _Route(users, me, G), _Route(items, me, G), _Route(feats, me, G)
+        re = _Route(torch.cat([users, items], 2), B, self.row_off_v, me, G)            # embedding-side slots: users | items
+        rf = _Route(feats, N, 0, me, G)
+        T = B + N * S1
         ar = torch.arange(N, device=dev)
-        inv_i = ri.inv.view(nb, N, S1)
-        Xc = torch.stack([ru.inv[:, ar % B], inv_i[:, :, 0]], 2).contiguous()          # compact ids = receive positions
+        inv_u, inv_i = re.inv[:, :B], re.inv[:, B:].reshape(nb, N, S1)
+        Xc = torch.stack([inv_u[:, ar % B], inv_i[:, :, 0]], 2).contiguous()           # compact ids = receive positions
         cand_c = inv_i[:, :, 1:].contiguous()
-        # the received feature row j belongs to true-item slot n = perm_f[j]; it must sit at the compact ITEM id of (n, 0)
-        perm_f = torch.argsort(rf.inv, dim=1)
-        feat_dst = torch.gather(inv_i[:, :, 0], 1, perm_f).to(torch.int32).contiguous()
+        # the received feature row j belongs to true-item slot n = perm_f[j]; it must sit at the compact id of item (n, 0)
+        feat_dst = torch.gather(inv_i[:, :, 0], 1, rf.perm).to(torch.int32).contiguous()
         f32 = torch.float32
-        wu, wi = D + Dq + 1, D + Dq + 2
+        we = D + Dq + 2                                                               # [emb | IPS factor | bias | prop]
+        e = lambda *shape: torch.empty(shape, dtype=f32, device=dev)
         self.plan = dict(
-            nb=nb, N=N, B=B, ru=ru, ri=ri, rf=rf, Xc=Xc, cand_c=cand_c, feat_dst=feat_dst,
-            send_u=torch.empty((ru.send_max, wu), dtype=f32, device=dev), recv_u=torch.empty((B, wu), dtype=f32, device=dev),
-            send_i=torch.empty((ri.send_max, wi), dtype=f32, device=dev), recv_i=torch.empty((N * S1, wi), dtype=f32, device=dev),
-            send_f=torch.empty((rf.send_max, self.F), dtype=f32, device=dev), recv_f=torch.empty((N, self.F), dtype=f32, device=dev),
-            Uc=torch.empty((B, D), dtype=f32, device=dev), Pc=torch.empty((B, Dq), dtype=f32, device=dev),
-            buc=torch.empty((B, 1), dtype=f32, device=dev),
-            Vc=torch.empty((N * S1, D), dtype=f32, device=dev), Qc=torch.empty((N * S1, Dq), dtype=f32, device=dev),
-            bic=torch.empty((N * S1, 1), dtype=f32, device=dev), propc=torch.ones((N * S1, 1), dtype=f32, device=dev),
-            featc=torch.zeros((N * S1, self.F), dtype=f32, device=dev),
-            gc=torch.zeros((B + N * S1, D), dtype=f32, device=dev),                    # [gUc ; gVc], zeroed by one memset
-            gback_u=torch.empty((ru.send_max, D), dtype=f32, device=dev),
-            gback_i=torch.empty((ri.send_max, D), dtype=f32, device=dev),
+            nb=nb, N=N, B=B, T=T, re=re, rf=rf, Xc=Xc, cand_c=cand_c, feat_dst=feat_dst,
+            send_e=e(re.send_max, we), recv_e=e(T, we), send_f=e(rf.send_max, self.F), recv_f=e(N, self.F),
+            E=e(T, D), PQ=e(T, Dq), bb=e(T, 1), prop=e(T, 1), featc=torch.zeros((T, self.F), dtype=f32, device=dev),
+            gc=torch.zeros((T, D), dtype=f32, device=dev), gback=e(re.send_max, D),
             Y=torch.cat([torch.ones(B, device=dev), torch.zeros(B, device=dev)]))
-        self.ips_tables_u = [self.U, self.ips['P'], self.ips['bu'].view(-1, 1)]
-        self.ips_tables_i = [self.V, self.ips['Q'], self.ips['bi'].view(-1, 1), self.ips['prop'].view(-1, 1)]
+        self.tables_u = [self.U, self.ips['P'], self.ips['bu'].view(-1, 1), self.user_pad]
+        self.tables_i = [self.V, self.ips['Q'], self.ips['bi'].view(-1, 1), self.ips['prop'].view(-1, 1)]
 
     # ------------------------------------------------------------------------------------------------ one step
     def _a2a(self, out, inp, out_splits, in_splits):
         dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)
 
     def train_step(self, k):
-        """Step k of the epoch prepared by begin_epoch.  Returns (prediction [2B], loss [1]) of THIS rank's pairs."""
+        """Step k of the epoch prepared by begin_epoch.  Returns (prediction [2B], loss [1]) of THIS rank's pairs.
+        4 collectives: rows (users + candidate items in one payload), feature rows, gradient rows, [dW | db]."""
         p, be = self.plan, self.be
-        ru, ri, rf = p['ru'], p['ri'], p['rf']
-        B, N, S1 = p['B'], p['N'], self.S + 1
-        nu, ni, nf = ru.send_n[k], ri.send_n[k], rf.send_n[k]
-        # rows out
-        be.pack_rows(ru.send_idx[k], nu, self.ips_tables_u, p['send_u'])
-        be.pack_rows(ri.send_idx[k], ni, self.ips_tables_i, p['send_i'])
-        be.pack_rows(rf.send_idx[k], nf, [self.feat], p['send_f'])
-        self._a2a(p['recv_u'], p['send_u'][:nu], ru.recv_splits[k], ru.send_splits[k])
-        self._a2a(p['recv_i'], p['send_i'][:ni], ri.recv_splits[k], ri.send_splits[k])
+        re, rf = p['re'], p['rf']
+        N, T = p['N'], p['T']
+        ne, nf = re.send_n[k], rf.send_n[k]
+        # rows out: users and items share one payload (both are [embedding | IPS factor | bias | prop] rows)
+        be.pack_rows(re.a_src[k], re.a_dst[k], re.na[k], self.tables_u, p['send_e'])
+        be.pack_rows(re.b_src[k], re.b_dst[k], re.nb_[k], self.tables_i, p['send_e'])
+        be.pack_rows(rf.a_src[k], rf.a_dst[k], nf, [self.feat], p['send_f'])
+        self._a2a(p['recv_e'], p['send_e'][:ne], re.recv_splits[k], re.send_splits[k])
         self._a2a(p['recv_f'], p['send_f'][:nf], rf.recv_splits[k], rf.send_splits[k])
-        # compact tables in receive order
-        be.unpack_rows(p['recv_u'], B, None, [p['Uc'], p['Pc'], p['buc']])
-        be.unpack_rows(p['recv_i'], N * S1, None, [p['Vc'], p['Qc'], p['bic'], p['propc']])
+        # compact tables in receive order: ONE table serves users and items (compact id = receive position)
+        be.unpack_rows(p['recv_e'], T, None, [p['E'], p['PQ'], p['bb'], p['prop']])
         be.unpack_rows(p['recv_f'], N, p['feat_dst'][k], [p['featc']])
-        ipsc = dict(P=p['Pc'], bu=p['buc'].view(-1), Q=p['Qc'], bi=p['bic'].view(-1), prop=p['propc'].view(-1),
+        ipsc = dict(P=p['PQ'], bu=p['bb'].view(-1), Q=p['PQ'], bi=p['bb'].view(-1), prop=p['prop'].view(-1),
                     b0=self.ips['b0'], M=self.ips['M'])
         p['gc'].zero_()
-        gUc, gVc = p['gc'][:B], p['gc'][B:]
-        pred, loss = be.local_step(p['Uc'], p['Vc'], self.W, self.b, p['featc'], ipsc, p['Xc'][k], p['cand_c'][k], p['Y'],
+        pred, loss = be.local_step(p['E'], p['E'], self.W, self.b, p['featc'], ipsc, p['Xc'][k], p['cand_c'][k], p['Y'],
                                    self.S, self.A, self.std, self.dropout, self.seed, self.t * self.G + self.rank,
-                                   gUc, gVc, self.gW, self.gb)
+                                   p['gc'], p['gc'], self.gW, self.gb)
         # gradient rows back (compact order == receive order: nothing to permute), summed at the owner
-        self._a2a(p['gback_u'][:nu], gUc, ru.send_splits[k], ru.recv_splits[k])
-        self._a2a(p['gback_i'][:ni], gVc, ri.send_splits[k], ri.recv_splits[k])
-        be.scatter_add(ru.send_idx[k], nu, p['gback_u'], self.gU)
-        be.scatter_add(ri.send_idx[k], ni, p['gback_i'], self.gV)
+        self._a2a(p['gback'][:ne], p['gc'], re.send_splits[k], re.recv_splits[k])
+        be.scatter_add(re.g_row[k], ne, p['gback'], self.g_rows)
         dist.all_reduce(self.g_dense, group=self.group)
         self.t += 1
         be.opt_step(self.flat_p, self.flat_g, self.s1, self.s2, self.lr, self.l2, self.t)
@@ -254,7 +264,7 @@ def bench_main(args, rank, world, dev):
                                       'user_num=%d item_num=%d D=%d F=%d S=%d A=%d, rows sharded mod %d, exposure from IPS '
                                       'factors, fused on-device negatives' % (U, I, D, F, S, A, world),
                           'batch_size_per_gpu': B, 'global_batch': B * world, 'optimizer': 'Adam lr=1e-3 l2=1e-4 dropout=0.2',
-                          'collectives_per_step': 'all_to_all x5 (rows, grad rows) + all_reduce([dW|db])'},
+                          'collectives_per_step': 'all_to_all x3 (rows, feature rows, grad rows) + all_reduce([dW|db])'},
                'roofline': None, 'cpu_baseline': None}
         print(json.dumps(out), flush=True)
     dist.destroy_process_group()

@@ -164,12 +164,13 @@ int dccf_sample_train_negatives(const int64_t* rows_indptr, const int64_t* rows,
 
 /* ---- row movers of the row-sharded multi-GPU path (dccf_amd/sharded.py; no reference counterpart — the reference is
  * single-GPU, src/main.py:106,153-155).  `tables` / `widths` are HOST arrays of up to 4 device pointers / row widths. */
-/* out[j, :] = [T0[idx[j], :] | T1[idx[j], :] | ...]  — the rows a peer needs, as one all-to-all payload */
-int shard_pack_rows(const int32_t* idx, int64_t n, const float* const* tables, const int32_t* widths, int32_t ntables,
-                    float* out, void* stream);
+/* out[dst[j] (j when dst is NULL), 0:sum(widths)] = [T0[idx[j], :] | T1[idx[j], :] | ...]; payload rows are ld floats
+ * apart — the rows a peer needs, as one all-to-all payload */
+int shard_pack_rows(const int32_t* idx, const int32_t* dst, int64_t n, const float* const* tables, const int32_t* widths,
+                    int32_t ntables, float* out, int32_t ld, void* stream);
 /* Tq[dst[j] (j when dst is NULL), :] = in[j, off_q : off_q + w_q]  — a received payload into the compact tables */
-int shard_unpack_rows(const float* in, int64_t n, const int32_t* dst, float* const* tables, const int32_t* widths,
-                      int32_t ntables, void* stream);
+int shard_unpack_rows(const float* in, int32_t ld, int64_t n, const int32_t* dst, float* const* tables,
+                      const int32_t* widths, int32_t ntables, void* stream);
 /* g[idx[j], :] += rows[j, :]  — received gradient rows into the owner's gradient shard (float atomics) */
 int shard_scatter_add(const int32_t* idx, int64_t n, const float* rows, int32_t width, float* g, void* stream);
 

@@ -28,9 +28,10 @@ class OracleBackend(object):
     def candidates(self, n_rows, S, item_num, seed, step):
         return torch.from_numpy(PH.candidates(seed, step, n_rows, S, item_num))
 
-    def pack_rows(self, idx, n, tables, out):
+    def pack_rows(self, idx, dst, n, tables, out):
         if n:
-            out[:n] = torch.cat([t[idx[:n].long()].view(n, -1) for t in tables], 1)
+            rows = torch.cat([t[idx[:n].long()].view(n, -1) for t in tables], 1)
+            out[(torch.arange(n) if dst is None else dst[:n].long()), :rows.shape[1]] = rows
 
     def unpack_rows(self, payload, n, dst, tables):
         rows = torch.arange(n) if dst is None else dst[:n].long()
