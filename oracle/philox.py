@@ -15,7 +15,7 @@ therefore established with *injected* draws (tests/golden); this module pins the
     STREAM_CAND   c0 = batch row n, c1 = g        -> 4 candidates s = 4g..4g+3, item = mulhi(u32, item_num)
     STREAM_NOISE  c0 = flat row l,  c1 = 32*(f//128) + f%32 -> the 4 normals of f%128//32 = 0..3 (Box-Muller on
                   (x0,x1) -> o=0 (cos), o=1 (sin); (x2,x3) -> o=2, o=3), multiplied by std
-    STREAM_DROP   c0 = flat row l,  c1 = d//4     -> element d%4 is dropped iff u32 < floor(p * 2^32)
+    STREAM_DROP   c0 = l//4, c1 = d             -> row l%4 of the group, column d, is dropped iff u32 < floor(p * 2^32)
     STREAM_NEG    c0 = uid, c1 = draw//4, c2 = epoch -> draw%4-th u32, item = mulhi(u32, item_num)
 """
 import numpy as np
@@ -97,11 +97,11 @@ def dropout_keep(seed, step, L, D, p):
     if p <= 0.0:
         return np.ones((L, D), dtype=np.uint8)
     k0, k1 = _key(seed, STREAM_DROP)
-    G = (D + 3) // 4
-    l = np.arange(L)[:, None]
-    g = np.arange(G)[None, :]
-    xs = philox4x32(l, g, step & 0xFFFFFFFF, (step >> 32) & 0xFFFFFFFF, k0, k1)
-    x = np.stack(xs, axis=2).reshape(L, G * 4)[:, :D]
+    G = (L + 3) // 4
+    g = np.arange(G)[:, None]
+    d = np.arange(D)[None, :]
+    xs = philox4x32(g, d, step & 0xFFFFFFFF, (step >> 32) & 0xFFFFFFFF, k0, k1)      # 4 x [G, D]: word w = row 4g+w
+    x = np.stack(xs, axis=1).reshape(G * 4, D)[:L]
     return (x >= np.uint32(drop_threshold(p))).astype(np.uint8)
 
 

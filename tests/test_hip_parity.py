@@ -500,3 +500,32 @@ def test_graph_replayed_steps_equal_eager_steps(L):
         results.append(m.flat_p.cpu().numpy().copy())
     # float atomics reorder sums inside the backward; Adam turns that into <= a fraction of one step (see STEP_FRAC)
     close(results[1], results[0], PARAM_RTOL, PARAM_ATOL + STEP_FRAC * 1e-3, 'graph vs eager parameters')
+
+
+def test_large_batch_forward_kernel_matches_small_batch_kernel(L, ctx):
+    """Eval-size batches take the rows-per-wave forward kernel (k_fwd_rows); it must agree with the K-split kernel that
+    small batches take, on the same injected draws — and its fused draws must equal its injected draws bit for bit."""
+    rng = np.random.RandomState(31)
+    U_, I_, D, F, S, A, N = 900, 700, 64, 768, 10, 2, 3072          # L = 67,584 rows -> 2,112 tiles (>= 2048)
+    Pm = [T((rng.randn(U_, D) * 0.3).astype(np.float32)), T((rng.randn(I_, D) * 0.3).astype(np.float32)),
+          T((rng.randn(D, D + F) * 0.05).astype(np.float32)), T((rng.randn(D) * 0.1).astype(np.float32))]
+    feat = T((rng.randn(I_, F) * 0.5).astype(np.float32))
+    expo = T(rng.randn(U_, I_).astype(np.float32))
+    m = L.model_struct(Pm[0], Pm[1], Pm[2], Pm[3], feat, expo, S, A, 0.1)
+    X = T(np.stack([rng.randint(0, U_, N), rng.randint(0, I_, N)], 1).astype(np.int64))
+    seed, step, p = 99, 4, 0.2
+    Ld = N * (S + 1) * A
+    si = L.debug_candidates(N, S, I_, seed, step, dev())
+    nz = L.debug_noise(Ld, F, 0.1, seed, step, dev())
+    kp = L.debug_keep(Ld, D, p, seed, step, dev())
+    big_fused = L.dccf_predict(ctx, m, L.rand_struct(seed=seed, step=step), X, p).clone()
+    big_inj = L.dccf_predict(ctx, m, L.rand_struct(sample_item=si, noise=nz, keep=kp), X, p).clone()
+    assert torch.equal(big_fused, big_inj)
+    rows = (S + 1) * A
+    parts = []
+    for n0 in range(0, N, 768):                                       # 768 rows -> 528 tiles: the K-split kernel
+        n1 = n0 + 768
+        r = L.rand_struct(sample_item=si[n0:n1].contiguous(), noise=nz[n0 * rows:n1 * rows].contiguous(),
+                          keep=kp[n0 * rows:n1 * rows].contiguous())
+        parts.append(L.dccf_predict(ctx, m, r, X[n0:n1].contiguous(), p).clone())
+    close(big_inj, torch.cat(parts).cpu().numpy(), FWD_RTOL, FWD_ATOL, 'rows-per-wave vs K-split forward')
