@@ -14,7 +14,7 @@ EXPORTS = ['dccf_ctx_create', 'dccf_ctx_destroy', 'dccf_ctx_reserve', 'dccf_last
            'dccf_predict', 'dccf_train_fwdbwd', 'dccf_dense_opt_step', 'dccf_sumsq', 'mf_predict', 'mf_train_fwdbwd',
            'mf_predict_full', 'dccf_sample_train_negatives', 'dccf_debug_candidates', 'dccf_debug_noise',
            'dccf_debug_keep', 'dccf_debug_workspace', 'dccf_profile', 'dccf_profile_read',
-           'shard_pack_rows', 'shard_unpack_rows', 'shard_scatter_add', 'dccf_dense_opt_step_rows', 'dccf_dense_opt_step_dev', 'dccf_advance']
+           'shard_pack_rows', 'shard_unpack_rows', 'shard_scatter_add', 'dccf_dense_opt_step_rows', 'dccf_dense_opt_step_dev', 'dccf_advance', 'rank_eval_topk']
 
 OPT_KIND = {'gd': 0, 'adagrad': 1, 'adam': 2}
 MF_KIND = {'RecModel': 0, 'BiasedMF': 1, 'IPSBiasedMF': 2}
@@ -78,6 +78,7 @@ def load():
         'dccf_dense_opt_step_dev': [i32, vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, vp, i32, C.POINTER(i64), C.POINTER(i64),
                                     C.POINTER(i32), C.POINTER(vp), vp],
         'dccf_advance': [vp, vp],
+        'rank_eval_topk': [vp, vp, vp, vp, i64, C.POINTER(i32), vp, i32, vp, vp],
         'dccf_sumsq': [vp, i64, vp, vp],
         'mf_predict': [C.POINTER(MFModelT), vp, i64, vp, vp],
         'mf_train_fwdbwd': [vp, C.POINTER(MFModelT), vp, vp, i64, i32, C.POINTER(MFGradsT), vp, vp, vp],
@@ -343,3 +344,15 @@ def shard_unpack_rows(payload, n, dst, tables):
 def shard_scatter_add(idx, n, rows, g):
     check(load().shard_scatter_add(ptr(idx, torch.int32), int(n), ptr(rows, torch.float32), int(g.shape[1]),
                                    ptr(g, torch.float32), stream()))
+
+
+def rank_eval_topk(pred, label, indptr, rows, ks):
+    """Per-user (ndcg, hit, precision, recall)@k for up to 4 cut-offs k <= 16 -> tensor [n_users, len(ks)+1, 4]."""
+    nu = indptr.numel() - 1
+    nk = len(ks)
+    ks_host = (C.c_int32 * nk)(*[int(k) for k in ks])
+    ks_dev = torch.tensor([int(k) for k in ks], dtype=torch.int32, device=pred.device)
+    out = torch.zeros((nu, nk + 1, 4), dtype=torch.float32, device=pred.device)
+    check(load().rank_eval_topk(ptr(pred, torch.float32), ptr(label, torch.float32), ptr(indptr, torch.int64),
+                                ptr(rows, torch.int64), nu, ks_host, ptr(ks_dev, torch.int32), nk, ptr(out), stream()))
+    return out

@@ -40,6 +40,7 @@ class DataProcessor(object):
             for uid, items in data_loader.vt_user_his.items():
                 self.vt_history_dict[uid] = set(items)
         self.vt_batches_buffer = {}
+        self._dev_eval = {}
         self._dev = None
 
     # ------------------------------------------------------------------ data dicts
@@ -193,6 +194,19 @@ class DataProcessor(object):
             self.vt_batches_buffer[key] = batches
         return batches
 
+    # ------------------------------------------------------------------ device-resident eval split
+    def device_eval_set(self, data):
+        """The eval split as device tensors + the per-user CSR the ranking kernel walks (DeviceEvalSet).  Validation and
+        test sets are fixed for a run (:73-111) and cached; the train dict is reshuffled in place every epoch, so it is
+        rebuilt (only rmse/mae are evaluated on it, BaseRunner.py:226,256 — no CSR needed)."""
+        key = 'validation' if data is self.validation_data else 'test' if data is self.test_data else None
+        if key is not None and key in self._dev_eval:
+            return self._dev_eval[key]
+        es = DeviceEvalSet(data, with_groups=key is not None or self.rank == 1)
+        if key is not None:
+            self._dev_eval[key] = es
+        return es
+
     # ------------------------------------------------------------------ device-resident epoch (fused negatives)
     def device_epoch(self, epoch, batch_size):
         """The epoch's batches as device tensors: (full [nb, 2B, 2] int64, tail [2r, 2] or None).  See DeviceTrainSet."""
@@ -203,6 +217,34 @@ class DataProcessor(object):
             self._dev = DeviceTrainSet(tr['uid'].values, tr['iid'].values, dl.user_num, dl.item_num, self.seed,
                                        hist_uid=pos['uid'].values, hist_iid=pos['iid'].values)
         return self._dev.epoch_batches(epoch, batch_size)
+
+
+class DeviceEvalSet(object):
+    """One eval split resident in HBM: X [n, 2] int64, Y [n] fp32 in sample-id order, and the CSR (indptr, rows) of each
+    user's rows, in row order, that rank_eval_topk walks instead of DataFrame.sort_values + groupby('uid')
+    (src/models/BaseModel.py:83-88)."""
+
+    def __init__(self, data, with_groups=True):
+        dev = utils.device()
+        self.n = len(data['Y'])
+        self.X = torch.as_tensor(np.ascontiguousarray(data['X']), dtype=torch.int64).to(dev)
+        self.Y = torch.as_tensor(np.asarray(data['Y'], dtype=np.float32)).to(dev)
+        self.n_groups, self.min_group = 0, 0
+        if with_groups:
+            uid = np.asarray(data['uid'], dtype=np.int64)
+            order = np.argsort(uid, kind='stable')
+            su = uid[order]
+            starts = np.flatnonzero(np.r_[True, su[1:] != su[:-1]]) if len(su) else np.zeros(0, np.int64)
+            indptr = np.r_[starts, len(su)].astype(np.int64)
+            self.n_groups = len(starts)
+            self.min_group = int(np.diff(indptr).min()) if self.n_groups else 0
+            self.indptr = torch.as_tensor(indptr).to(dev)
+            self.rows = torch.as_tensor(order.astype(np.int64)).to(dev)
+
+    def batches(self, batch_size, dropout):
+        for b0 in range(0, self.n, batch_size):
+            yield {'train': False, 'rank': 1, 'dropout': dropout, 'X': self.X[b0:b0 + batch_size],
+                   'Y': self.Y[b0:b0 + batch_size]}
 
 
 class DeviceTrainSet(object):

@@ -115,7 +115,7 @@ def main(argv=None):
     runner = runner_cls(optimizer=args.optimizer, learning_rate=args.lr, epoch=args.epoch, batch_size=args.batch_size,
                         eval_batch_size=args.eval_batch_size, dropout=args.dropout, l2=args.l2, metrics=args.metric,
                         check_epoch=args.check_epoch, early_stop=args.early_stop, fused_sampling=args.fused_sampling,
-                        use_graph=args.use_graph)
+                        use_graph=args.use_graph, device_eval=args.device_eval)
     logging.info('Test Before Training = ' + utils.format_metric(
         runner.evaluate(model, data_processor.get_test_data(), data_processor)) + ' ' + ','.join(runner.metrics))
     if args.load > 0:
@@ -126,6 +126,7 @@ def main(argv=None):
         runner.evaluate(model, data_processor.get_test_data(), data_processor, write_rank=True)) + ' ' + ','.join(runner.metrics))
     np.save(args.result_file, runner.predict(model, data_processor.get_test_data(), data_processor))
     logging.info('Save Test Results to ' + args.result_file)
+    runner.model, runner.data_processor = model, data_processor      # for callers that keep working with the trained model
     return runner
 
 

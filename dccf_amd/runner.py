@@ -10,7 +10,7 @@ import numpy as np
 import pandas as pd
 import torch
 
-from dccf_amd import utils
+from dccf_amd import utils, _lib
 from dccf_amd.models import FusedOptimizer
 
 
@@ -32,18 +32,22 @@ class BaseRunner(object):
         parser.add_argument('--skip_eval', type=int, default=0, help='number of epochs without evaluation')
         parser.add_argument('--fused_sampling', type=int, default=1,
                             help='1: train negatives and batches stay on the GPU (Philox); 0: the reference host path')
+        parser.add_argument('--device_eval', type=int, default=1,
+                            help='1: predictions, top-k selection and ndcg/hit/precision/recall/f1@k (k <= 16) stay on the '
+                                 'GPU; 0: the reference host path (pandas-free numpy restatement)')
         parser.add_argument('--use_graph', type=int, default=0,
                             help='1: replay each DCCF training step as one hipGraph (needs --fused_sampling 1); measured '
                                  'slower than eager launches at batch 128 on MI355X (graph-launch floor), hence off')
         return parser
 
     def __init__(self, optimizer='GD', learning_rate=0.01, epoch=100, batch_size=128, eval_batch_size=128 * 128,
-                 dropout=0.2, l2=1e-5, metrics='RMSE', check_epoch=10, early_stop=1, fused_sampling=1, use_graph=0):
+                 dropout=0.2, l2=1e-5, metrics='RMSE', check_epoch=10, early_stop=1, fused_sampling=1, use_graph=0, device_eval=1):
         self.optimizer_name, self.learning_rate, self.epoch = optimizer, learning_rate, epoch
         self.batch_size, self.eval_batch_size = batch_size, eval_batch_size
         self.dropout, self.no_dropout, self.l2_weight = dropout, 0.0, l2
         self.metrics = metrics.lower().split(',')
         self.check_epoch, self.early_stop, self.fused_sampling, self.use_graph = check_epoch, early_stop, fused_sampling, use_graph
+        self.device_eval = device_eval
         self.time = None
         self.train_results, self.valid_results, self.test_results = [], [], []
 
@@ -195,10 +199,55 @@ class BaseRunner(object):
                                 self.time[1] - self.time[0]) + ','.join(self.metrics))
             model.load_model()
 
+    @staticmethod
+    def _device_metrics_ok(metrics):
+        ks = set()
+        for m in metrics:
+            if m in ('rmse', 'mae'):
+                continue
+            name, _, k = m.partition('@')
+            if name not in ('ndcg', 'hit', 'precision', 'recall', 'f1') or not k.isdigit() or not 1 <= int(k) <= 16:
+                return False
+            ks.add(int(k))
+        return len(ks) <= 4
+
+    def evaluate_device(self, model, data, data_processor, metrics):
+        """evaluate() without leaving the GPU: batched predict straight from the resident split, then one wave per user
+        selects the top-k and scores it (rank_eval_topk) — replaces BaseRunner.py:134-157 + BaseModel.py:55-128."""
+        es = data_processor.device_eval_set(data)
+        model.eval()
+        preds = [model.predict(b)['prediction'] for b in es.batches(self.eval_batch_size, self.no_dropout)]
+        p = torch.cat(preds) if preds else torch.zeros(0, dtype=torch.float32, device=es.Y.device)
+        ks = sorted({int(m.split('@')[1]) for m in metrics if '@' in m})
+        per_user = None
+        if ks:
+            if any(m.startswith('precision@') for m in metrics) and es.min_group < max(
+                    int(m.split('@')[1]) for m in metrics if m.startswith('precision@')):
+                raise ValueError('Relevance score length < k')        # rank_metrics.py:80-81
+            per_user = _lib.rank_eval_topk(p, es.Y, es.indptr, es.rows, ks).double()
+        out = []
+        for m in metrics:
+            if m == 'rmse':
+                out.append(float(torch.sqrt(torch.mean((es.Y.double() - p.double()) ** 2))))
+            elif m == 'mae':
+                out.append(float(torch.mean(torch.abs(es.Y.double() - p.double()))))
+            else:
+                name, k = m.split('@')
+                j, k = ks.index(int(k)), int(k)
+                col = {'ndcg': 0, 'hit': 1, 'precision': 2, 'recall': 3}.get(name)
+                if col is not None:
+                    vals = per_user[:, j, col]
+                else:       # f1@k = 2 * hits / (k + positives)
+                    vals = 2.0 * per_user[:, j, 2] * k / (k + per_user[:, len(ks), 0])
+                out.append(float(vals.mean()))
+        return out
+
     def evaluate(self, model, data, data_processor, metrics=None, write_rank=False):
         """src/runners/BaseRunner.py:305-332."""
         if metrics is None:
             metrics = self.metrics
+        if self.device_eval and not write_rank and self._device_metrics_ok(metrics):
+            return self.evaluate_device(model, data, data_processor, metrics)
         predictions = self.predict(model, data, data_processor)
         if write_rank:
             df = pd.DataFrame({'uid': data['uid'], 'iid': data['iid'], 'score': predictions, 'label': data['Y']})

@@ -424,6 +424,7 @@ def gen_e2e(outdir):
     c = E2E
     rec = {k: np.array(v) for k, v in c.items()}
     cwd = os.getcwd()
+    done = []
     for seed in c['seeds']:
         tmp = tempfile.mkdtemp()
         try:
@@ -447,12 +448,14 @@ def gen_e2e(outdir):
             rec['seed%d/valid' % seed] = np.array([[float(x) for x in e[2].split(',')] for e in ep])
             rec['seed%d/test' % seed] = np.array([[float(x) for x in e[3].split(',')] for e in ep])
             print('seed', seed, 'valid ndcg@5 per epoch', rec['seed%d/valid' % seed][:, 0], flush=True)
+            done.append(seed)
+            rec['seeds'] = np.array(done)          # saved after every seed: a run takes minutes per seed
+            np.savez_compressed(os.path.join(outdir, os.environ.get('E2E_OUT', 'e2e.npz')), **rec)
         finally:
             os.chdir(cwd)
             for h in logging.root.handlers[:]:
                 logging.root.removeHandler(h)
             shutil.rmtree(tmp)
-    np.savez_compressed(os.path.join(outdir, os.environ.get('E2E_OUT', 'e2e.npz')), **rec)
 
 
 if __name__ == '__main__':
