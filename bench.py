@@ -44,6 +44,9 @@ def parse():
     p.add_argument('--cpu_steps', type=int, default=60)
     p.add_argument('--seed', type=int, default=2019)
     p.add_argument('--force_sharded', type=int, default=0, help='run the row-sharded pipeline even at --gpus 1')
+    p.add_argument('--overlap', type=int, default=0, help='1: dccf_train_step with the untouched-row optimizer pass on a side '
+                                                          'stream (see DESIGN.md: +5 %% only with DCCF_SIDE_CUS=128 --stream 1)')
+    p.add_argument('--stream', type=int, default=0, help='1: run on a created stream instead of the default (null) stream')
     p.add_argument('--graph', type=int, default=0, help='1: each step is one hipGraph replay (device-side step counter); '
                    'measured slower than eager launches here (132 vs 122 us/step), hence off')
     return p.parse_args()
@@ -92,6 +95,8 @@ def main():
                              % (args.gpus, args.gpus))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    if args.stream:
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     if world > 1 or args.force_sharded:
         import torch.distributed as dist
         if world == 1:
@@ -141,6 +146,11 @@ def main():
     batch = {'Y': y, 'rank': 1, 'train': True, 'dropout': p_drop}
 
     def run(full, k0, k1, events=None):
+        if events is None:      # one library call per step (dccf_train_step)
+            for k in range(k0, k1):
+                batch['X'] = full[k]
+                model.train_step(batch, overlap=args.overlap)
+            return
         for k in range(k0, k1):
             batch['X'] = full[k]
             model(batch)

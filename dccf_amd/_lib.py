@@ -14,7 +14,7 @@ EXPORTS = ['dccf_ctx_create', 'dccf_ctx_destroy', 'dccf_ctx_reserve', 'dccf_last
            'dccf_predict', 'dccf_train_fwdbwd', 'dccf_dense_opt_step', 'dccf_sumsq', 'mf_predict', 'mf_train_fwdbwd',
            'mf_predict_full', 'dccf_sample_train_negatives', 'dccf_debug_candidates', 'dccf_debug_noise',
            'dccf_debug_keep', 'dccf_debug_workspace', 'dccf_profile', 'dccf_profile_read',
-           'shard_pack_rows', 'shard_unpack_rows', 'shard_scatter_add', 'dccf_dense_opt_step_rows', 'dccf_dense_opt_step_dev', 'dccf_advance', 'rank_eval_topk']
+           'shard_pack_rows', 'shard_unpack_rows', 'shard_scatter_add', 'dccf_dense_opt_step_rows', 'dccf_dense_opt_step_dev', 'dccf_advance', 'rank_eval_topk', 'dccf_train_step']
 
 OPT_KIND = {'gd': 0, 'adagrad': 1, 'adam': 2}
 MF_KIND = {'RecModel': 0, 'BiasedMF': 1, 'IPSBiasedMF': 2}
@@ -37,6 +37,13 @@ class RandT(C.Structure):
 
 class GradsT(C.Structure):
     _fields_ = [('gU', _f), ('gV', _f), ('gW', _f), ('gb', _f), ('touchedU', _f), ('touchedV', _f)]
+
+
+class OptT(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('overlap', C.c_int32), ('p', _f), ('g', _f), ('s1', _f), ('s2', _f), ('n', C.c_int64),
+                ('lr', C.c_float), ('wd', C.c_float), ('l2', C.c_float), ('clip', C.c_float), ('step', C.c_int64),
+                ('nseg', C.c_int32), ('reserved', C.c_int32), ('seg_begin', _f), ('seg_rows', _f), ('seg_width', _f),
+                ('seg_flags', _f)]
 
 
 class MFModelT(C.Structure):
@@ -78,6 +85,8 @@ def load():
         'dccf_dense_opt_step_dev': [i32, vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, vp, i32, C.POINTER(i64), C.POINTER(i64),
                                     C.POINTER(i32), C.POINTER(vp), vp],
         'dccf_advance': [vp, vp],
+        'dccf_train_step': [vp, C.POINTER(ModelT), C.POINTER(RandT), vp, vp, i64, i32, f32, C.POINTER(GradsT),
+                            C.POINTER(OptT), vp, vp, vp],
         'rank_eval_topk': [vp, vp, vp, vp, i64, C.POINTER(i32), vp, i32, vp, vp],
         'dccf_sumsq': [vp, i64, vp, vp],
         'mf_predict': [C.POINTER(MFModelT), vp, i64, vp, vp],
@@ -210,6 +219,35 @@ def dccf_train_fwdbwd(ctx, m, r, X, Y, rank, dropout, gU, gV, gW, gb, pred=None,
     g = GradsT(ptr(gU), ptr(gV), ptr(gW), ptr(gb), ptr(touchedU, torch.uint8), ptr(touchedV, torch.uint8))
     check(load().dccf_train_fwdbwd(ctx.h, C.byref(m), C.byref(r), ptr(X, torch.int64), ptr(Y), N, int(rank),
                                    float(dropout), C.byref(g), ptr(pred), ptr(loss), stream()))
+    return pred, loss
+
+
+def opt_struct(kind, p, g, s1, s2, lr, wd, l2, clip, segments, overlap):
+    """dccf_opt_t for dccf_train_step; `step` is filled in per call.  Keeps the host arrays and tensors alive."""
+    n = len(segments)
+    o = OptT()
+    o._refs = [(C.c_int64 * max(n, 1))(*[int(s[0]) for s in segments]), (C.c_int64 * max(n, 1))(*[int(s[1]) for s in segments]),
+               (C.c_int32 * max(n, 1))(*[int(s[2]) for s in segments]),
+               (C.c_void_p * max(n, 1))(*[ptr(s[3], torch.uint8) for s in segments]), p, g, s1, s2, segments]
+    o.kind, o.overlap = OPT_KIND[kind.lower()], int(overlap)
+    o.p, o.g, o.s1, o.s2, o.n = ptr(p, torch.float32), ptr(g, torch.float32), ptr(s1), ptr(s2), p.numel()
+    o.lr, o.wd, o.l2, o.clip, o.nseg = float(lr), float(wd), float(l2), float(clip), n
+    o.seg_begin, o.seg_rows, o.seg_width, o.seg_flags = [C.cast(a, C.c_void_p) for a in o._refs[:4]]
+    return o
+
+
+def dccf_train_step(ctx, m, r, X, Y, rank, dropout, gU, gV, gW, gb, opt, step, pred=None, loss=None, touchedU=None,
+                    touchedV=None):
+    """forward + loss + backward + regularised optimizer step (dccf_train_step): BaseRunner.py:172-188 in one call."""
+    N = X.shape[0]
+    if pred is None:
+        pred = torch.empty(N, dtype=torch.float32, device=X.device)
+    if loss is None:
+        loss = torch.empty(1, dtype=torch.float32, device=X.device)
+    g = GradsT(ptr(gU), ptr(gV), ptr(gW), ptr(gb), ptr(touchedU, torch.uint8), ptr(touchedV, torch.uint8))
+    opt.step = int(step)
+    check(load().dccf_train_step(ctx.h, C.byref(m), C.byref(r), ptr(X, torch.int64), ptr(Y), N, int(rank), float(dropout),
+                                 C.byref(g), C.byref(opt), ptr(pred), ptr(loss), stream()))
     return pred, loss
 
 

@@ -41,6 +41,14 @@ struct dccf_ctx {
   hipEvent_t* ev;
   int* ev_slot;
   int ev_used;
+  // overlapped training step (dccf_train_step): low-priority side stream for the untouched-row optimizer pass, fork/join
+  // events, and the de-duplicated list of the rows this step touches (built by k_prep, consumed by k_opt_touched)
+  hipStream_t side;
+  hipEvent_t ev_fork, ev_join;
+  int64_t* tl_list;
+  int64_t tl_cap;
+  int* tl_cnt;      // [2]: counters of the current / next step (double-buffered so no launch is spent on the reset)
+  int tl_parity;
 };
 static inline void prof_begin(dccf_ctx* c, hipStream_t st) {
   if (c->prof_on && c->ev_used + 2 <= DCCF_PROF_EVENTS) (void)hipEventRecord(c->ev[c->ev_used], st);
@@ -53,6 +61,25 @@ static inline void prof_end(dccf_ctx* c, int slot, hipStream_t st) {
   }
 }
 int dccf_ws_ensure(dccf_ctx* ctx, size_t bytes);
+int dccf_step_ensure(dccf_ctx* ctx, int64_t max_rows);
+
+// What k_prep needs to mark the rows a training step touches before the forward starts (overlapped step).
+// flag arrays are the uint8 "touched" bytes viewed as 32-bit words (atomicOr de-duplicates); list entries = (seg << 40) | row.
+struct MarkPlan {
+  uint32_t* flagU;
+  uint32_t* flagV;
+  int64_t tagU, tagV;
+  int64_t* list;
+  int* cnt;
+  int* cnt_next;
+};
+
+struct dccf_opt_args;      // == dccf_opt_t of include/dccf_hip.h
+#define OPT_PHASE_ALL 0
+#define OPT_PHASE_UNTOUCHED 1
+#define OPT_PHASE_TOUCHED 2
+// opt_kernels.hip: one phase of the dense regularised optimizer step described by `o` (dccf_opt_t)
+int dccf_opt_phase(const void* o, int phase, const int64_t* list, const int* cnt, int64_t max_rows, hipStream_t st);
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -59,17 +59,46 @@ static Lay make_layout(int64_t N, int D, int F, int S, int A) {
 }
 
 // ================================================================================================ K0: prep
+// Sets the row's "touched" byte; the first setter appends the row to the step's list.  Divergence-safe: the ballot is over
+// the lanes that reached this call.
+__device__ __forceinline__ void mark_row(uint32_t* flags, int64_t row, int64_t tag, const MarkPlan& mp) {
+  const uint32_t mask = 1u << (8 * (int)(row & 3));
+  const uint32_t old = atomicOr(flags + (row >> 2), mask);
+  const bool first = (old & mask) == 0;
+  const uint64_t b = __ballot(first);
+  if (b == 0) return;
+  const int lane = threadIdx.x & 63;
+  const int leader = __ffsll((unsigned long long)b) - 1;
+  int base = 0;
+  if (lane == leader) base = atomicAdd(mp.cnt, __popcll(b));
+  base = __shfl(base, leader, 64);
+  if (first) mp.list[base + __popcll(b & ((1ull << lane) - 1))] = tag | row;
+}
+
+// Expo[u, i] (models/DCCF.py:98), dense or recomputed from the IPSBiasedMF factors that produced it (IPSBiasedMF.py:32-40)
+__device__ __forceinline__ float expo_at(const dccf_model_t& M, int64_t u, int64_t i) {
+  if (M.expo) return M.expo[u * M.item_num + i];
+  float acc = 0.f;
+  for (int k = 0; k < M.ipsD; ++k) acc = fmaf(M.ipsP[u * M.ipsD + k], M.ipsQ[i * M.ipsD + k], acc);
+  acc = acc + M.ipsBu[u] + M.ipsBi[i] + M.ipsB0;
+  return acc / fmaxf(M.ipsProp[i], M.ipsM);
+}
+
 // WT[k][d] = W[d][k] (zero padded), cand[n][0] = true item, cand[n][s] = injected or Philox candidate
-// (models/DCCF.py:72-74), m = 0 (only when two column halves add into it), loss = 0.
-__global__ void k_prep(const float* __restrict__ W, float* __restrict__ WT, int D, int F, int DP, int FP,
+// (models/DCCF.py:72-74), eg[n][s] = Expo[u(n), cand[n][s]] (gathered HERE, before the optimizer side stream starts to
+// saturate HBM: the epilogue's dependent gathers would otherwise queue behind it), m = 0 (only when two column halves
+// add into it), loss = 0.
+__global__ void k_prep(dccf_model_t M, float* __restrict__ WT, int D, int F, int DP, int FP,
                        const int64_t* X, const int64_t* __restrict__ sample_item, int* __restrict__ cand,
-                       int64_t N, int S, int64_t item_num, int fused, rng_key key, float* __restrict__ m, int64_t Lm,
-                       float* __restrict__ loss, StepRef sr) {
+                       float* __restrict__ eg, int64_t N, int S, int64_t item_num, int fused, rng_key key,
+                       float* __restrict__ m, int64_t Lm, float* __restrict__ loss, StepRef sr, MarkPlan mp) {
+  const float* __restrict__ W = M.W;
   {
     const int64_t k = step_k(sr);
     X = step_X(sr, X, k);
     key = key_plus(key, k);
   }
+  if (mp.list && blockIdx.x == 0 && threadIdx.x == 0) *mp.cnt_next = 0;    // the NEXT step's counter (double-buffered)
   const int64_t nWT = (int64_t)(D + FP) * DP;
   const int64_t NS = N * (S + 1);
   const int64_t total = nWT + NS + Lm + 1;
@@ -91,6 +120,11 @@ __global__ void k_prep(const float* __restrict__ W, float* __restrict__ WT, int 
         it = (int64_t)(((uint64_t)pick4(r, (s - 1) & 3) * (uint64_t)item_num) >> 32);
       }
       cand[j] = (int)it;
+      eg[j] = expo_at(M, X[2 * n], it);
+      if (mp.list) {        // overlapped step: every row this batch reads/updates, once (wave-aggregated append)
+        mark_row(mp.flagV, it, mp.tagV, mp);
+        if (s == 0) mark_row(mp.flagU, X[2 * n], mp.tagU, mp);
+      }
     } else if (i < nWT + NS + Lm) {
       m[i - nWT - NS] = 0.f;
     } else if (loss) {
@@ -407,13 +441,6 @@ __global__ __launch_bounds__(NWV * 64) void k_fwd_rows(const float* __restrict__
 // ================================================================================================ K2: pair epilogue
 // One lane per candidate: softmax_s(Expo[u, cand[n,s]]) (DCCF.py:98), prediction = mean_a sum_s w m (DCCF.py:100),
 // loss and d loss / d m (DCCF.py:116-125).  A group of GS lanes serves one pair (rank 1) or one row.
-__device__ __forceinline__ float expo_at(const dccf_model_t& M, int64_t u, int64_t i) {
-  if (M.expo) return M.expo[u * M.item_num + i];
-  float acc = 0.f;
-  for (int k = 0; k < M.ipsD; ++k) acc = fmaf(M.ipsP[u * M.ipsD + k], M.ipsQ[i * M.ipsD + k], acc);
-  acc = acc + M.ipsBu[u] + M.ipsBi[i] + M.ipsB0;
-  return acc / fmaxf(M.ipsProp[i], M.ipsM);
-}
 
 template <int GS>
 __device__ __forceinline__ float group_sum(float v) {
@@ -429,11 +456,10 @@ __device__ __forceinline__ float group_max(float v) {
 }
 
 template <int GS>
-__device__ __forceinline__ float row_predict(const dccf_model_t& M, const int64_t* X, const int* cand, const float* m,
-                                             int64_t n, int s, int S1, int A, float& w_over_A) {
+__device__ __forceinline__ float row_predict(const float* eg, const float* m, int64_t n, int s, int S1, int A,
+                                             float& w_over_A) {
   const bool valid = s < S1;
-  const int64_t u = X[2 * n];
-  const float e = valid ? expo_at(M, u, cand[n * S1 + s]) : -INFINITY;
+  const float e = valid ? eg[n * S1 + s] : -INFINITY;
   const float mx = group_max<GS>(e);
   const float ex = valid ? expf(e - mx) : 0.f;
   const float w = ex / group_sum<GS>(ex);
@@ -444,13 +470,11 @@ __device__ __forceinline__ float row_predict(const dccf_model_t& M, const int64_
 }
 
 template <int GS>
-__global__ __launch_bounds__(256) void k_pair_epilogue(dccf_model_t M, const int64_t* X,
-                                                       const float* __restrict__ Y, const int* __restrict__ cand,
-                                                       const float* __restrict__ m, float* __restrict__ dmns,
+__global__ __launch_bounds__(256) void k_pair_epilogue(int S1, int A, const float* __restrict__ Y,
+                                                       const float* __restrict__ m, float* dmns,
                                                        float* __restrict__ pred, float* __restrict__ loss, int64_t N,
-                                                       int rank, int train, StepRef sr) {
-  X = step_X(sr, X, step_k(sr));
-  const int S1 = M.S + 1, A = M.A;
+                                                       int rank, int train) {
+  // dmns[n][s] arrives holding Expo[u, cand] (k_prep) and leaves holding d loss / d (mean_a m) — same lane, same slot
   const int s = threadIdx.x % GS;
   const int64_t gid = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / GS;
   const int64_t ngr = (int64_t)gridDim.x * blockDim.x / GS;
@@ -465,8 +489,8 @@ __global__ __launch_bounds__(256) void k_pair_epilogue(dccf_model_t M, const int
     if (pairs) {
       const int64_t B = N / 2;
       float wp, wn;
-      const float pp = row_predict<GS>(M, X, cand, m, k, s, S1, A, wp);
-      const float pn = row_predict<GS>(M, X, cand, m, B + k, s, S1, A, wn);
+      const float pp = row_predict<GS>(dmns, m, k, s, S1, A, wp);
+      const float pn = row_predict<GS>(dmns, m, B + k, s, S1, A, wn);
       const float d = pp - pn;
       const float sg = 1.f / (1.f + expf(-d));
       const float gp = -(1.f - sg);                 // d loss / d pos = -sigmoid(neg - pos)
@@ -481,7 +505,7 @@ __global__ __launch_bounds__(256) void k_pair_epilogue(dccf_model_t M, const int
       }
     } else {
       float w;
-      const float p = row_predict<GS>(M, X, cand, m, k, s, S1, A, w);
+      const float p = row_predict<GS>(dmns, m, k, s, S1, A, w);
       if (live && s == 0) pred[k] = p;
       if (train && live) {
         const float diff = p - Y[k];
@@ -807,9 +831,18 @@ static int check_model(const dccf_model_t* M) {
     default: { CALL(128); } break; \
   }
 
+// The optimizer half of dccf_train_step, threaded through run_dccf: `overlap` forks the untouched-row pass onto the
+// context's side stream right after k_prep has marked the rows of this batch.
+struct StepPlan {
+  const dccf_opt_t* opt;
+  bool overlap;
+  MarkPlan mark;
+  int64_t max_rows;
+};
+
 static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd, const int64_t* X, const float* Y,
                     int64_t N, int rank, float dropout, const dccf_grads_t* G, float* pred, float* loss, bool train,
-                    hipStream_t st) {
+                    hipStream_t st, const StepPlan* plan = nullptr) {
   ARG_CHECK(ctx != nullptr, "ctx is NULL");
   if (int e = check_model(M)) return e;
   ARG_CHECK(N >= 0 && N * (int64_t)(M->S + 1) * M->A < 4294967296LL, "N*(S+1)*A must be < 2^32");
@@ -828,6 +861,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
   }
   if (N == 0) {
     if (train) HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), st));
+    if (plan) return dccf_opt_phase(plan->opt, OPT_PHASE_ALL, nullptr, nullptr, 0, st);
     return 0;
   }
   const int D = M->D, F = M->F, S1 = M->S + 1, A = M->A;
@@ -855,10 +889,21 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
   {
     const int64_t total = (int64_t)(D + y.FP) * y.DP + y.NS + (y.GY > 1 ? y.L : 0) + 1;
     const int grid = (int)min((int64_t)2048, (total + 255) / 256);
+    MarkPlan mark;
+    memset(&mark, 0, sizeof(mark));
+    if (plan && plan->overlap) mark = plan->mark;
     prof_begin(ctx, st);
-    hipLaunchKernelGGL(k_prep, dim3(grid), dim3(256), 0, st, M->W, WT, D, F, y.DP, y.FP, X, rnd->sample_item, cand, N,
-                       M->S, M->item_num, fused_cand ? 1 : 0, ckey, m, y.GY > 1 ? y.L : (int64_t)0, train ? loss : nullptr, sr);
+    hipLaunchKernelGGL(k_prep, dim3(grid), dim3(256), 0, st, *M, WT, D, F, y.DP, y.FP, X, rnd->sample_item, cand, dmns, N,
+                       M->S, M->item_num, fused_cand ? 1 : 0, ckey, m, y.GY > 1 ? y.L : (int64_t)0, train ? loss : nullptr, sr,
+                       mark);
     prof_end(ctx, 0, st);
+  }
+  if (plan && plan->overlap) {
+    // fork: rows NOT on this batch's list see only the l2 term -> their optimizer pass needs nothing from this step
+    HIP_TRY(hipEventRecord(ctx->ev_fork, st));
+    HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+    if (int e = dccf_opt_phase(plan->opt, OPT_PHASE_UNTOUCHED, nullptr, nullptr, 0, ctx->side)) return e;
+    HIP_TRY(hipEventRecord(ctx->ev_join, ctx->side));
   }
   if (ntiles >= 2048) {
     // eval-size batch: rows-per-wave kernel, W^T through LDS in two halves
@@ -904,8 +949,8 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     const int grid = (int)min((int64_t)2048, (units * GS + 255) / 256);
     prof_begin(ctx, st);
 #define LAUNCH_PE(GS_)                                                                                              \
-  hipLaunchKernelGGL((k_pair_epilogue<GS_>), dim3(grid), dim3(256), 0, st, *M, X, Y, cand, m, dmns, pred, loss, N, rank, \
-                     train ? 1 : 0, sr)
+  hipLaunchKernelGGL((k_pair_epilogue<GS_>), dim3(grid), dim3(256), 0, st, S1, A, Y, m, dmns, pred, loss, N, rank, \
+                     train ? 1 : 0)
     if (GS == 16) LAUNCH_PE(16); else if (GS == 32) LAUNCH_PE(32); else LAUNCH_PE(64);
 #undef LAUNCH_PE
     prof_end(ctx, 3, st);
@@ -945,7 +990,56 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     prof_end(ctx, 5, st);
   }
   HIP_TRY(hipGetLastError());
+  if (plan) {
+    prof_begin(ctx, st);
+    if (plan->overlap) {
+      HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));
+      if (int e = dccf_opt_phase(plan->opt, OPT_PHASE_TOUCHED, plan->mark.list, plan->mark.cnt, plan->max_rows, st)) return e;
+    } else {
+      if (int e = dccf_opt_phase(plan->opt, OPT_PHASE_ALL, nullptr, nullptr, 0, st)) return e;
+    }
+    prof_end(ctx, 6, st);
+  }
   return 0;
+}
+
+extern "C" int dccf_train_step(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd, const int64_t* X, const float* Y,
+                               int64_t N, int32_t rank, float dropout, const dccf_grads_t* G, const dccf_opt_t* opt,
+                               float* prediction, float* loss, void* stream) {
+  ARG_CHECK(ctx && M && G && opt, "NULL argument");
+  ARG_CHECK(rnd && rnd->k_dev == nullptr, "dccf_train_step takes a host-side step (no k_dev)");
+  StepPlan plan;
+  memset(&plan, 0, sizeof(plan));
+  plan.opt = opt;
+  plan.overlap = opt->overlap != 0 && N > 0;
+  if (plan.overlap) {
+    // the segments that hold U and V, by address
+    int qU = -1, qV = -1;
+    ARG_CHECK(opt->nseg >= 2 && opt->nseg <= 4 && opt->seg_begin && opt->seg_rows && opt->seg_width && opt->seg_flags && opt->p,
+              "overlap needs the U and V row segments");
+    for (int q = 0; q < opt->nseg; ++q) {
+      if (opt->p + opt->seg_begin[q] == M->U) qU = q;
+      if (opt->p + opt->seg_begin[q] == M->V) qV = q;
+    }
+    ARG_CHECK(qU >= 0 && qV >= 0 && qU != qV, "model->U / model->V are not the start of a row segment of opt->p");
+    ARG_CHECK(opt->seg_rows[qU] == M->user_num && opt->seg_rows[qV] == M->item_num && opt->seg_width[qU] == M->D &&
+                  opt->seg_width[qV] == M->D,
+              "U / V segments do not match the model");
+    ARG_CHECK(G->touchedU == opt->seg_flags[qU] && G->touchedV == opt->seg_flags[qV] && G->touchedU && G->touchedV,
+              "grads->touchedU/V must be the flags of the U / V segments");
+    ARG_CHECK((uintptr_t)G->touchedU % 4 == 0 && (uintptr_t)G->touchedV % 4 == 0, "touched flags must be 4-byte aligned");
+    plan.max_rows = N * (int64_t)(M->S + 2);
+    if (int e = dccf_step_ensure(ctx, plan.max_rows)) return e;
+    plan.mark.flagU = (uint32_t*)G->touchedU;
+    plan.mark.flagV = (uint32_t*)G->touchedV;
+    plan.mark.tagU = (int64_t)qU << 40;
+    plan.mark.tagV = (int64_t)qV << 40;
+    plan.mark.list = ctx->tl_list;
+    plan.mark.cnt = ctx->tl_cnt + ctx->tl_parity;
+    plan.mark.cnt_next = ctx->tl_cnt + (ctx->tl_parity ^ 1);
+    ctx->tl_parity ^= 1;
+  }
+  return run_dccf(ctx, M, rnd, X, Y, N, rank, dropout, G, prediction, loss, true, (hipStream_t)stream, &plan);
 }
 
 extern "C" int dccf_predict(dccf_ctx* ctx, const dccf_model_t* model, const dccf_rand_t* rnd, const int64_t* X,

@@ -1,0 +1,62 @@
+// opt_device.hpp — element arithmetic and argument blocks of the dense regularised optimizer step (opt_kernels.hip):
+// src/runners/BaseRunner.py:92-100,181-187 (+ l2, clip_grad_value_(50), torch.optim step).
+#pragma once
+#include "common.hpp"
+
+// Op order mirrors torch 2.10's single-tensor CPU paths so that results agree with the oracle to rounding
+// (contraction is disabled for this file's arithmetic via explicit __fmul_rn/__fadd_rn where it matters).
+struct OptArgs {
+  float lr, wd, l2, clip;
+  float step_size_neg;   // Adam: -(lr / (1 - beta1^t))
+  float bc2_sqrt;        // Adam: sqrt(1 - beta2^t)
+  int zero_grad;
+  const int64_t* k_dev;  // graph-replayable form: step = step0 + *k_dev, bias corrections computed here
+  int64_t step0;
+};
+
+__device__ __forceinline__ void opt_resolve(OptArgs& a) {
+  if (a.k_dev) {
+    const double t = (double)(a.step0 + *a.k_dev);
+    a.step_size_neg = (float)(-((double)a.lr / (1.0 - pow(0.9, t))));
+    a.bc2_sqrt = (float)sqrt(1.0 - pow(0.999, t));
+  }
+}
+
+template <int KIND>
+__device__ __forceinline__ void opt_elem(float& p, float& g, float& s1, float& s2, const OptArgs& a) {
+  // explicit l2 term of the loss, then the clip, then the optimizer's coupled weight decay
+  float gt = __fadd_rn(g, __fmul_rn(a.l2, __fmul_rn(2.0f, p)));
+  gt = fminf(fmaxf(gt, -a.clip), a.clip);
+  gt = __fadd_rn(gt, __fmul_rn(a.wd, p));
+  if (KIND == DCCF_OPT_GD) {
+    p = __fadd_rn(p, __fmul_rn(-a.lr, gt));
+  } else if (KIND == DCCF_OPT_ADAGRAD) {
+    s1 = __fadd_rn(s1, __fmul_rn(gt, gt));
+    const float sd = __fadd_rn(__fsqrt_rn(s1), 1e-10f);
+    p = __fadd_rn(p, __fdiv_rn(__fmul_rn(-a.lr, gt), sd));
+  } else {
+    s1 = __fadd_rn(s1, __fmul_rn(0.1f, __fsub_rn(gt, s1)));                       // lerp_(g, 1-beta1), weight < 0.5
+    s2 = __fadd_rn(__fmul_rn(s2, 0.999f), __fmul_rn(__fmul_rn(0.001f, gt), gt));  // mul_(b2).addcmul_(g, g, 1-b2)
+    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(s2), a.bc2_sqrt), 1e-8f);
+    p = __fadd_rn(p, __fdiv_rn(__fmul_rn(a.step_size_neg, s1), denom));
+  }
+  if (a.zero_grad) g = 0.f;
+}
+
+
+// Row segments of the flat buffer: one "touched" byte per row (see dccf_dense_opt_step_rows).
+struct RowSegs {
+  int64_t begin[4], end[4];
+  int width[4];
+  uint8_t* flags[4];
+  int n;
+};
+
+// Everything a kernel needs to run (part of) one optimizer step.
+struct OptJob {
+  float *p, *g, *s1, *s2;
+  int64_t n;
+  int kind;
+  OptArgs a;
+  RowSegs sg;
+};

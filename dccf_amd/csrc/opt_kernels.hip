@@ -8,6 +8,7 @@
 // streaming pass over p, g and the optimizer state — HBM bound: Adam reads p,g,m,v and writes p,m,v,g(=0),
 // 32 B per parameter (28 B without the fused zero_grad).
 #include "common.hpp"
+#include "opt_device.hpp"
 
 // No implicit FMA contraction in this file: a*b+c written as two operations stays two roundings (explicit fmaf() calls
 // are still FMAs).  It keeps "fused draws == injected draws" bit for bit and the optimizer in torch's op order.
@@ -29,6 +30,12 @@ extern "C" int dccf_ctx_create(dccf_ctx** out, int device) {
   c->ev = nullptr;
   c->ev_slot = nullptr;
   c->ev_used = 0;
+  c->side = nullptr;
+  c->ev_fork = c->ev_join = nullptr;
+  c->tl_list = nullptr;
+  c->tl_cap = 0;
+  c->tl_cnt = nullptr;
+  c->tl_parity = 0;
   *out = c;
   return 0;
 }
@@ -69,7 +76,45 @@ extern "C" int dccf_ctx_destroy(dccf_ctx* ctx) {
     delete[] ctx->ev;
     delete[] ctx->ev_slot;
   }
+  if (ctx->side) (void)hipStreamDestroy(ctx->side);
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->tl_list) (void)hipFree(ctx->tl_list);
+  if (ctx->tl_cnt) (void)hipFree(ctx->tl_cnt);
   delete ctx;
+  return 0;
+}
+
+// Side stream, events and touched-row list of the overlapped step; the list grows like the workspace does.
+int dccf_step_ensure(dccf_ctx* ctx, int64_t max_rows) {
+  if (!ctx->side) {
+    int lo = 0, hi = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));      // lo = least priority: forward/backward win the dispatcher
+    // DCCF_SIDE_CUS=n: confine the side stream to n of the 256 CUs (mask bits interleave over the 8 XCDs, so every XCD
+    // gives n/8) — the optimizer pass saturates HBM from a subset of the CUs and leaves the rest to forward/backward
+    int ncu = 0;
+    if (const char* e = getenv("DCCF_SIDE_CUS")) ncu = atoi(e);
+    if (ncu > 0 && ncu < 256) {
+      uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int i = 0; i < ncu; ++i) mask[i >> 5] |= 1u << (i & 31);
+      HIP_TRY(hipExtStreamCreateWithCUMask(&ctx->side, 8, mask));
+    } else {
+      HIP_TRY(hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, lo));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    HIP_TRY(hipMalloc((void**)&ctx->tl_cnt, 2 * sizeof(int)));
+    HIP_TRY(hipMemset(ctx->tl_cnt, 0, 2 * sizeof(int)));
+  }
+  if (max_rows > ctx->tl_cap) {
+    HIP_TRY(hipDeviceSynchronize());
+    if (ctx->tl_list) HIP_TRY(hipFree(ctx->tl_list));
+    ctx->tl_list = nullptr;
+    ctx->tl_cap = 0;
+    const int64_t want = max_rows + max_rows / 8 + 1024;
+    HIP_TRY(hipMalloc((void**)&ctx->tl_list, (size_t)want * sizeof(int64_t)));
+    ctx->tl_cap = want;
+  }
   return 0;
 }
 
@@ -87,45 +132,7 @@ int dccf_ws_ensure(dccf_ctx* ctx, size_t bytes) {
 }
 
 // ---------------------------------------------------------------------------------------------- optimizer
-// Op order mirrors torch 2.10's single-tensor CPU paths so that results agree with the oracle to rounding
-// (contraction is disabled for this file's arithmetic via explicit __fmul_rn/__fadd_rn where it matters).
-struct OptArgs {
-  float lr, wd, l2, clip;
-  float step_size_neg;   // Adam: -(lr / (1 - beta1^t))
-  float bc2_sqrt;        // Adam: sqrt(1 - beta2^t)
-  int zero_grad;
-  const int64_t* k_dev;  // graph-replayable form: step = step0 + *k_dev, bias corrections computed here
-  int64_t step0;
-};
-
-__device__ __forceinline__ void opt_resolve(OptArgs& a) {
-  if (a.k_dev) {
-    const double t = (double)(a.step0 + *a.k_dev);
-    a.step_size_neg = (float)(-((double)a.lr / (1.0 - pow(0.9, t))));
-    a.bc2_sqrt = (float)sqrt(1.0 - pow(0.999, t));
-  }
-}
-
-template <int KIND>
-__device__ __forceinline__ void opt_elem(float& p, float& g, float& s1, float& s2, const OptArgs& a) {
-  // explicit l2 term of the loss, then the clip, then the optimizer's coupled weight decay
-  float gt = __fadd_rn(g, __fmul_rn(a.l2, __fmul_rn(2.0f, p)));
-  gt = fminf(fmaxf(gt, -a.clip), a.clip);
-  gt = __fadd_rn(gt, __fmul_rn(a.wd, p));
-  if (KIND == DCCF_OPT_GD) {
-    p = __fadd_rn(p, __fmul_rn(-a.lr, gt));
-  } else if (KIND == DCCF_OPT_ADAGRAD) {
-    s1 = __fadd_rn(s1, __fmul_rn(gt, gt));
-    const float sd = __fadd_rn(__fsqrt_rn(s1), 1e-10f);
-    p = __fadd_rn(p, __fdiv_rn(__fmul_rn(-a.lr, gt), sd));
-  } else {
-    s1 = __fadd_rn(s1, __fmul_rn(0.1f, __fsub_rn(gt, s1)));                       // lerp_(g, 1-beta1), weight < 0.5
-    s2 = __fadd_rn(__fmul_rn(s2, 0.999f), __fmul_rn(__fmul_rn(0.001f, gt), gt));  // mul_(b2).addcmul_(g, g, 1-b2)
-    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(s2), a.bc2_sqrt), 1e-8f);
-    p = __fadd_rn(p, __fdiv_rn(__fmul_rn(a.step_size_neg, s1), denom));
-  }
-  if (a.zero_grad) g = 0.f;
-}
+// (element arithmetic, OptArgs, RowSegs and the fused-slice role: opt_device.hpp)
 
 template <int KIND>
 __global__ __launch_bounds__(256) void k_dense_opt(float* __restrict__ p, float* __restrict__ g, float* __restrict__ s1,
@@ -161,19 +168,51 @@ __global__ __launch_bounds__(256) void k_dense_opt(float* __restrict__ p, float*
   }
 }
 
-// Row-aware variant: g of a row whose "touched" byte is 0 is all zeros by construction -> not read, not re-zeroed.
-// A wave handles 64 consecutive float4 = 256 consecutive floats = whole rows (row widths 16..128 divide 256 and segments
-// start on a 256-float boundary), so every lane of a row sees the byte before the row's first lane clears it.
-struct RowSegs {
-  int64_t begin[4], end[4];
-  int width[4];
-  uint8_t* flags[4];
+// Element intervals outside the row segments ("dense": always read their gradient).
+struct DenseSegs {
+  int64_t begin[5], end[5];
   int n;
 };
 
+// The rows on the step's touched list (half a wave per row).
+template <int KIND>
+__device__ __forceinline__ void touched_rows(float* __restrict__ p, float* __restrict__ g, float* __restrict__ s1,
+                                             float* __restrict__ s2, const OptArgs& a, const RowSegs& sg,
+                                             const int64_t* __restrict__ list, int n, int block, int row_blocks) {
+  const int half = threadIdx.x >> 5, l = threadIdx.x & 31;
+  for (int e = block * 8 + half; e < n; e += row_blocks * 8) {
+    const int64_t tag = list[e];
+    const int q = (int)(tag >> 40);
+    const int64_t row = tag & ((1LL << 40) - 1);
+    const int w4 = sg.width[q] >> 2;
+    const int64_t i0 = (sg.begin[q] + row * sg.width[q]) >> 2;
+    if (l < w4) {
+      const int64_t i = i0 + l;
+      float4 pv = reinterpret_cast<float4*>(p)[i];
+      float4 gv = reinterpret_cast<float4*>(g)[i];
+      float4 av = make_float4(0, 0, 0, 0), bv = make_float4(0, 0, 0, 0);
+      if (KIND != DCCF_OPT_GD) av = reinterpret_cast<float4*>(s1)[i];
+      if (KIND == DCCF_OPT_ADAM) bv = reinterpret_cast<float4*>(s2)[i];
+      opt_elem<KIND>(pv.x, gv.x, av.x, bv.x, a);
+      opt_elem<KIND>(pv.y, gv.y, av.y, bv.y, a);
+      opt_elem<KIND>(pv.z, gv.z, av.z, bv.z, a);
+      opt_elem<KIND>(pv.w, gv.w, av.w, bv.w, a);
+      reinterpret_cast<float4*>(p)[i] = pv;
+      reinterpret_cast<float4*>(g)[i] = make_float4(0, 0, 0, 0);
+      if (KIND != DCCF_OPT_GD) reinterpret_cast<float4*>(s1)[i] = av;
+      if (KIND == DCCF_OPT_ADAM) reinterpret_cast<float4*>(s2)[i] = bv;
+    }
+    if (l == 0) sg.flags[q][row] = 0;
+  }
+}
+
+// Row-aware variant: g of a row whose "touched" byte is 0 is all zeros by construction -> not read, not re-zeroed.
+// A wave handles 64 consecutive float4 = 256 consecutive floats = whole rows (row widths 16..128 divide 256 and segments
+// start on a 256-float boundary), so every lane of a row sees the byte before the row's first lane clears it.
 template <int KIND>
 __global__ __launch_bounds__(256) void k_dense_opt_rows(float* __restrict__ p, float* __restrict__ g, float* __restrict__ s1,
-                                                        float* __restrict__ s2, int64_t n, OptArgs a, RowSegs sg) {
+                                                        float* __restrict__ s2, int64_t n, OptArgs a, RowSegs sg,
+                                                        int phase) {
   opt_resolve(a);
   const int64_t n4 = n / 4;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -190,6 +229,7 @@ __global__ __launch_bounds__(256) void k_dense_opt_rows(float* __restrict__ p, f
         first = off % sg.width[q] == 0;
       }
     if (fl) touched = *fl != 0;
+    if (phase == OPT_PHASE_UNTOUCHED && (!fl || touched)) continue;     // those wait for the backward (k_opt_touched)
     float4 pv = reinterpret_cast<float4*>(p)[i];
     float4 gv = make_float4(0, 0, 0, 0);
     if (touched) gv = reinterpret_cast<float4*>(g)[i];
@@ -206,6 +246,7 @@ __global__ __launch_bounds__(256) void k_dense_opt_rows(float* __restrict__ p, f
     if (KIND == DCCF_OPT_ADAM) reinterpret_cast<float4*>(s2)[i] = bv;
     if (fl && touched && first) *fl = 0;
   }
+  if (phase == OPT_PHASE_UNTOUCHED) return;
   for (int64_t i = n4 * 4 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) {   // dense tail
     float pv = p[i], gv = g[i], av = 0.f, bv = 0.f;
     if (KIND != DCCF_OPT_GD) av = s1[i];
@@ -218,9 +259,36 @@ __global__ __launch_bounds__(256) void k_dense_opt_rows(float* __restrict__ p, f
   }
 }
 
-static int opt_rows_impl(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t n, float lr, float wd, float l2,
-                         float clip, int64_t step, const int64_t* k_dev, int32_t nseg, const int64_t* seg_begin,
-                         const int64_t* seg_rows, const int32_t* seg_width, uint8_t* const* seg_flags, void* stream) {
+// Second half of the overlapped step: the rows on the step's touched list (half a wave per row) and the elements outside
+// the row segments (W, b: dense), after the backward has produced their gradients.
+template <int KIND>
+__global__ __launch_bounds__(256) void k_opt_touched(float* __restrict__ p, float* __restrict__ g, float* __restrict__ s1,
+                                                     float* __restrict__ s2, OptArgs a, RowSegs sg,
+                                                     const int64_t* __restrict__ list, const int* __restrict__ cnt,
+                                                     int row_blocks, DenseSegs ds) {
+  opt_resolve(a);
+  if ((int)blockIdx.x < row_blocks) {
+    touched_rows<KIND>(p, g, s1, s2, a, sg, list, *cnt, blockIdx.x, row_blocks);
+    return;
+  }
+  const int64_t tid = (int64_t)(blockIdx.x - row_blocks) * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)(gridDim.x - row_blocks) * blockDim.x;
+  for (int d = 0; d < ds.n; ++d)
+    for (int64_t i = ds.begin[d] + tid; i < ds.end[d]; i += stride) {
+      float pv = p[i], gv = g[i], av = 0.f, bv = 0.f;
+      if (KIND != DCCF_OPT_GD) av = s1[i];
+      if (KIND == DCCF_OPT_ADAM) bv = s2[i];
+      opt_elem<KIND>(pv, gv, av, bv, a);
+      p[i] = pv;
+      g[i] = 0.f;
+      if (KIND != DCCF_OPT_GD) s1[i] = av;
+      if (KIND == DCCF_OPT_ADAM) s2[i] = bv;
+    }
+}
+
+static int make_job(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t n, float lr, float wd, float l2,
+                    float clip, int64_t step, const int64_t* k_dev, int32_t nseg, const int64_t* seg_begin,
+                    const int64_t* seg_rows, const int32_t* seg_width, uint8_t* const* seg_flags, OptJob* out) {
   ARG_CHECK(p && g && n >= 0 && step >= 1, "NULL p/g, n < 0 or step < 1");
   ARG_CHECK(kind == DCCF_OPT_GD || kind == DCCF_OPT_ADAGRAD || kind == DCCF_OPT_ADAM, "unknown optimizer kind");
   ARG_CHECK(kind == DCCF_OPT_GD || s1, "optimizer state s1 is NULL");
@@ -229,7 +297,8 @@ static int opt_rows_impl(int32_t kind, float* p, float* g, float* s1, float* s2,
                 (!s2 || (uintptr_t)s2 % 16 == 0),
             "buffers must be 16-byte aligned");
   ARG_CHECK(nseg >= 0 && nseg <= 4 && (nseg == 0 || (seg_begin && seg_rows && seg_width && seg_flags)), "bad segments");
-  RowSegs sg;
+  RowSegs& sg = out->sg;
+  memset(&sg, 0, sizeof(sg));
   sg.n = nseg;
   for (int q = 0; q < nseg; ++q) {
     const int w = seg_width[q];
@@ -241,21 +310,82 @@ static int opt_rows_impl(int32_t kind, float* p, float* g, float* s1, float* s2,
     sg.width[q] = w;
     sg.flags[q] = seg_flags[q];
   }
-  if (n == 0) return 0;
-  OptArgs a;
+  OptArgs& a = out->a;
   a.lr = lr; a.wd = wd; a.l2 = l2; a.clip = clip; a.zero_grad = 1;
   a.k_dev = k_dev; a.step0 = step;
+  // bias corrections in double like torch's Python scalars (torch/optim/adam.py::_single_tensor_adam)
   const double bc1 = 1.0 - pow(0.9, (double)step), bc2 = 1.0 - pow(0.999, (double)step);
   a.step_size_neg = (float)(-((double)lr / bc1));
   a.bc2_sqrt = (float)sqrt(bc2);
-  const int64_t work = (n + 3) / 4;
+  out->p = p; out->g = g; out->s1 = s1; out->s2 = s2; out->n = n; out->kind = kind;
+  return 0;
+}
+
+// the complement of the row segments, in ascending order
+static int dense_complement(const RowSegs& sg, int64_t n, DenseSegs* ds, int64_t* total) {
+  ds->n = 0;
+  int order[4] = {0, 1, 2, 3};
+  for (int i = 0; i < sg.n; ++i)
+    for (int j = i + 1; j < sg.n; ++j)
+      if (sg.begin[order[j]] < sg.begin[order[i]]) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+  int64_t at = 0;
+  *total = 0;
+  for (int i = 0; i <= sg.n; ++i) {
+    const int64_t b = i < sg.n ? sg.begin[order[i]] : n;
+    ARG_CHECK(b >= at, "row segments overlap");
+    if (b > at) { ds->begin[ds->n] = at; ds->end[ds->n] = b; ++ds->n; *total += b - at; }
+    if (i < sg.n) at = sg.end[order[i]];
+  }
+  return 0;
+}
+
+#define BY_KIND(kind, K, ...)                                                               \
+  if (kind == DCCF_OPT_GD) hipLaunchKernelGGL(K<DCCF_OPT_GD>, __VA_ARGS__);                 \
+  else if (kind == DCCF_OPT_ADAGRAD) hipLaunchKernelGGL(K<DCCF_OPT_ADAGRAD>, __VA_ARGS__);  \
+  else hipLaunchKernelGGL(K<DCCF_OPT_ADAM>, __VA_ARGS__)
+
+static int launch_job(const OptJob& j, int phase, const int64_t* list, const int* cnt, int64_t max_rows, hipStream_t st) {
+  if (j.n == 0) return 0;
+  if (phase == OPT_PHASE_TOUCHED) {
+    ARG_CHECK(list && cnt, "touched phase needs the row list");
+    DenseSegs ds;
+    int64_t dense_total = 0;
+    if (int e = dense_complement(j.sg, j.n, &ds, &dense_total)) return e;
+    const int row_blocks = (int)min((int64_t)2048, (max_rows + 7) / 8);
+    const int dense_blocks = (int)min((int64_t)1024, (dense_total + 255) / 256);
+    const int grid = row_blocks + dense_blocks;
+    if (grid == 0) return 0;
+    BY_KIND(j.kind, k_opt_touched, dim3(grid), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.a, j.sg, list, cnt, row_blocks, ds);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
+  const int64_t work = (j.n + 3) / 4;
   const int grid = (int)min((int64_t)(256 * 16), (work + 255) / 256);
-  hipStream_t st = (hipStream_t)stream;
-  if (kind == DCCF_OPT_GD) hipLaunchKernelGGL(k_dense_opt_rows<DCCF_OPT_GD>, dim3(grid), dim3(256), 0, st, p, g, s1, s2, n, a, sg);
-  else if (kind == DCCF_OPT_ADAGRAD) hipLaunchKernelGGL(k_dense_opt_rows<DCCF_OPT_ADAGRAD>, dim3(grid), dim3(256), 0, st, p, g, s1, s2, n, a, sg);
-  else hipLaunchKernelGGL(k_dense_opt_rows<DCCF_OPT_ADAM>, dim3(grid), dim3(256), 0, st, p, g, s1, s2, n, a, sg);
+  BY_KIND(j.kind, k_dense_opt_rows, dim3(grid), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.n, j.a, j.sg, phase);
   HIP_TRY(hipGetLastError());
   return 0;
+}
+
+static int opt_rows_impl(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t n, float lr, float wd, float l2,
+                         float clip, int64_t step, const int64_t* k_dev, int32_t nseg, const int64_t* seg_begin,
+                         const int64_t* seg_rows, const int32_t* seg_width, uint8_t* const* seg_flags, void* stream) {
+  OptJob j;
+  if (int e = make_job(kind, p, g, s1, s2, n, lr, wd, l2, clip, step, k_dev, nseg, seg_begin, seg_rows, seg_width, seg_flags, &j))
+    return e;
+  return launch_job(j, OPT_PHASE_ALL, nullptr, nullptr, 0, (hipStream_t)stream);
+}
+
+static int opt_job(const void* ov, OptJob* out) {
+  const dccf_opt_t* o = (const dccf_opt_t*)ov;
+  ARG_CHECK(o != nullptr, "opt is NULL");
+  return make_job(o->kind, o->p, o->g, o->s1, o->s2, o->n, o->lr, o->wd, o->l2, o->clip, o->step, nullptr, o->nseg,
+                  o->seg_begin, o->seg_rows, o->seg_width, o->seg_flags, out);
+}
+
+int dccf_opt_phase(const void* ov, int phase, const int64_t* list, const int* cnt, int64_t max_rows, hipStream_t st) {
+  OptJob j;
+  if (int e = opt_job(ov, &j)) return e;
+  return launch_job(j, phase, list, cnt, max_rows, st);
 }
 
 extern "C" int dccf_dense_opt_step_rows(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t n, float lr,

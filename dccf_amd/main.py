@@ -115,7 +115,7 @@ def main(argv=None):
     runner = runner_cls(optimizer=args.optimizer, learning_rate=args.lr, epoch=args.epoch, batch_size=args.batch_size,
                         eval_batch_size=args.eval_batch_size, dropout=args.dropout, l2=args.l2, metrics=args.metric,
                         check_epoch=args.check_epoch, early_stop=args.early_stop, fused_sampling=args.fused_sampling,
-                        use_graph=args.use_graph, device_eval=args.device_eval)
+                        use_graph=args.use_graph, device_eval=args.device_eval, overlap_opt=args.overlap_opt)
     logging.info('Test Before Training = ' + utils.format_metric(
         runner.evaluate(model, data_processor.get_test_data(), data_processor)) + ' ' + ','.join(runner.metrics))
     if args.load > 0:

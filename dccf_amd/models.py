@@ -365,8 +365,9 @@ class DCCF(DMF):
         self._modules = [_ParamModule('embedding', p['uid_embeddings.weight']), _ParamModule('embedding', p['iid_embeddings.weight']),
                          _ParamModule('linear', p['mlp.0.weight'], p['mlp.0.bias'])]
         # one "touched" byte per embedding row, set by the backward, consumed by the row-aware dense optimizer step
-        self.touchedU = torch.zeros(self.user_num, dtype=torch.uint8, device=self.device)
-        self.touchedV = torch.zeros(self.item_num, dtype=torch.uint8, device=self.device)
+        # (padded to whole 32-bit words: the overlapped step marks them with word atomics)
+        self.touchedU = torch.zeros((self.user_num + 3) // 4 * 4, dtype=torch.uint8, device=self.device)[:self.user_num]
+        self.touchedV = torch.zeros((self.item_num + 3) // 4 * 4, dtype=torch.uint8, device=self.device)[:self.item_num]
         D = self.ui_vector_size
         self.row_segments = [(self.offsets['uid_embeddings.weight'], self.user_num, D, self.touchedU),
                              (self.offsets['iid_embeddings.weight'], self.item_num, D, self.touchedV)]
@@ -406,6 +407,26 @@ class DCCF(DMF):
                                             feed_dict['Y'], feed_dict['rank'], feed_dict['dropout'],
                                             g['uid_embeddings.weight'], g['iid_embeddings.weight'], g['mlp.0.weight'],
                                             g['mlp.0.bias'], loss=self._loss, touchedU=self.touchedU, touchedV=self.touchedV)
+        return {'prediction': pred, 'check': [('prediction', pred)], 'loss': loss[0]}
+
+    def train_step(self, feed_dict, overlap=0):
+        """zero_grad + forward + backward + `+ l2` + clip + optimizer.step() of src/runners/BaseRunner.py:172-188 as ONE
+        library call (dccf_train_step).  ``overlap``: 0 = optimizer pass after the backward; 1 = the pass over the
+        embedding rows this batch does not touch runs on a side stream beside forward/backward.  Same arithmetic per
+        element either way."""
+        o = self.optimizer
+        key = (o.name, o.lr, o.l2, o.clip, int(overlap))
+        if getattr(self, '_opt_struct_key', None) != key:
+            self._opt_struct = _lib.opt_struct(o.name, self.flat_p, self.flat_g, o.s1, o.s2, o.lr, o.l2, o.l2, o.clip,
+                                               self.row_segments, overlap)
+            self._opt_struct_key = key
+        g = self.grads
+        o.t += 1
+        pred, loss = _lib.dccf_train_step(self.ctx, self._struct(), self._rand(feed_dict), feed_dict['X'].contiguous(),
+                                          feed_dict['Y'], feed_dict['rank'], feed_dict['dropout'],
+                                          g['uid_embeddings.weight'], g['iid_embeddings.weight'], g['mlp.0.weight'],
+                                          g['mlp.0.bias'], self._opt_struct, o.t, loss=self._loss, touchedU=self.touchedU,
+                                          touchedV=self.touchedV)
         return {'prediction': pred, 'check': [('prediction', pred)], 'loss': loss[0]}
 
 

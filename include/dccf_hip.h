@@ -121,6 +121,34 @@ int dccf_dense_opt_step(int32_t kind, float* p, float* g, float* s1, float* s2, 
 int dccf_dense_opt_step_rows(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t n, float lr, float wd,
                              float l2, float clip, int64_t step, int32_t nseg, const int64_t* seg_begin,
                              const int64_t* seg_rows, const int32_t* seg_width, uint8_t* const* seg_flags, void* stream);
+/* ---- ONE training step = the body of BaseRunner.fit's batch loop (src/runners/BaseRunner.py:172-188): forward, loss,
+ * backward, + l2, clip, optimizer step, zero_grad.  Same results, bit for bit, as dccf_train_fwdbwd followed by
+ * dccf_dense_opt_step_rows.  With overlap != 0 the optimizer pass over the rows this batch does NOT touch (all but a few
+ * thousand of the U/V rows: their gradient is the l2 term alone, independent of the batch) runs on the context's
+ * low-priority side stream WHILE forward/backward run on `stream`; the touched rows + W, b follow after the backward.
+ * Needs grads->touchedU / touchedV == the flags of the segments that hold model->U / model->V, 4-byte aligned and padded
+ * to a multiple of 4 bytes. */
+typedef struct {
+  int32_t kind;              /* DCCF_OPT_*                                                          */
+  int32_t overlap;
+  float* p;                  /* flat parameters; model->U/V/W/b point into it                         */
+  float* g;                  /* flat gradients;  grads->gU/... point into it                          */
+  float* s1;
+  float* s2;
+  int64_t n;
+  float lr, wd, l2, clip;
+  int64_t step;              /* 1-based                                                              */
+  int32_t nseg;
+  int32_t reserved;
+  const int64_t* seg_begin;  /* HOST arrays, as in dccf_dense_opt_step_rows                          */
+  const int64_t* seg_rows;
+  const int32_t* seg_width;
+  uint8_t* const* seg_flags;
+} dccf_opt_t;
+int dccf_train_step(dccf_ctx* ctx, const dccf_model_t* model, const dccf_rand_t* rnd, const int64_t* X, const float* Y,
+                    int64_t N, int32_t rank, float dropout, const dccf_grads_t* grads, const dccf_opt_t* opt,
+                    float* prediction, float* loss, void* stream);
+
 /* Graph-replayable form of the two calls above: the 1-based step is step + *k_dev (bias corrections computed on the
  * device); dccf_advance adds 1 to *k_dev (last node of a captured step). */
 int dccf_dense_opt_step_dev(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t n, float lr, float wd,

@@ -46,9 +46,11 @@ def test_cli_training_matches_reference_statistically(tmp_path):
     assert mine.shape == ref_valid.shape
     # training must move NDCG well above the untrained level, as it does in the reference
     assert mine[:, -1].mean() > ref_init.mean() + 0.5 * (ref_valid[:, -1].mean() - ref_init.mean())
-    # seed-averaged NDCG@5 per epoch: within 3 standard errors of the two seed-means + 2e-3
+    # seed-averaged NDCG@5 per epoch: within 3 standard errors of the two seed-means + 2e-3.  The per-seed spread of a
+    # 1.2k-user validation set is ~0.006-0.013 in the reference; a sample variance below that floor is luck, not precision
+    floor = 0.006 ** 2
     for e in range(mine.shape[1]):
-        se = np.sqrt(ref_valid[:, e].var(ddof=1) / len(seeds) + mine[:, e].var(ddof=1) / len(seeds))
+        se = np.sqrt(max(ref_valid[:, e].var(ddof=1), floor) / len(seeds) + max(mine[:, e].var(ddof=1), floor) / len(seeds))
         assert abs(mine[:, e].mean() - ref_valid[:, e].mean()) <= 3 * se + 2e-3, \
             'epoch %d: mine %.4f vs reference %.4f (se %.4f)' % (e + 1, mine[:, e].mean(), ref_valid[:, e].mean(), se)
     # artefacts with the reference's names and formats
