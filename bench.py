@@ -43,6 +43,9 @@ def parse():
     p.add_argument('--cpu_baseline', type=int, default=1)
     p.add_argument('--cpu_steps', type=int, default=60)
     p.add_argument('--seed', type=int, default=2019)
+    p.add_argument('--mp', type=str, default='replicated', help='multi-GPU layout: replicated (full model per GPU, one '
+                                                                'all-gather per step) | sharded (rows mod G, 4 collectives)')
+    p.add_argument('--force_replicated', type=int, default=0, help='run the replicated data-parallel pipeline even at --gpus 1')
     p.add_argument('--force_sharded', type=int, default=0, help='run the row-sharded pipeline even at --gpus 1')
     p.add_argument('--overlap', type=int, default=0, help='1: dccf_train_step with the untouched-row optimizer pass on a side '
                                                           'stream (see DESIGN.md: +5 %% only with DCCF_SIDE_CUS=128 --stream 1)')
@@ -97,7 +100,7 @@ def main():
     dev = torch.device('cuda', local)
     if args.stream:
         torch.cuda.set_stream(torch.cuda.Stream(device=dev))
-    if world > 1 or args.force_sharded:
+    if world > 1 or args.force_sharded or args.force_replicated:
         import torch.distributed as dist
         if world == 1:
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -105,8 +108,11 @@ def main():
             dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
         else:
             dist.init_process_group('nccl', device_id=dev)
-        from dccf_amd import sharded
-        return sharded.bench_main(args, rank, world, dev)
+        if args.mp == 'sharded' or args.force_sharded:
+            from dccf_amd import sharded
+            return sharded.bench_main(args, rank, world, dev)
+        from dccf_amd import replicated
+        return replicated.bench_main(args, rank, world, dev)
 
     from dccf_amd import _lib as L
     from dccf_amd.models import DCCF, FusedOptimizer

@@ -14,7 +14,8 @@ EXPORTS = ['dccf_ctx_create', 'dccf_ctx_destroy', 'dccf_ctx_reserve', 'dccf_last
            'dccf_predict', 'dccf_train_fwdbwd', 'dccf_dense_opt_step', 'dccf_sumsq', 'mf_predict', 'mf_train_fwdbwd',
            'mf_predict_full', 'dccf_sample_train_negatives', 'dccf_debug_candidates', 'dccf_debug_noise',
            'dccf_debug_keep', 'dccf_debug_workspace', 'dccf_profile', 'dccf_profile_read',
-           'shard_pack_rows', 'shard_unpack_rows', 'shard_scatter_add', 'dccf_dense_opt_step_rows', 'dccf_dense_opt_step_dev', 'dccf_advance', 'rank_eval_topk', 'dccf_train_step']
+           'shard_pack_rows', 'shard_unpack_rows', 'shard_scatter_add', 'dccf_dense_opt_step_rows', 'dccf_dense_opt_step_dev', 'dccf_advance', 'rank_eval_topk', 'dccf_train_step', 'dp_buffer_words',
+           'dp_export_touched', 'dp_import_touched']
 
 OPT_KIND = {'gd': 0, 'adagrad': 1, 'adam': 2}
 MF_KIND = {'RecModel': 0, 'BiasedMF': 1, 'IPSBiasedMF': 2}
@@ -85,6 +86,8 @@ def load():
         'dccf_dense_opt_step_dev': [i32, vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, vp, i32, C.POINTER(i64), C.POINTER(i64),
                                     C.POINTER(i32), C.POINTER(vp), vp],
         'dccf_advance': [vp, vp],
+        'dp_export_touched': [vp, i64, i32, vp, vp, vp, vp, i64, vp, vp, i64, i32, i32, vp],
+        'dp_import_touched': [vp, i32, vp, i64, i32, vp, vp, vp, vp, i64, vp, i64, i32, i32, vp, vp],
         'dccf_train_step': [vp, C.POINTER(ModelT), C.POINTER(RandT), vp, vp, i64, i32, f32, C.POINTER(GradsT),
                             C.POINTER(OptT), vp, vp, vp],
         'rank_eval_topk': [vp, vp, vp, vp, i64, C.POINTER(i32), vp, i32, vp, vp],
@@ -394,3 +397,29 @@ def rank_eval_topk(pred, label, indptr, rows, ks):
     check(load().rank_eval_topk(ptr(pred, torch.float32), ptr(label, torch.float32), ptr(indptr, torch.int64),
                                 ptr(rows, torch.int64), nu, ks_host, ptr(ks_dev, torch.int32), nk, ptr(out), stream()))
     return out
+
+
+def _seg_arrays(segments):
+    n = len(segments)
+    return (n, (C.c_int64 * n)(*[int(s[0]) for s in segments]), (C.c_int64 * n)(*[int(s[1]) for s in segments]),
+            (C.c_int32 * n)(*[int(s[2]) for s in segments]), (C.c_void_p * n)(*[ptr(s[3], torch.uint8) for s in segments]))
+
+
+def dp_buffer_words(cap, D, nd):
+    f = load().dp_buffer_words
+    f.restype, f.argtypes = C.c_int64, [C.c_int64, C.c_int32, C.c_int64]
+    return int(f(int(cap), int(D), int(nd)))
+
+
+def dp_export_touched(g, segments, dense_begin, loss, buf, cap, D, reset=True):
+    """Moves the touched gradient rows + the dense tail of flat `g` into this rank's all-gather buffer."""
+    n, beg, rows, wid, fl = _seg_arrays(segments)
+    check(load().dp_export_touched(ptr(g, torch.float32), g.numel(), n, beg, rows, wid, fl, int(dense_begin), ptr(loss),
+                                   ptr(buf, torch.float32), int(cap), int(D), 1 if reset else 0, stream()))
+
+
+def dp_import_touched(bufs, G, g, segments, dense_begin, loss_sum, cap, D, list_cap=0, reset_buf=None):
+    """g <- rank-ordered sum of the G gathered buffers (rows, dense tail); sets the touched bytes."""
+    n, beg, rows, wid, fl = _seg_arrays(segments)
+    check(load().dp_import_touched(ptr(bufs, torch.float32), int(G), ptr(g, torch.float32), g.numel(), n, beg, rows, wid, fl,
+                                   int(dense_begin), ptr(loss_sum), int(cap), int(D), int(list_cap), ptr(reset_buf), stream()))

@@ -1,0 +1,267 @@
+// dp_kernels.hip — gradient exchange of the replicated data-parallel path (dccf_amd/replicated.py): every GPU keeps the
+// whole model (16.4 M parameters + the 48.5 GB exposure matrix fit one MI355X many times over), trains its own pairs, and
+// the ranks exchange only what a step produced: the few thousand embedding rows its batch touched and the dense [dW|db].
+//
+//   dp_export_touched   compacts (row id, gradient row) of every row whose "touched" byte is set into this rank's slot of
+//                       the all-gather buffer, zeroes those rows of g and clears the bytes; copies (and zeroes) the dense
+//                       tail [dW | db] and the loss.
+//   dp_import_touched   after the all-gather: g[row] = sum over ranks IN RANK ORDER of the received rows (so that every
+//                       replica computes bit-identical sums and the replicas never drift apart), sets the "touched" bytes,
+//                       dense tail = sum over ranks in rank order.  No atomics on data: a workgroup owns the destination
+//                       rows with (row + segment) mod #workgroups == its index.
+//
+// Buffer of one rank (32-bit words): [count | loss | pad pad | ids int64[cap] | rows fp32[cap][D] | dense fp32[nd]].
+#include "common.hpp"
+#include "opt_device.hpp"
+
+#define DP_HDR 4
+#define DP_GMAX 16
+#define DP_LCAP 64
+
+struct DpLay {
+  int64_t cap, nd, ids_off, rows_off, dense_off, words;
+  int D;
+};
+static DpLay dp_layout(int64_t cap, int D, int64_t nd) {
+  DpLay y;
+  y.cap = cap; y.D = D; y.nd = nd;
+  y.ids_off = DP_HDR;
+  y.rows_off = y.ids_off + 2 * cap;
+  y.dense_off = y.rows_off + cap * D;
+  y.words = (y.dense_off + nd + 3) / 4 * 4;
+  return y;
+}
+
+extern "C" int64_t dp_buffer_words(int64_t cap, int32_t D, int64_t nd) { return dp_layout(cap, D, nd).words; }
+
+// ---------------------------------------------------------------------------------------------- export
+// A wave looks at 256 consecutive flag bytes of one segment (one 32-bit word per lane): a wave-wide prefix sum places its
+// set bytes behind ONE atomicAdd on the buffer's counter, then 16-lane groups ship four rows at a time (float4 columns).
+__global__ __launch_bounds__(256) void k_dp_export(float* __restrict__ g, RowSegs sg, int64_t dense_begin, const float* loss,
+                                                   float* __restrict__ buf, DpLay y, int scan_blocks) {
+  __shared__ int wl[4][256];                  // per wave: the rows found in the current chunk
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int* count = reinterpret_cast<int*>(buf);
+  int64_t* ids = reinterpret_cast<int64_t*>(buf + y.ids_off);
+  float* rows = buf + y.rows_off;
+  if ((int)blockIdx.x >= scan_blocks) {       // dense tail + loss
+    const int64_t tid = (int64_t)(blockIdx.x - scan_blocks) * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)(gridDim.x - scan_blocks) * blockDim.x;
+    for (int64_t i = tid; i < y.nd; i += stride) {
+      buf[y.dense_off + i] = g[dense_begin + i];
+      g[dense_begin + i] = 0.f;
+    }
+    if (tid == 0) buf[1] = loss ? loss[0] : 0.f;
+    return;
+  }
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)scan_blocks * blockDim.x) >> 6;
+  const int d4 = y.D >> 2, grp = lane >> 4, sub = lane & 15;
+  for (int q = 0; q < sg.n; ++q) {
+    const int64_t nrows = (sg.end[q] - sg.begin[q]) / sg.width[q];
+    const int64_t nwords = (nrows + 3) / 4;          // flag arrays are padded to whole words (zeros)
+    uint32_t* fw = reinterpret_cast<uint32_t*>(sg.flags[q]);
+    for (int64_t w0 = wave * 64; w0 < nwords; w0 += nw * 64) {
+      const int64_t wi = w0 + lane;
+      const uint32_t word = wi < nwords ? fw[wi] : 0u;
+      if (__ballot(word != 0) == 0) continue;
+      int mine = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) mine += ((word >> (8 * b)) & 0xffu) != 0;
+      int incl = mine;                               // inclusive prefix sum over the lanes
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+      }
+      const int total = __shfl(incl, 63, 64);
+      int base = 0;
+      if (lane == 0) base = atomicAdd(count, total);
+      base = __shfl(base, 0, 64);
+      int k = incl - mine;
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        if (((word >> (8 * b)) & 0xffu) != 0) {
+          const int64_t row = wi * 4 + b;
+          wl[wv][k] = (int)(row - w0 * 4);
+          if (base + k < y.cap) ids[base + k] = ((int64_t)q << 40) | row;
+          ++k;
+        }
+      if (word != 0) fw[wi] = 0u;                    // the bytes are consumed
+      __builtin_amdgcn_wave_barrier();
+      for (int t0 = 0; t0 < total; t0 += 4) {
+        const int t = t0 + grp;
+        if (t < total && base + t < y.cap) {
+          const int64_t row = w0 * 4 + wl[wv][t];
+          float4* grow = reinterpret_cast<float4*>(g + sg.begin[q] + row * sg.width[q]);
+          float4* dst = reinterpret_cast<float4*>(rows + (int64_t)(base + t) * y.D);
+          for (int c = sub; c < d4; c += 16) {
+            dst[c] = grow[c];
+            grow[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+extern "C" int dp_export_touched(float* g, int64_t n, int32_t nseg, const int64_t* seg_begin, const int64_t* seg_rows,
+                                 const int32_t* seg_width, uint8_t* const* seg_flags, int64_t dense_begin, const float* loss,
+                                 float* buf, int64_t cap, int32_t D, int32_t reset, void* stream) {
+  ARG_CHECK(g && buf && nseg >= 1 && nseg <= 4 && seg_begin && seg_rows && seg_width && seg_flags, "NULL / bad segments");
+  ARG_CHECK(cap >= 1 && dense_begin >= 0 && dense_begin <= n, "bad cap / dense_begin");
+  RowSegs sg;
+  memset(&sg, 0, sizeof(sg));
+  sg.n = nseg;
+  int64_t max_rows = 0;
+  for (int q = 0; q < nseg; ++q) {
+    ARG_CHECK(seg_width[q] == D, "every row segment must have width D");
+    ARG_CHECK(seg_flags[q] && (uintptr_t)seg_flags[q] % 4 == 0, "flags must be 4-byte aligned (and padded to whole words)");
+    ARG_CHECK(seg_begin[q] + seg_rows[q] * D <= dense_begin, "row segments must lie below dense_begin");
+    sg.begin[q] = seg_begin[q];
+    sg.end[q] = seg_begin[q] + seg_rows[q] * D;
+    sg.width[q] = D;
+    sg.flags[q] = seg_flags[q];
+    max_rows = max(max_rows, seg_rows[q]);
+  }
+  const DpLay y = dp_layout(cap, D, n - dense_begin);
+  hipStream_t st = (hipStream_t)stream;
+  ARG_CHECK(D % 4 == 0, "D must be a multiple of 4");
+  if (reset) HIP_TRY(hipMemsetAsync(buf, 0, DP_HDR * sizeof(float), st));     // else: dp_import_touched(reset_buf) did it
+  const int scan_blocks = (int)max((int64_t)1, min((int64_t)1024, (max_rows / 4 + 255) / 256));
+  const int dense_blocks = (int)max((int64_t)1, min((int64_t)256, (y.nd + 255) / 256));
+  hipLaunchKernelGGL(k_dp_export, dim3(scan_blocks + dense_blocks), dim3(256), 0, st, g, sg, dense_begin, loss, buf, y,
+                     scan_blocks);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- import
+__global__ __launch_bounds__(256) void k_dp_import(const float* __restrict__ bufs, int G, float* __restrict__ g, RowSegs sg,
+                                                   int64_t dense_begin, float* __restrict__ loss_sum, DpLay y, int row_blocks,
+                                                   int lcap, float* reset_buf) {
+  __shared__ int64_t lid[DP_GMAX][DP_LCAP];      // ids of the entries this workgroup owns, per source rank
+  __shared__ int lent[DP_GMAX][DP_LCAP];         // their entry index in the rank's buffer
+  __shared__ int lcnt[DP_GMAX];
+  __shared__ int overflow;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if ((int)blockIdx.x >= row_blocks) {           // dense tail: sum in rank order
+    const int64_t tid = (int64_t)(blockIdx.x - row_blocks) * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)(gridDim.x - row_blocks) * blockDim.x;
+    for (int64_t i = tid; i < y.nd; i += stride) {
+      float s = bufs[y.dense_off + i];
+      for (int r = 1; r < G; ++r) s += bufs[(int64_t)r * y.words + y.dense_off + i];
+      g[dense_begin + i] = s;
+    }
+    if (tid == 0 && reset_buf) reinterpret_cast<int*>(reset_buf)[0] = 0;      // the local export buffer's counter
+    if (tid == 0 && loss_sum) {
+      float s = bufs[1];
+      for (int r = 1; r < G; ++r) s += bufs[(int64_t)r * y.words + 1];
+      loss_sum[0] = s;
+    }
+    return;
+  }
+  if (threadIdx.x < DP_GMAX) lcnt[threadIdx.x] = 0;
+  if (threadIdx.x == 0) overflow = 0;
+  __syncthreads();
+  // 1. collect the entries whose destination row this workgroup owns
+  for (int r = 0; r < G; ++r) {
+    const float* b = bufs + (int64_t)r * y.words;
+    const int n = min((int64_t)reinterpret_cast<const int*>(b)[0], y.cap);
+    const int64_t* ids = reinterpret_cast<const int64_t*>(b + y.ids_off);
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+      const int64_t id = ids[e];
+      if ((int)(((id & ((1LL << 40) - 1)) + (id >> 40)) % row_blocks) == (int)blockIdx.x) {
+        const int pos = atomicAdd(&lcnt[r], 1);
+        if (pos < lcap) { lid[r][pos] = id; lent[r][pos] = e; }
+        else overflow = 1;
+      }
+    }
+  }
+  __syncthreads();
+  if (overflow) {
+    // slow but order-preserving fallback (a list did not fit): rank after rank, re-scanning the ids
+    for (int r = 0; r < G; ++r) {
+      const float* b = bufs + (int64_t)r * y.words;
+      const int n = min((int64_t)reinterpret_cast<const int*>(b)[0], y.cap);
+      const int64_t* ids = reinterpret_cast<const int64_t*>(b + y.ids_off);
+      for (int e = wave; e < n; e += 4) {
+        const int64_t id = ids[e];
+        const int q = (int)(id >> 40);
+        const int64_t row = id & ((1LL << 40) - 1);
+        if ((int)((row + q) % row_blocks) != (int)blockIdx.x) continue;
+        float* grow = g + sg.begin[q] + row * sg.width[q];
+        for (int c = lane; c < y.D; c += 64) grow[c] += b[y.rows_off + (int64_t)e * y.D + c];
+        if (lane == 0) sg.flags[q][row] = 1;
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  // 2. every owned entry looks for the same row in lower ranks (then it is not the leader) and, as leader, adds the
+  //    matching rows of the higher ranks in rank order
+  int total = 0;
+  for (int r = 0; r < G; ++r) total += lcnt[r];
+  for (int t = wave; t < total; t += 4) {
+    int r = 0, j = t;
+    while (j >= lcnt[r]) { j -= lcnt[r]; ++r; }
+    const int64_t id = lid[r][j];
+    bool dup = false;
+    for (int r2 = 0; r2 < r && !dup; ++r2)
+      for (int k0 = 0; k0 < lcnt[r2]; k0 += 64) {
+        const bool hit = k0 + lane < lcnt[r2] && lid[r2][k0 + lane] == id;
+        if (__ballot(hit)) { dup = true; break; }
+      }
+    if (dup) continue;
+    const int q = (int)(id >> 40);
+    const int64_t row = id & ((1LL << 40) - 1);
+    float acc[2] = {0.f, 0.f};                        // D <= 128: two columns per lane
+    {
+      const float* src = bufs + (int64_t)r * y.words + y.rows_off + (int64_t)lent[r][j] * y.D;
+      for (int c = lane, i = 0; c < y.D; c += 64, ++i) acc[i] = src[c];
+    }
+    for (int r2 = r + 1; r2 < G; ++r2) {
+      int found = -1;
+      for (int k0 = 0; k0 < lcnt[r2] && found < 0; k0 += 64) {
+        const bool hit = k0 + lane < lcnt[r2] && lid[r2][k0 + lane] == id;
+        const uint64_t m = __ballot(hit);
+        if (m) found = k0 + __ffsll((unsigned long long)m) - 1;
+      }
+      if (found >= 0) {
+        const float* src = bufs + (int64_t)r2 * y.words + y.rows_off + (int64_t)lent[r2][found] * y.D;
+        for (int c = lane, i = 0; c < y.D; c += 64, ++i) acc[i] += src[c];
+      }
+    }
+    float* grow = g + sg.begin[q] + row * sg.width[q];
+    for (int c = lane, i = 0; c < y.D; c += 64, ++i) grow[c] = acc[i];     // the row was zero: exported rows are zeroed
+    if (lane == 0) sg.flags[q][row] = 1;
+  }
+}
+
+extern "C" int dp_import_touched(const float* bufs, int32_t G, float* g, int64_t n, int32_t nseg, const int64_t* seg_begin,
+                                 const int64_t* seg_rows, const int32_t* seg_width, uint8_t* const* seg_flags,
+                                 int64_t dense_begin, float* loss_sum, int64_t cap, int32_t D, int32_t list_cap,
+                                 float* reset_buf, void* stream) {
+  ARG_CHECK(bufs && g && G >= 1 && G <= DP_GMAX, "1..16 ranks");
+  ARG_CHECK(nseg >= 1 && nseg <= 4 && seg_begin && seg_rows && seg_width && seg_flags, "bad segments");
+  ARG_CHECK(D >= 1 && D <= 128 && cap >= 1 && dense_begin >= 0 && dense_begin <= n, "bad D / cap / dense_begin");
+  ARG_CHECK(list_cap >= 0 && list_cap <= DP_LCAP, "list_cap in [0, 64] (0 = default)");
+  RowSegs sg;
+  memset(&sg, 0, sizeof(sg));
+  sg.n = nseg;
+  for (int q = 0; q < nseg; ++q) {
+    ARG_CHECK(seg_width[q] == D && seg_flags[q], "every row segment must have width D and flags");
+    sg.begin[q] = seg_begin[q];
+    sg.end[q] = seg_begin[q] + seg_rows[q] * D;
+    sg.width[q] = D;
+    sg.flags[q] = seg_flags[q];
+  }
+  const DpLay y = dp_layout(cap, D, n - dense_begin);
+  // about 4 owned entries per (workgroup, rank): lists of 64 overflow only in adversarial cases (handled, slowly)
+  const int row_blocks = (int)max((int64_t)64, min((int64_t)2048, cap / 4));
+  const int dense_blocks = (int)max((int64_t)1, min((int64_t)256, (y.nd + 255) / 256));
+  hipLaunchKernelGGL(k_dp_import, dim3(row_blocks + dense_blocks), dim3(256), 0, (hipStream_t)stream, bufs, G, g, sg,
+                     dense_begin, loss_sum, y, row_blocks, list_cap > 0 ? list_cap : DP_LCAP, reset_buf);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,222 @@
+# coding=utf-8
+"""Replicated data-parallel DCCF training across the GPUs of one node (the default of ``bench.py --gpus N``).
+
+The reference is single-GPU (src/main.py:106,153-155); this is new capability with no reference counterpart.
+
+MI355X-first partitioning: nothing is sharded.  The whole model is 16.4 M parameters (66 MB; 197 MB with Adam's state),
+the frozen tables are 193 MB (768-d features) + 48.5 GB (dense exposure matrix) at Electronics size — a 288 GB GPU holds
+all of it, so every rank keeps a full replica and the per-step exchange shrinks to what a step PRODUCES:
+
+  * each rank runs the unchanged single-GPU forward/backward kernels on its own ``batch_size`` pairs (one process per GPU,
+    ``torch.distributed`` backend "nccl" = RCCL over xGMI); Philox step word = t * G + rank, so the ranks draw
+    independent candidates / noise / dropout;
+  * ``dp_export_touched`` compacts the ~3 k embedding rows the batch touched (row id + gradient row) and the dense
+    ``[dW | db]`` (213 KB) into ONE buffer (~1 MB at batch 128);
+  * ONE collective per step: ``all_gather_into_tensor`` of those buffers;
+  * ``dp_import_touched`` sums the G buffers into the local flat gradient IN RANK ORDER (no float atomics), so every
+    replica holds bit-identical gradients and, after the same dense regularised Adam pass, bit-identical parameters —
+    replicas cannot drift, no parameter broadcast is ever needed.
+
+One optimizer step therefore sees the sum of the G ranks' BPR terms: exactly the reference's step at batch size G * B
+(loss = -sum log sigmoid, src/models/DCCF.py:116-120).  The row-sharded alternative (dccf_amd/sharded.py) is for tables
+that do not fit one GPU; it needs 4 collectives per step instead of 1.
+"""
+import torch
+import torch.distributed as dist
+
+
+class HipBackend(object):
+    """The product backend: libdccf_hip.so through dccf_amd._lib.  The argument blocks of the four library calls of a step
+    are built once (`prepare`): a step at batch 128 is ~150 us of GPU work, the host must stay well below that."""
+
+    def __init__(self, device):
+        from dccf_amd import _lib
+        self.L = _lib
+        self.device = device
+        self.ctx = _lib.Context(device.index or 0)
+        self.ready = None
+
+    def prepare(self, tr):
+        import ctypes as C
+        L = self.L
+        lib = L.load()
+        f32, u8 = torch.float32, torch.uint8
+        self.m = L.model_struct(tr.U, tr.V, tr.W, tr.b, tr.feat, tr.expo, tr.S, tr.A, tr.std, ips=tr.ips)
+        self.r = L.rand_struct(seed=tr.seed, step=0)
+        self.g = L.GradsT(L.ptr(tr.gU), L.ptr(tr.gV), L.ptr(tr.gW), L.ptr(tr.gb), L.ptr(tr.tU, u8), L.ptr(tr.tV, u8))
+        self.seg = L._seg_arrays(tr.segments)
+        self.mp, self.rp, self.gp = C.byref(self.m), C.byref(self.r), C.byref(self.g)
+        self.a_export = (L.ptr(tr.flat_g, f32), tr.flat_g.numel()) + self.seg + (
+            int(tr.dense_begin), L.ptr(tr.loss, f32), L.ptr(tr.buf, f32), int(tr.cap), int(tr.D), 0)
+        self.a_import = (L.ptr(tr.bufs, f32), int(tr.G), L.ptr(tr.flat_g, f32), tr.flat_g.numel()) + self.seg + (
+            int(tr.dense_begin), L.ptr(tr.loss_sum, f32), int(tr.cap), int(tr.D), 0, L.ptr(tr.buf, f32))
+        self.a_opt = (L.OPT_KIND['adam'], L.ptr(tr.flat_p, f32), L.ptr(tr.flat_g, f32), L.ptr(tr.s1, f32), L.ptr(tr.s2, f32),
+                      tr.flat_p.numel(), float(tr.lr), float(tr.l2), float(tr.l2), 50.0)
+        self.f_fwbw, self.f_export, self.f_import, self.f_opt = (lib.dccf_train_fwdbwd, lib.dp_export_touched,
+                                                                 lib.dp_import_touched, lib.dccf_dense_opt_step_rows)
+        self.ready = tr
+
+    def local_step(self, tr, X, Y, step, pred):
+        if self.ready is not tr:
+            self.prepare(tr)
+        if pred is None:
+            pred = torch.empty(X.shape[0], dtype=torch.float32, device=X.device)
+        self.r.step = step
+        self.L.check(self.f_fwbw(self.ctx.h, self.mp, self.rp, self.L.ptr(X, torch.int64), self.L.ptr(Y, torch.float32),
+                                 X.shape[0], 1, tr.dropout, self.gp, self.L.ptr(pred, torch.float32), tr.loss.data_ptr(),
+                                 self.L.stream()))
+        return pred, tr.loss
+
+    def export(self, tr):
+        self.L.check(self.f_export(*self.a_export, self.L.stream()))
+
+    def import_(self, tr):
+        self.L.check(self.f_import(*self.a_import, self.L.stream()))
+
+    def opt_step(self, tr):
+        self.L.check(self.f_opt(*self.a_opt, tr.t, *self.seg, self.L.stream()))
+
+
+class ReplicatedDCCF(object):
+    def __init__(self, rank, world, user_num, item_num, D, S, A, std, dropout, lr, l2, seed, backend, device, feat,
+                 expo=None, ips=None, max_rows=256, group=None):
+        """feat [item_num, F]; expo [user_num, item_num] or ips (dict of IPSBiasedMF factors) — full tables, identical on
+        every rank.  max_rows: the largest 2B a step will see (sizes the all-gather buffer)."""
+        self.rank, self.G, self.group, self.dev, self.be = rank, world, group, device, backend
+        self.user_num, self.item_num, self.D, self.S, self.A = user_num, item_num, D, S, A
+        self.std, self.dropout, self.lr, self.l2, self.seed = std, dropout, lr, l2, seed
+        self.feat, self.expo, self.ips = feat, expo, ips
+        F = feat.shape[1]
+        sizes = [user_num * D, item_num * D, D * (D + F), D]
+        pads = [(n + 255) // 256 * 256 for n in sizes]
+        f32 = torch.float32
+        self.flat_p = torch.zeros(sum(pads), dtype=f32, device=device)
+        self.flat_g = torch.zeros_like(self.flat_p)
+        self.s1, self.s2 = torch.zeros_like(self.flat_p), torch.zeros_like(self.flat_p)
+        o, views, gviews, offs = 0, [], [], []
+        for n, pd, shp in zip(sizes, pads, [(user_num, D), (item_num, D), (D, D + F), (D,)]):
+            views.append(self.flat_p[o:o + n].view(shp))
+            gviews.append(self.flat_g[o:o + n].view(shp))
+            offs.append(o)
+            o += pd
+        self.U, self.V, self.W, self.b = views
+        self.gU, self.gV, self.gW, self.gb = gviews
+        u8 = torch.uint8
+        self.tU = torch.zeros((user_num + 3) // 4 * 4, dtype=u8, device=device)[:user_num]     # whole 32-bit words
+        self.tV = torch.zeros((item_num + 3) // 4 * 4, dtype=u8, device=device)[:item_num]
+        self.segments = [(offs[0], user_num, D, self.tU), (offs[1], item_num, D, self.tV)]
+        self.dense_begin = offs[2]
+        self.cap = max_rows * (S + 2)                       # users + true items + S candidates per row, at most
+        self.words = self._buffer_words(self.cap, D, self.flat_p.numel() - self.dense_begin)
+        self.buf = torch.zeros(self.words, dtype=f32, device=device)
+        self.bufs = torch.zeros(world * self.words, dtype=f32, device=device)
+        self.loss = torch.zeros(1, dtype=f32, device=device)
+        self.loss_sum = torch.zeros(1, dtype=f32, device=device)
+        self.t = 0
+
+    @staticmethod
+    def _buffer_words(cap, D, nd):
+        return (4 + 2 * cap + cap * D + nd + 3) // 4 * 4     # == dp_buffer_words (include/dccf_hip.h)
+
+    def init_params(self, std=0.01):
+        """BaseModel.init_paras (src/models/BaseModel.py:130-142): N(0, 0.01); the SAME values on every rank."""
+        g = torch.Generator(device=self.dev).manual_seed(self.seed * 7919 + 7)
+        for t in (self.U, self.V, self.W, self.b):
+            t.normal_(0.0, std, generator=g)
+
+    def set_params(self, U, V, W, b):
+        for dst, src in ((self.U, U), (self.V, V), (self.W, W), (self.b, b)):
+            dst.copy_(src)
+
+    def train_step(self, X, Y, pred=None):
+        """X int64 [2B, 2] = this rank's [positives ; negatives]; one optimizer step over the G ranks' batches.
+        Returns (prediction of this rank's rows, loss summed over the ranks)."""
+        be = self.be
+        pred, _ = be.local_step(self, X, Y, self.t * self.G + self.rank, pred)
+        be.export(self)
+        if self.G > 1:
+            dist.all_gather_into_tensor(self.bufs, self.buf, group=self.group)       # the step's only collective
+        else:
+            self.bufs.copy_(self.buf)
+        be.import_(self)
+        self.t += 1
+        be.opt_step(self)
+        return pred, self.loss_sum
+
+
+# ------------------------------------------------------------------------------------------------------ bench entry
+def bench_main(args, rank, world, dev):
+    """bench.py --gpus N (N > 1): weak scaling — every rank trains `batch_size` pairs per step on a full replica."""
+    import json
+    import time
+    from dccf_amd.data_processor import DeviceTrainSet
+    from bench import synthetic_interactions
+    U, I, D, F, B = args.users, args.items, args.dim, args.feat, args.batch_size
+    S, A = 10, 2
+    be = HipBackend(dev)
+    g = torch.Generator(device=dev).manual_seed(args.seed)          # same tables on every rank
+    feat = torch.randn(I, F, generator=g, device=dev) * 0.05
+    expo_mode = args.expo
+    if expo_mode == 'auto':
+        expo_mode = 'dense' if U * I * 4 < 160e9 else 'factors'
+    expo, ips = None, None
+    if expo_mode == 'dense':
+        expo = torch.empty(U, I, device=dev)
+        rows = max(1, (1 << 30) // (4 * I))
+        for r0 in range(0, U, rows):
+            expo[r0:r0 + rows].normal_(generator=g)
+    else:
+        ips = dict(P=torch.randn(U, 64, generator=g, device=dev) * 0.1, Q=torch.randn(I, 64, generator=g, device=dev) * 0.1,
+                   bu=torch.randn(U, generator=g, device=dev) * 0.1, bi=torch.randn(I, generator=g, device=dev) * 0.1,
+                   prop=torch.rand(I, generator=g, device=dev), b0=0.1, M=0.1)
+    tr = ReplicatedDCCF(rank, world, U, I, D, S, A, 0.1, 0.2, 1e-3, 1e-4, args.seed, be, dev, feat, expo=expo, ips=ips,
+                        max_rows=2 * B)
+    tr.init_params()
+    be.ctx.reserve(2 * B, D, F, S, A)
+    n_steps = args.steps + args.warmup
+    n_pairs = (n_steps + 2) * B * world
+    uid, iid = synthetic_interactions(int(n_pairs * 1.15) + 1000, U, I, args.seed)      # replicated train set
+    ds = DeviceTrainSet(uid[:n_pairs], iid[:n_pairs], U, I, args.seed)
+    y = torch.cat([torch.ones(B, device=dev), torch.zeros(B, device=dev)])
+    pred = torch.empty(2 * B, device=dev)
+
+    def schedule(e, n):
+        full, _ = ds.epoch_batches(e, B)                       # same permutation / negatives on every rank
+        return full[:n * world].view(n, world, 2 * B, 2)[:, rank].contiguous()     # step k: rank r trains full[k*world + r]
+
+    mine = schedule(0, args.warmup)
+    for k in range(args.warmup):
+        tr.train_step(mine[k], y, pred)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    mine = schedule(1, args.steps)                             # the epoch's negative sampling is timed
+    for k in range(args.steps):
+        tr.train_step(mine[k], y, pred)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt)
+    # replicas must be bit-identical: compare a checksum of the parameters across ranks (outside the timed region)
+    chk = torch.stack([tr.flat_p.double().sum(), tr.flat_p.double().abs().sum()])
+    lo, hi = chk.clone(), chk.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        out = {'metric': 'train pairs/sec at rank=64 Electronics', 'value': round(args.steps * B * world / dt, 1),
+               'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+               'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+               'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': 'DCCF train step (fwd + BPR + bwd + dense l2/clip/Adam), Electronics-shaped synthetic: '
+                                      'user_num=%d item_num=%d D=%d F=%d S=%d A=%d, exposure=%s, full replica per GPU, fused '
+                                      'on-device negatives' % (U, I, D, F, S, A, expo_mode),
+                          'batch_size_per_gpu': B, 'global_batch': B * world, 'optimizer': 'Adam lr=1e-3 l2=1e-4 dropout=0.2',
+                          'collectives_per_step': 'all_gather x1 (touched gradient rows + [dW|db], %.2f MB per rank)'
+                                                  % (tr.words * 4 / 1e6),
+                          'replicas_bit_identical': bool(torch.equal(lo, hi))},
+               'roofline': None, 'cpu_baseline': None}
+        print(json.dumps(out), flush=True)
+    dist.destroy_process_group()

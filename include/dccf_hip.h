@@ -198,6 +198,26 @@ int dccf_sample_train_negatives(const int64_t* rows_indptr, const int64_t* rows,
 int rank_eval_topk(const float* pred, const float* label, const int64_t* indptr, const int64_t* rows, int64_t n_users,
                    const int32_t* ks_host, const int32_t* ks_dev, int32_t nk, float* out, void* stream);
 
+/* ---- gradient exchange of the replicated data-parallel path (dccf_amd/replicated.py; new capability, the reference is
+ * single-GPU: src/main.py:106,153-155).  Every rank holds the whole model; per step the ranks all-gather ONE buffer each:
+ *   32-bit words [count | loss | 0 0 | ids int64[cap] | rows fp32[cap][D] | dense fp32[n - dense_begin]]
+ * dp_export_touched fills this rank's buffer from its local gradient: every row whose "touched" byte is set (segments as
+ * in dccf_dense_opt_step_rows, all of width D, flags 4-byte aligned and zero-padded to whole words) is moved out of g
+ * (the row is zeroed, the byte cleared), id = (segment << 40) | row; the dense tail g[dense_begin:n] ([dW | db]) is moved
+ * too, *loss copied.  dp_import_touched takes the G gathered buffers and leaves in g, for every listed row, the sum of the
+ * ranks' rows IN RANK ORDER (bit-identical on every replica, no float atomics), sets the bytes again and sums the dense
+ * tails and losses in rank order — g is then exactly what one GPU would hold after a backward over the G batches, and
+ * dccf_dense_opt_step_rows finishes the step.  list_cap: 0 (default 64), smaller values only to test the fallback.
+ * The export appends behind the counter in buf[0]: reset != 0 zeroes it first (one more launch); a training loop passes its
+ * local buffer as reset_buf to the import instead, which zeroes the counter for the next step's export. */
+int64_t dp_buffer_words(int64_t cap, int32_t D, int64_t nd);
+int dp_export_touched(float* g, int64_t n, int32_t nseg, const int64_t* seg_begin, const int64_t* seg_rows,
+                      const int32_t* seg_width, uint8_t* const* seg_flags, int64_t dense_begin, const float* loss, float* buf,
+                      int64_t cap, int32_t D, int32_t reset, void* stream);
+int dp_import_touched(const float* bufs, int32_t G, float* g, int64_t n, int32_t nseg, const int64_t* seg_begin,
+                      const int64_t* seg_rows, const int32_t* seg_width, uint8_t* const* seg_flags, int64_t dense_begin,
+                      float* loss_sum, int64_t cap, int32_t D, int32_t list_cap, float* reset_buf, void* stream);
+
 /* ---- row movers of the row-sharded multi-GPU path (dccf_amd/sharded.py; no reference counterpart — the reference is
  * single-GPU, src/main.py:106,153-155).  `tables` / `widths` are HOST arrays of up to 4 device pointers / row widths. */
 /* out[dst[j] (j when dst is NULL), 0:sum(widths)] = [T0[idx[j], :] | T1[idx[j], :] | ...]; payload rows are ld floats

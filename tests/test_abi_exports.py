@@ -10,7 +10,7 @@ from conftest import REPO
 def header_functions():
     src = open(os.path.join(REPO, 'include', 'dccf_hip.h')).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
-    return sorted(set(re.findall(r'^(?:int|const char\*)\s+(\w+)\s*\(', src, flags=re.M)))
+    return sorted(set(re.findall(r'^(?:int|int64_t|const char\*)\s+(\w+)\s*\(', src, flags=re.M)))
 
 
 def test_library_exports_every_declared_symbol():

@@ -1,0 +1,111 @@
+# coding=utf-8
+"""GPU: the gradient exchange kernels of the replicated data-parallel path (dp_export_touched / dp_import_touched) and the
+trainer at world size 1 over RCCL (the N > 1 logic runs in tests/test_replicated_gloo.py on the CPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def make_state(U, I, D, nd_extra, touchedU, touchedV, seed):
+    rng = np.random.RandomState(seed)
+    sizes = [U * D, I * D, nd_extra]
+    pads = [(n + 255) // 256 * 256 for n in sizes]
+    g = torch.zeros(sum(pads), device='cuda')
+    offs = np.cumsum([0] + pads[:-1])
+    tU = torch.zeros((U + 3) // 4 * 4, dtype=torch.uint8, device='cuda')[:U]
+    tV = torch.zeros((I + 3) // 4 * 4, dtype=torch.uint8, device='cuda')[:I]
+    gU, gV = g[:U * D].view(U, D), g[offs[1]:offs[1] + I * D].view(I, D)
+    for t, gv, rows in ((tU, gU, touchedU), (tV, gV, touchedV)):
+        rows = torch.as_tensor(rows, device='cuda', dtype=torch.int64)
+        t[rows] = 1
+        gv[rows] = torch.as_tensor(rng.randn(len(rows), D).astype(np.float32), device='cuda')
+    g[offs[2]:] = torch.as_tensor(rng.randn(pads[2]).astype(np.float32), device='cuda')
+    segs = [(int(offs[0]), U, D, tU), (int(offs[1]), I, D, tV)]
+    return g, segs, int(offs[2]), tU, tV
+
+
+@pytest.mark.parametrize('D,list_cap', [(64, 0), (16, 0), (128, 0), (64, 2)])
+def test_export_import_rank_ordered_sum(D, list_cap):
+    """G = 5 simulated ranks with overlapping touched sets: import == sum of the ranks' gradients in rank order, flags
+    set exactly on the union, exported gradients zeroed.  list_cap = 2 forces the order-preserving fallback."""
+    from dccf_amd import _lib as L
+    U, I, G, cap, nd = 1001, 777, 5, 600, 1000
+    rng = np.random.RandomState(3)
+    words = L.dp_buffer_words(cap, D, 1024)
+    bufs = torch.zeros(G * words, device='cuda')
+    want = None
+    union_u, union_v = set(), set()
+    for r in range(G):
+        tu = rng.choice(U, 150, replace=False)
+        tv = rng.choice(I, 400, replace=False)        # 5 x 400 of 777: heavy overlap between the ranks
+        if r == 1:
+            tu = np.r_[tu[:-2], [U - 1, U - 2]]       # last rows: the padded flag word
+            tu = np.unique(tu)
+        union_u |= set(tu.tolist())
+        union_v |= set(tv.tolist())
+        g, segs, dense_begin, tU, tV = make_state(U, I, D, nd, tu, tv, 10 + r)
+        ref = g.clone()
+        loss = torch.tensor([1.5 + r], device='cuda')
+        L.dp_export_touched(g, segs, dense_begin, loss, bufs[r * words:(r + 1) * words], cap, D)
+        torch.cuda.synchronize()
+        assert float(g.abs().max()) == 0.0 and int(tU.sum()) == 0 and int(tV.sum()) == 0
+        cnt = int(bufs[r * words:r * words + 1].view(torch.int32)[0])
+        assert cnt == len(tu) + len(tv)
+        want = ref if want is None else want + ref      # rank order: ((r0 + r1) + r2) + ...
+    g, segs, dense_begin, tU, tV = make_state(U, I, D, nd, [], [], 99)
+    g.zero_()
+    loss_sum = torch.zeros(1, device='cuda')
+    L.dp_import_touched(bufs, G, g, segs, dense_begin, loss_sum, cap, D, list_cap=list_cap)
+    torch.cuda.synchronize()
+    assert torch.equal(g, want)                          # bit-exact: same order of additions
+    assert sorted(torch.nonzero(tU).flatten().tolist()) == sorted(union_u)
+    assert sorted(torch.nonzero(tV).flatten().tolist()) == sorted(union_v)
+    assert float(loss_sum) == pytest.approx(sum(1.5 + r for r in range(G)))
+
+
+def test_replicated_trainer_world1_equals_single_gpu_step():
+    """At G = 1 the replicated step (fwd/bwd -> export -> [all_gather] -> import -> Adam) must equal the plain step."""
+    import torch.distributed as dist
+    from dccf_amd import replicated, _lib as L
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29731')
+    dev = torch.device('cuda', 0)
+    if not dist.is_initialized():
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    U, I, D, F, S, A, B = 500, 300, 64, 160, 10, 2, 48
+    g = torch.Generator(device='cuda').manual_seed(1)
+    feat = torch.randn(I, F, generator=g, device='cuda') * 0.3
+    expo = torch.randn(U, I, generator=g, device='cuda')
+    tr = replicated.ReplicatedDCCF(0, 1, U, I, D, S, A, 0.1, 0.2, 1e-3, 1e-4, 5, replicated.HipBackend(dev), dev, feat,
+                                   expo=expo, max_rows=2 * B)
+    tr.init_params(0.1)
+    # the plain path on a copy
+    p0 = tr.flat_p.clone()
+    gg, s1, s2 = torch.zeros_like(p0), torch.zeros_like(p0), torch.zeros_like(p0)
+    views = [p0[o:o + n * w].view(n, w) for (o, n, w, _) in tr.segments]
+    oW = tr.dense_begin
+    W, b = p0[oW:oW + D * (D + F)].view(D, D + F), p0[oW + D * (D + F):oW + D * (D + F) + D]
+    gviews = [gg[o:o + n * w].view(n, w) for (o, n, w, _) in tr.segments]
+    gW, gb = gg[oW:oW + D * (D + F)].view(D, D + F), gg[oW + D * (D + F):oW + D * (D + F) + D]
+    ctx = L.Context(0)
+    y = torch.cat([torch.ones(B, device='cuda'), torch.zeros(B, device='cuda')])
+    gen = torch.Generator(device='cuda').manual_seed(2)
+    for t in range(4):
+        X = torch.stack([torch.randint(0, U, (2 * B,), generator=gen, device='cuda'),
+                         torch.randint(0, I, (2 * B,), generator=gen, device='cuda')], 1)
+        pred, loss = tr.train_step(X, y)
+        m = L.model_struct(views[0], views[1], W, b, feat, expo, S, A, 0.1)
+        pred2, loss2 = L.dccf_train_fwdbwd(ctx, m, L.rand_struct(seed=5, step=t), X, y, 1, 0.2, gviews[0], gviews[1], gW, gb)
+        L.dense_opt_step('adam', p0, gg, s1, s2, 1e-3, 1e-4, 1e-4, 50.0, t + 1)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(pred.cpu().numpy(), pred2.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        assert float(loss) == pytest.approx(float(loss2), rel=1e-5)
+    # float atomics inside the backward reorder sums between the two runs; Adam turns that into a fraction of lr
+    d = (tr.flat_p - p0).abs()
+    assert float(d.max()) <= 4 * 1e-3 and int((d > 4 * 5e-3 * 1e-3).sum()) <= 4 * D + 8
+    assert int(tr.tU.sum()) == 0 and int(tr.tV.sum()) == 0 and float(tr.flat_g.abs().max()) == 0.0
+    dist.destroy_process_group()
