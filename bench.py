@@ -45,6 +45,8 @@ def parse():
     p.add_argument('--seed', type=int, default=2019)
     p.add_argument('--mp', type=str, default='replicated', help='multi-GPU layout: replicated (full model per GPU, one '
                                                                 'all-gather per step) | sharded (rows mod G, 4 collectives)')
+    p.add_argument('--dp_overlap', type=int, default=1, help='replicated path: run the optimizer pass over the rows no rank '
+                                                             'touches on a side stream while the gradient exchange is in flight')
     p.add_argument('--force_replicated', type=int, default=0, help='run the replicated data-parallel pipeline even at --gpus 1')
     p.add_argument('--force_sharded', type=int, default=0, help='run the row-sharded pipeline even at --gpus 1')
     p.add_argument('--overlap', type=int, default=0, help='1: dccf_train_step with the untouched-row optimizer pass on a side '

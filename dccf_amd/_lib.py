@@ -15,7 +15,7 @@ EXPORTS = ['dccf_ctx_create', 'dccf_ctx_destroy', 'dccf_ctx_reserve', 'dccf_last
            'mf_predict_full', 'dccf_sample_train_negatives', 'dccf_debug_candidates', 'dccf_debug_noise',
            'dccf_debug_keep', 'dccf_debug_workspace', 'dccf_profile', 'dccf_profile_read',
            'shard_pack_rows', 'shard_unpack_rows', 'shard_scatter_add', 'dccf_dense_opt_step_rows', 'dccf_dense_opt_step_dev', 'dccf_advance', 'rank_eval_topk', 'dccf_train_step', 'dp_buffer_words',
-           'dp_export_touched', 'dp_import_touched']
+           'dp_export_touched', 'dp_import_touched', 'dp_mark_global', 'dccf_dense_opt_phase', 'dccf_ctx_side_stream']
 
 OPT_KIND = {'gd': 0, 'adagrad': 1, 'adam': 2}
 MF_KIND = {'RecModel': 0, 'BiasedMF': 1, 'IPSBiasedMF': 2}
@@ -86,6 +86,10 @@ def load():
         'dccf_dense_opt_step_dev': [i32, vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, vp, i32, C.POINTER(i64), C.POINTER(i64),
                                     C.POINTER(i32), C.POINTER(vp), vp],
         'dccf_advance': [vp, vp],
+        'dccf_ctx_side_stream': [vp, C.POINTER(vp)],
+        'dp_mark_global': [vp, i32, i64, i32, i64, u64, u64, vp, vp, i32, i32, vp, vp, vp, vp],
+        'dccf_dense_opt_phase': [i32, vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, i32, C.POINTER(i64), C.POINTER(i64),
+                                 C.POINTER(i32), C.POINTER(vp), i32, vp, vp, i64, vp],
         'dp_export_touched': [vp, i64, i32, vp, vp, vp, vp, i64, vp, vp, i64, i32, i32, vp],
         'dp_import_touched': [vp, i32, vp, i64, i32, vp, vp, vp, vp, i64, vp, i64, i32, i32, vp, vp],
         'dccf_train_step': [vp, C.POINTER(ModelT), C.POINTER(RandT), vp, vp, i64, i32, f32, C.POINTER(GradsT),
@@ -143,6 +147,12 @@ class Context(object):
 
     def reserve(self, max_rows, D, F, S, A):
         check(load().dccf_ctx_reserve(self.h, int(max_rows), int(D), int(F), int(S), int(A)))
+
+    def side_stream(self):
+        """The context's low-priority (or CU-masked, DCCF_SIDE_CUS) stream as a torch stream."""
+        h = C.c_void_p()
+        check(load().dccf_ctx_side_stream(self.h, C.byref(h)))
+        return torch.cuda.ExternalStream(h.value)
 
     KERNELS = ['prep', 'base', 'noise_fwd', 'pair_epilogue', 'bwd_small', 'noise_bwd_eps', 'noise_bwd_feat', 'unused']
 
@@ -423,3 +433,21 @@ def dp_import_touched(bufs, G, g, segments, dense_begin, loss_sum, cap, D, list_
     n, beg, rows, wid, fl = _seg_arrays(segments)
     check(load().dp_import_touched(ptr(bufs, torch.float32), int(G), ptr(g, torch.float32), g.numel(), n, beg, rows, wid, fl,
                                    int(dense_begin), ptr(loss_sum), int(cap), int(D), int(list_cap), ptr(reset_buf), stream()))
+
+
+def dp_mark_global(X_all, S, item_num, seed, step0, flagsU, flagsV, list_, cnt, parity, segU=0, segV=1):
+    """Marks every row any rank touches in this step (bytes + list); cnt: int32 [2] device counters, parity selects."""
+    G, N = X_all.shape[0], X_all.shape[1]
+    c = ptr(cnt, torch.int32)
+    check(load().dp_mark_global(ptr(X_all, torch.int64), G, N, int(S), int(item_num), int(seed) & 0xFFFFFFFFFFFFFFFF, int(step0),
+                                ptr(flagsU, torch.uint8), ptr(flagsV, torch.uint8), segU, segV, ptr(list_, torch.int64),
+                                c + 4 * parity, c + 4 * (1 - parity), stream()))
+
+
+def dense_opt_phase(kind, p, g, s1, s2, lr, wd, l2, clip, step, segments, phase, list_=None, cnt=None, parity=0, max_rows=0):
+    n, beg, rows, wid, fl = _seg_arrays(segments)
+    c = ptr(cnt, torch.int32)
+    check(load().dccf_dense_opt_phase(OPT_KIND[kind.lower()], ptr(p, torch.float32), ptr(g, torch.float32), ptr(s1), ptr(s2),
+                                      p.numel(), float(lr), float(wd), float(l2), float(clip), int(step), n, beg, rows, wid, fl,
+                                      int(phase), ptr(list_, torch.int64), (c + 4 * parity) if c else None, int(max_rows),
+                                      stream()))

@@ -179,3 +179,21 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+
+// ---------------------------------------------------------------------------------------------- touched-row marking
+// Sets the row's "touched" byte; the first setter appends the row to the step's list.  Divergence-safe: the ballot is over
+// the lanes that reached this call.
+__device__ __forceinline__ void mark_row(uint32_t* flags, int64_t row, int64_t tag, const MarkPlan& mp) {
+  const uint32_t mask = 1u << (8 * (int)(row & 3));
+  const uint32_t old = atomicOr(flags + (row >> 2), mask);
+  const bool first = (old & mask) == 0;
+  const uint64_t b = __ballot(first);
+  if (b == 0) return;
+  const int lane = threadIdx.x & 63;
+  const int leader = __ffsll((unsigned long long)b) - 1;
+  int base = 0;
+  if (lane == leader) base = atomicAdd(mp.cnt, __popcll(b));
+  base = __shfl(base, leader, 64);
+  if (first) mp.list[base + __popcll(b & ((1ull << lane) - 1))] = tag | row;
+}
+

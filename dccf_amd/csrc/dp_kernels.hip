@@ -265,3 +265,53 @@ extern "C" int dp_import_touched(const float* bufs, int32_t G, float* g, int64_t
   HIP_TRY(hipGetLastError());
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------- global marking
+// Which rows will ANY rank's batch touch this step?  Known before the step starts: the schedule X_all [G][N][2] is
+// replicated and rank r's candidates are the Philox stream of (seed, step0 + r) — the same draws k_prep makes on rank r
+// (models/DCCF.py:72-74).  Rows outside this set see only the l2 term, so their optimizer pass does not have to wait for
+// the exchange: it runs on a side stream while export / all-gather / import are in flight.
+__global__ __launch_bounds__(256) void k_dp_mark(const int64_t* __restrict__ X_all, int G, int64_t N, int S, int64_t item_num,
+                                                 rng_key key0, MarkPlan mp) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *mp.cnt_next = 0;
+  const int S1 = S + 1;
+  const int64_t per = N * S1, total = (int64_t)G * per;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / per);
+    const int64_t j = i % per, n = j / S1;
+    const int s = (int)(j % S1);
+    const int64_t* X = X_all + (int64_t)r * N * 2;
+    int64_t it;
+    if (s == 0) {
+      it = X[2 * n + 1];
+    } else {
+      const rng_key key = key_plus(key0, r);
+      const u32x4 rr = philox4x32_10((uint32_t)n, (uint32_t)((s - 1) >> 2), key.s0, key.s1, key.k0, key.k1);
+      it = (int64_t)(((uint64_t)pick4(rr, (s - 1) & 3) * (uint64_t)item_num) >> 32);
+    }
+    mark_row(mp.flagV, it, mp.tagV, mp);
+    if (s == 0) mark_row(mp.flagU, X[2 * n], mp.tagU, mp);
+  }
+}
+
+extern "C" int dp_mark_global(const int64_t* X_all, int32_t G, int64_t N, int32_t S, int64_t item_num, uint64_t seed,
+                              uint64_t step0, uint8_t* flagsU, uint8_t* flagsV, int32_t segU, int32_t segV, int64_t* list,
+                              int32_t* cnt, int32_t* cnt_next, void* stream) {
+  ARG_CHECK(X_all && flagsU && flagsV && list && cnt && cnt_next, "NULL argument");
+  ARG_CHECK(G >= 1 && N >= 1 && S >= 0 && item_num > 0, "bad sizes");
+  ARG_CHECK((uintptr_t)flagsU % 4 == 0 && (uintptr_t)flagsV % 4 == 0, "flags must be 4-byte aligned (padded to whole words)");
+  MarkPlan mp;
+  mp.flagU = (uint32_t*)flagsU;
+  mp.flagV = (uint32_t*)flagsV;
+  mp.tagU = (int64_t)segU << 40;
+  mp.tagV = (int64_t)segV << 40;
+  mp.list = list;
+  mp.cnt = cnt;
+  mp.cnt_next = cnt_next;
+  const int64_t total = (int64_t)G * N * (S + 1);
+  const int grid = (int)min((int64_t)1024, (total + 255) / 256);
+  hipLaunchKernelGGL(k_dp_mark, dim3(grid), dim3(256), 0, (hipStream_t)stream, X_all, G, N, S, item_num,
+                     make_key(seed, STREAM_CAND, step0), mp);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}

@@ -118,6 +118,13 @@ int dccf_step_ensure(dccf_ctx* ctx, int64_t max_rows) {
   return 0;
 }
 
+extern "C" int dccf_ctx_side_stream(dccf_ctx* ctx, void** out) {
+  ARG_CHECK(ctx && out, "NULL argument");
+  if (int e = dccf_step_ensure(ctx, 0)) return e;
+  *out = (void*)ctx->side;
+  return 0;
+}
+
 int dccf_ws_ensure(dccf_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->ws_bytes) return 0;
   // grow-only; growing synchronises the device (earlier launches may still use the old slab)
@@ -394,6 +401,17 @@ extern "C" int dccf_dense_opt_step_rows(int32_t kind, float* p, float* g, float*
                                         void* stream) {
   return opt_rows_impl(kind, p, g, s1, s2, n, lr, wd, l2, clip, step, nullptr, nseg, seg_begin, seg_rows, seg_width, seg_flags,
                        stream);
+}
+
+extern "C" int dccf_dense_opt_phase(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t n, float lr, float wd,
+                                    float l2, float clip, int64_t step, int32_t nseg, const int64_t* seg_begin,
+                                    const int64_t* seg_rows, const int32_t* seg_width, uint8_t* const* seg_flags,
+                                    int32_t phase, const int64_t* list, const int32_t* cnt, int64_t max_rows, void* stream) {
+  ARG_CHECK(phase == OPT_PHASE_UNTOUCHED || phase == OPT_PHASE_TOUCHED, "phase must be 1 (untouched rows) or 2 (listed rows + dense)");
+  OptJob j;
+  if (int e = make_job(kind, p, g, s1, s2, n, lr, wd, l2, clip, step, nullptr, nseg, seg_begin, seg_rows, seg_width, seg_flags, &j))
+    return e;
+  return launch_job(j, phase, list, cnt, max_rows, (hipStream_t)stream);
 }
 
 extern "C" int dccf_dense_opt_step_dev(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t n, float lr, float wd,

@@ -17,6 +17,11 @@ all of it, so every rank keeps a full replica and the per-step exchange shrinks 
     replica holds bit-identical gradients and, after the same dense regularised Adam pass, bit-identical parameters —
     replicas cannot drift, no parameter broadcast is ever needed.
 
+Hiding the collective (``overlap``): the schedule and the candidate streams are replicated, so every rank knows BEFORE the
+step which rows ANY rank will touch (``dp_mark_global``).  All other rows — 98 % of the tables — see only the l2 term: their
+optimizer pass (``dccf_dense_opt_phase`` 1, the 58 us HBM-bound bulk of a step) is enqueued right after the all-gather was
+handed to RCCL's stream and runs while the buffers travel; the listed rows + W, b follow after the import (phase 2).
+
 One optimizer step therefore sees the sum of the G ranks' BPR terms: exactly the reference's step at batch size G * B
 (loss = -sum log sigmoid, src/models/DCCF.py:116-120).  The row-sharded alternative (dccf_amd/sharded.py) is for tables
 that do not fit one GPU; it needs 4 collectives per step instead of 1.
@@ -54,6 +59,14 @@ class HipBackend(object):
                       tr.flat_p.numel(), float(tr.lr), float(tr.l2), float(tr.l2), 50.0)
         self.f_fwbw, self.f_export, self.f_import, self.f_opt = (lib.dccf_train_fwdbwd, lib.dp_export_touched,
                                                                  lib.dp_import_touched, lib.dccf_dense_opt_step_rows)
+        # overlap mode: global marks, optimizer in two phases, the untouched-row phase while the all-gather is in flight
+        self.gseg = L._seg_arrays(tr.gsegments)
+        self.a_import_g = (L.ptr(tr.bufs, f32), int(tr.G), L.ptr(tr.flat_g, f32), tr.flat_g.numel()) + self.gseg + (
+            int(tr.dense_begin), L.ptr(tr.loss_sum, f32), int(tr.cap), int(tr.D), 0, L.ptr(tr.buf, f32))
+        self.a_mark = (int(tr.S), int(tr.item_num), int(tr.seed) & 0xFFFFFFFFFFFFFFFF)
+        self.p_flags = (L.ptr(tr.gfU, u8), L.ptr(tr.gfV, u8), 0, 1, L.ptr(tr.glist, torch.int64))
+        self.p_cnt = L.ptr(tr.gcnt, torch.int32)
+        self.f_mark, self.f_phase = lib.dp_mark_global, lib.dccf_dense_opt_phase
         self.ready = tr
 
     def local_step(self, tr, X, Y, step, pred):
@@ -70,8 +83,24 @@ class HipBackend(object):
     def export(self, tr):
         self.L.check(self.f_export(*self.a_export, self.L.stream()))
 
-    def import_(self, tr):
-        self.L.check(self.f_import(*self.a_import, self.L.stream()))
+    def import_(self, tr, global_flags=False):
+        self.L.check(self.f_import(*(self.a_import_g if global_flags else self.a_import), self.L.stream()))
+
+    def mark_global(self, tr, X_all, step0):
+        if self.ready is not tr:
+            self.prepare(tr)
+        c = self.p_cnt
+        self.L.check(self.f_mark(self.L.ptr(X_all, torch.int64), X_all.shape[0], X_all.shape[1], *self.a_mark, int(step0),
+                                 *self.p_flags, c + 4 * tr.parity, c + 4 * (1 - tr.parity), self.L.stream()))
+
+    def opt_untouched(self, tr, t):
+        """Phase 1 on the current stream: enqueued right after the all-gather was handed to RCCL's stream, so the
+        collective's kernel is already resident when this pass starts to fill the GPU."""
+        self.L.check(self.f_phase(*self.a_opt, t, *self.gseg, 1, None, None, 0, self.L.stream()))
+
+    def opt_touched(self, tr, t):
+        self.L.check(self.f_phase(*self.a_opt, t, *self.gseg, 2, self.p_flags[4], self.p_cnt + 4 * tr.parity, tr.glist.numel(),
+                                  self.L.stream()))
 
     def opt_step(self, tr):
         self.L.check(self.f_opt(*self.a_opt, tr.t, *self.seg, self.L.stream()))
@@ -79,7 +108,7 @@ class HipBackend(object):
 
 class ReplicatedDCCF(object):
     def __init__(self, rank, world, user_num, item_num, D, S, A, std, dropout, lr, l2, seed, backend, device, feat,
-                 expo=None, ips=None, max_rows=256, group=None):
+                 expo=None, ips=None, max_rows=256, group=None, overlap=True):
         """feat [item_num, F]; expo [user_num, item_num] or ips (dict of IPSBiasedMF factors) — full tables, identical on
         every rank.  max_rows: the largest 2B a step will see (sizes the all-gather buffer)."""
         self.rank, self.G, self.group, self.dev, self.be = rank, world, group, device, backend
@@ -113,6 +142,15 @@ class ReplicatedDCCF(object):
         self.loss = torch.zeros(1, dtype=f32, device=device)
         self.loss_sum = torch.zeros(1, dtype=f32, device=device)
         self.t = 0
+        # overlap mode: "touched by ANY rank" bytes + list (known before the step: schedule and candidate streams are
+        # replicated), so that the optimizer pass over all the other rows can run while the exchange is in flight
+        self.overlap = overlap
+        self.gfU = torch.zeros((user_num + 3) // 4 * 4, dtype=u8, device=device)[:user_num]
+        self.gfV = torch.zeros((item_num + 3) // 4 * 4, dtype=u8, device=device)[:item_num]
+        self.gsegments = [(offs[0], user_num, D, self.gfU), (offs[1], item_num, D, self.gfV)]
+        self.glist = torch.zeros(world * self.cap + 1024, dtype=torch.int64, device=device)
+        self.gcnt = torch.zeros(2, dtype=torch.int32, device=device)
+        self.parity = 0
 
     @staticmethod
     def _buffer_words(cap, D, nd):
@@ -128,19 +166,34 @@ class ReplicatedDCCF(object):
         for dst, src in ((self.U, U), (self.V, V), (self.W, W), (self.b, b)):
             dst.copy_(src)
 
-    def train_step(self, X, Y, pred=None):
+    def train_step(self, X, Y, pred=None, X_all=None):
         """X int64 [2B, 2] = this rank's [positives ; negatives]; one optimizer step over the G ranks' batches.
+        X_all int64 [G, 2B, 2] (every rank's batch of this step, X_all[rank] == X) enables the overlap of the optimizer
+        pass over the rows NO rank touches with the all-gather.
         Returns (prediction of this rank's rows, loss summed over the ranks)."""
         be = self.be
-        pred, _ = be.local_step(self, X, Y, self.t * self.G + self.rank, pred)
+        ov = self.overlap and X_all is not None
+        step0, t = self.t * self.G, self.t + 1
+        if ov:
+            be.mark_global(self, X_all, step0)
+        pred, _ = be.local_step(self, X, Y, step0 + self.rank, pred)
         be.export(self)
-        if self.G > 1:
-            dist.all_gather_into_tensor(self.bufs, self.buf, group=self.group)       # the step's only collective
+        work = None
+        if self.G > 1:                                             # the step's only collective
+            work = dist.all_gather_into_tensor(self.bufs, self.buf, group=self.group, async_op=ov)
         else:
             self.bufs.copy_(self.buf)
-        be.import_(self)
-        self.t += 1
-        be.opt_step(self)
+        if ov:
+            be.opt_untouched(self, t)          # rows no rank touches: runs while RCCL moves the buffers
+            if work is not None:
+                work.wait()
+        be.import_(self, global_flags=ov)
+        self.t = t
+        if ov:
+            be.opt_touched(self, t)
+            self.parity ^= 1
+        else:
+            be.opt_step(self)
         return pred, self.loss_sum
 
 
@@ -170,7 +223,7 @@ def bench_main(args, rank, world, dev):
                    bu=torch.randn(U, generator=g, device=dev) * 0.1, bi=torch.randn(I, generator=g, device=dev) * 0.1,
                    prop=torch.rand(I, generator=g, device=dev), b0=0.1, M=0.1)
     tr = ReplicatedDCCF(rank, world, U, I, D, S, A, 0.1, 0.2, 1e-3, 1e-4, args.seed, be, dev, feat, expo=expo, ips=ips,
-                        max_rows=2 * B)
+                        max_rows=2 * B, overlap=bool(args.dp_overlap))
     tr.init_params()
     be.ctx.reserve(2 * B, D, F, S, A)
     n_steps = args.steps + args.warmup
@@ -182,18 +235,18 @@ def bench_main(args, rank, world, dev):
 
     def schedule(e, n):
         full, _ = ds.epoch_batches(e, B)                       # same permutation / negatives on every rank
-        return full[:n * world].view(n, world, 2 * B, 2)[:, rank].contiguous()     # step k: rank r trains full[k*world + r]
+        return full[:n * world].view(n, world, 2 * B, 2)       # step k: rank r trains full[k*world + r]
 
-    mine = schedule(0, args.warmup)
+    sched = schedule(0, args.warmup)
     for k in range(args.warmup):
-        tr.train_step(mine[k], y, pred)
+        tr.train_step(sched[k, rank], y, pred, X_all=sched[k])
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    mine = schedule(1, args.steps)                             # the epoch's negative sampling is timed
+    sched = schedule(1, args.steps)                            # the epoch's negative sampling is timed
     for k in range(args.steps):
-        tr.train_step(mine[k], y, pred)
+        tr.train_step(sched[k, rank], y, pred, X_all=sched[k])
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()

@@ -121,6 +121,17 @@ int dccf_dense_opt_step(int32_t kind, float* p, float* g, float* s1, float* s2, 
 int dccf_dense_opt_step_rows(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t n, float lr, float wd,
                              float l2, float clip, int64_t step, int32_t nseg, const int64_t* seg_begin,
                              const int64_t* seg_rows, const int32_t* seg_width, uint8_t* const* seg_flags, void* stream);
+/* The same step in two launches, for callers that know BEFORE the backward which rows a step will touch (a de-duplicated
+ * `list` of (segment << 40) | row with its device-side count, flags set for exactly those rows):
+ *   phase 1: every row whose byte is 0 (gradient = l2 term only) — independent of the batch, may run on another stream
+ *            while forward / backward / gradient exchange are in flight;
+ *   phase 2: the listed rows (gradient read, zeroed, byte cleared) and everything outside the segments (W, b).
+ * Together they equal dccf_dense_opt_step_rows bit for bit. */
+int dccf_dense_opt_phase(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t n, float lr, float wd, float l2,
+                         float clip, int64_t step, int32_t nseg, const int64_t* seg_begin, const int64_t* seg_rows,
+                         const int32_t* seg_width, uint8_t* const* seg_flags, int32_t phase, const int64_t* list,
+                         const int32_t* cnt, int64_t max_rows, void* stream);
+
 /* ---- ONE training step = the body of BaseRunner.fit's batch loop (src/runners/BaseRunner.py:172-188): forward, loss,
  * backward, + l2, clip, optimizer step, zero_grad.  Same results, bit for bit, as dccf_train_fwdbwd followed by
  * dccf_dense_opt_step_rows.  With overlap != 0 the optimizer pass over the rows this batch does NOT touch (all but a few
@@ -145,6 +156,10 @@ typedef struct {
   const int32_t* seg_width;
   uint8_t* const* seg_flags;
 } dccf_opt_t;
+/* The context's side stream (hipStream_t): least priority, or confined to the first n CUs when the environment variable
+ * DCCF_SIDE_CUS=n is set at its creation (the mask interleaves over the 8 XCDs).  For callers that run
+ * dccf_dense_opt_phase(1) beside other work themselves (dccf_amd/replicated.py). */
+int dccf_ctx_side_stream(dccf_ctx* ctx, void** out);
 int dccf_train_step(dccf_ctx* ctx, const dccf_model_t* model, const dccf_rand_t* rnd, const int64_t* X, const float* Y,
                     int64_t N, int32_t rank, float dropout, const dccf_grads_t* grads, const dccf_opt_t* opt,
                     float* prediction, float* loss, void* stream);
@@ -211,6 +226,13 @@ int rank_eval_topk(const float* pred, const float* label, const int64_t* indptr,
  * The export appends behind the counter in buf[0]: reset != 0 zeroes it first (one more launch); a training loop passes its
  * local buffer as reset_buf to the import instead, which zeroes the counter for the next step's export. */
 int64_t dp_buffer_words(int64_t cap, int32_t D, int64_t nd);
+/* Marks (bytes + de-duplicated list, as dccf_dense_opt_phase wants them) every row ANY of the G ranks will touch in the step
+ * whose rank-0 Philox step word is step0: X_all int64 [G][N][2] is the replicated schedule, rank r's S candidates per row
+ * are the STREAM_CAND draws of (seed, step0 + r) — what dccf_train_fwdbwd draws on rank r in fused mode.  segU / segV: the
+ * segment indices of the user / item tables; *cnt must be 0 on entry, *cnt_next is zeroed (double-buffered counters). */
+int dp_mark_global(const int64_t* X_all, int32_t G, int64_t N, int32_t S, int64_t item_num, uint64_t seed, uint64_t step0,
+                   uint8_t* flagsU, uint8_t* flagsV, int32_t segU, int32_t segV, int64_t* list, int32_t* cnt,
+                   int32_t* cnt_next, void* stream);
 int dp_export_touched(float* g, int64_t n, int32_t nseg, const int64_t* seg_begin, const int64_t* seg_rows,
                       const int32_t* seg_width, uint8_t* const* seg_flags, int64_t dense_begin, const float* loss, float* buf,
                       int64_t cap, int32_t D, int32_t reset, void* stream);

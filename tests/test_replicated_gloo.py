@@ -58,8 +58,34 @@ class OracleBackend(object):
         buf[4 + 2 * cap + cap * D:4 + 2 * cap + cap * D + nd] = tr.flat_g[tr.dense_begin:]
         tr.flat_g[tr.dense_begin:] = 0
 
-    def import_(self, tr):
+    def mark_global(self, tr, X_all, step0):
+        """numpy restatement of dp_mark_global: bytes for every row any rank touches."""
+        for r in range(X_all.shape[0]):
+            X = X_all[r].numpy()
+            cand = PH.candidates(tr.seed, step0 + r, X.shape[0], tr.S, tr.item_num)
+            tr.gfU[torch.from_numpy(X[:, 0])] = 1
+            tr.gfV[torch.from_numpy(np.concatenate([X[:, 1], cand.reshape(-1)]))] = 1
+
+    def opt_untouched(self, tr, t):
+        """Phase 1 touches only rows whose global byte is 0; the dense optimizer is element-wise, so the oracle defers the
+        arithmetic to opt_touched and checks here what the phase relies on: nothing was (or will be) added to those rows."""
+        self.untouched = []
+        for off, n, w, flags in tr.gsegments:
+            rows = torch.nonzero(flags == 0).flatten()
+            assert float(tr.flat_g[off:off + n * w].view(n, w)[rows].abs().max()) == 0.0
+            self.untouched.append(rows)
+
+    def opt_touched(self, tr, t):
+        for (off, n, w, flags), rows in zip(tr.gsegments, self.untouched):
+            assert float(tr.flat_g[off:off + n * w].view(n, w)[rows].abs().max()) == 0.0      # still zero after the import
+        assert t == tr.t
+        self.opt_step(tr)
+        for _, _, _, flags in tr.gsegments:
+            flags.zero_()
+
+    def import_(self, tr, global_flags=False):
         D, cap, W = tr.D, tr.cap, tr.words
+        segments = tr.gsegments if global_flags else tr.segments
         nd = tr.flat_g.numel() - tr.dense_begin
         tr.loss_sum.zero_()
         for r in range(tr.G):                                      # rank order
@@ -68,7 +94,7 @@ class OracleBackend(object):
             ids = b[4:4 + 2 * cap].view(torch.int64)[:cnt].tolist()
             for e, id_ in enumerate(ids):
                 q, row = id_ >> 40, id_ & ((1 << 40) - 1)
-                off, n, w, flags = tr.segments[q]
+                off, n, w, flags = segments[q]
                 tr.flat_g[off + row * w:off + (row + 1) * w] += b[4 + 2 * cap + e * D:4 + 2 * cap + (e + 1) * D]
                 flags[row] = 1
             tr.flat_g[tr.dense_begin:] += b[4 + 2 * cap + cap * D:4 + 2 * cap + cap * D + nd]
@@ -100,7 +126,8 @@ def make_world(c):
     return P, feat, expo, X
 
 
-def worker(rank, world, port, out):
+def worker(rank, world, port, out, overlap):
+    CFG['overlap'] = overlap
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -114,7 +141,7 @@ def worker(rank, world, port, out):
     Y = torch.cat([torch.ones(c['B']), torch.zeros(c['B'])])
     preds, losses = [], []
     for step in range(c['steps']):
-        pred, loss = tr.train_step(T(X[step][rank]), Y)
+        pred, loss = tr.train_step(T(X[step][rank]), Y, X_all=T(X[step]) if c.get('overlap') else None)
         preds.append(pred.numpy().copy())
         losses.append(float(loss))
     np.savez(os.path.join(out, 'rank%d.npz' % rank), p=tr.flat_p.numpy(), U=tr.U.numpy(), V=tr.V.numpy(), W=tr.W.numpy(),
@@ -122,10 +149,14 @@ def worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_replicated_step_equals_union_batch(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize('overlap', [False, True])
+def test_replicated_step_equals_union_batch(tmp_path, overlap):
     world = 2
-    port = 31000 + os.getpid() % 2000
-    mp.spawn(worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    port = 31000 + os.getpid() % 2000 + (7 if overlap else 0)
+    mp.spawn(worker, args=(world, port, str(tmp_path), overlap), nprocs=world, join=True)
     c = CFG
     P, feat, expo, X = make_world(c)
     opt = O.DenseOptimizer('adam', c['lr'], c['l2'])

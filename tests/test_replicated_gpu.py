@@ -10,6 +10,14 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope='module', autouse=True)
+def _process_group_teardown():
+    yield
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def make_state(U, I, D, nd_extra, touchedU, touchedV, seed):
     rng = np.random.RandomState(seed)
     sizes = [U * D, I * D, nd_extra]
@@ -67,8 +75,34 @@ def test_export_import_rank_ordered_sum(D, list_cap):
     assert float(loss_sum) == pytest.approx(sum(1.5 + r for r in range(G)))
 
 
-def test_replicated_trainer_world1_equals_single_gpu_step():
-    """At G = 1 the replicated step (fwd/bwd -> export -> [all_gather] -> import -> Adam) must equal the plain step."""
+def test_mark_global_matches_oracle_streams():
+    """dp_mark_global: bytes + de-duplicated list == the rows of X_all and of every rank's Philox candidates (oracle)."""
+    from dccf_amd import _lib as L
+    from oracle import philox as PH
+    U, I, G, N, S, seed, step0 = 1003, 517, 3, 40, 10, 77, 12
+    rng = np.random.RandomState(0)
+    X_all = np.stack([np.stack([rng.randint(0, U, N), rng.randint(0, I, N)], 1) for _ in range(G)]).astype(np.int64)
+    fU = torch.zeros((U + 3) // 4 * 4, dtype=torch.uint8, device='cuda')[:U]
+    fV = torch.zeros((I + 3) // 4 * 4, dtype=torch.uint8, device='cuda')[:I]
+    lst = torch.zeros(G * N * (S + 2) + 8, dtype=torch.int64, device='cuda')
+    cnt = torch.tensor([0, 99], dtype=torch.int32, device='cuda')
+    L.dp_mark_global(torch.as_tensor(X_all).cuda(), S, I, seed, step0, fU, fV, lst, cnt, 0)
+    torch.cuda.synchronize()
+    users, items = set(X_all[:, :, 0].reshape(-1).tolist()), set(X_all[:, :, 1].reshape(-1).tolist())
+    for r in range(G):
+        items |= set(PH.candidates(seed, step0 + r, N, S, I).reshape(-1).tolist())
+    assert sorted(torch.nonzero(fU).flatten().tolist()) == sorted(users)
+    assert sorted(torch.nonzero(fV).flatten().tolist()) == sorted(items)
+    n = int(cnt[0])
+    assert n == len(users) + len(items) and int(cnt[1]) == 0          # the other counter is reset for the next step
+    got = lst[:n].tolist()
+    assert sorted(got) == sorted(list(users) + [(1 << 40) | i for i in items])
+
+
+@pytest.mark.parametrize('overlap', [False, True])
+def test_replicated_trainer_world1_equals_single_gpu_step(overlap):
+    """At G = 1 the replicated step (fwd/bwd -> export -> [all_gather] -> import -> Adam), with and without the optimizer
+    pass over the untouched rows on the side stream, must equal the plain step."""
     import torch.distributed as dist
     from dccf_amd import replicated, _lib as L
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -76,12 +110,13 @@ def test_replicated_trainer_world1_equals_single_gpu_step():
     dev = torch.device('cuda', 0)
     if not dist.is_initialized():
         dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    # (the process group is left alive for the second parametrisation; pytest tears the process down)
     U, I, D, F, S, A, B = 500, 300, 64, 160, 10, 2, 48
     g = torch.Generator(device='cuda').manual_seed(1)
     feat = torch.randn(I, F, generator=g, device='cuda') * 0.3
     expo = torch.randn(U, I, generator=g, device='cuda')
     tr = replicated.ReplicatedDCCF(0, 1, U, I, D, S, A, 0.1, 0.2, 1e-3, 1e-4, 5, replicated.HipBackend(dev), dev, feat,
-                                   expo=expo, max_rows=2 * B)
+                                   expo=expo, max_rows=2 * B, overlap=overlap)
     tr.init_params(0.1)
     # the plain path on a copy
     p0 = tr.flat_p.clone()
@@ -94,10 +129,12 @@ def test_replicated_trainer_world1_equals_single_gpu_step():
     ctx = L.Context(0)
     y = torch.cat([torch.ones(B, device='cuda'), torch.zeros(B, device='cuda')])
     gen = torch.Generator(device='cuda').manual_seed(2)
+    seen = []
     for t in range(4):
-        X = torch.stack([torch.randint(0, U, (2 * B,), generator=gen, device='cuda'),
+        X = torch.stack([torch.randint(0, U // 2, (2 * B,), generator=gen, device='cuda'),
                          torch.randint(0, I, (2 * B,), generator=gen, device='cuda')], 1)
-        pred, loss = tr.train_step(X, y)
+        seen.append(X[:, 0])
+        pred, loss = tr.train_step(X, y, X_all=X[None].contiguous() if overlap else None)
         m = L.model_struct(views[0], views[1], W, b, feat, expo, S, A, 0.1)
         pred2, loss2 = L.dccf_train_fwdbwd(ctx, m, L.rand_struct(seed=5, step=t), X, y, 1, 0.2, gviews[0], gviews[1], gW, gb)
         L.dense_opt_step('adam', p0, gg, s1, s2, 1e-3, 1e-4, 1e-4, 50.0, t + 1)
@@ -108,4 +145,9 @@ def test_replicated_trainer_world1_equals_single_gpu_step():
     d = (tr.flat_p - p0).abs()
     assert float(d.max()) <= 4 * 1e-3 and int((d > 4 * 5e-3 * 1e-3).sum()) <= 4 * D + 8
     assert int(tr.tU.sum()) == 0 and int(tr.tV.sum()) == 0 and float(tr.flat_g.abs().max()) == 0.0
-    dist.destroy_process_group()
+    assert int(tr.gfU.sum()) == 0 and int(tr.gfV.sum()) == 0
+    # rows no batch touched are bit-identical (their update never sees a float atomic)
+    never = torch.ones(U, dtype=torch.bool, device='cuda')
+    never[torch.cat(seen)] = False
+    assert torch.equal(tr.U[never], views[0][never])
+    torch.cuda.synchronize()
