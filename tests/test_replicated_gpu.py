@@ -151,3 +151,80 @@ def test_replicated_trainer_world1_equals_single_gpu_step(overlap):
     never[torch.cat(seen)] = False
     assert torch.equal(tr.U[never], views[0][never])
     torch.cuda.synchronize()
+
+
+def _rank_main(rank, world, port, out, overlap):
+    import torch.distributed as dist
+    from dccf_amd import replicated
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)       # two ranks share the one GPU of the test box
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    c = W2
+    g = torch.Generator(device='cuda').manual_seed(1)
+    feat = torch.randn(c['I'], c['F'], generator=g, device='cuda') * 0.3
+    expo = torch.randn(c['U'], c['I'], generator=g, device='cuda')
+    tr = replicated.ReplicatedDCCF(rank, world, c['U'], c['I'], c['D'], c['S'], c['A'], 0.1, 0.2, 1e-2, 1e-4, 5,
+                                   replicated.HipBackend(dev), dev, feat, expo=expo, max_rows=2 * c['B'], overlap=overlap)
+    tr.init_params(0.1)
+    y = torch.cat([torch.ones(c['B'], device='cuda'), torch.zeros(c['B'], device='cuda')])
+    gen = torch.Generator(device='cuda').manual_seed(2)
+    losses = []
+    for t in range(c['steps']):
+        X_all = torch.stack([torch.stack([torch.randint(0, c['U'], (2 * c['B'],), generator=gen, device='cuda'),
+                                          torch.randint(0, c['I'], (2 * c['B'],), generator=gen, device='cuda')], 1)
+                             for _ in range(world)])
+        _, loss = tr.train_step(X_all[rank].contiguous(), y, X_all=X_all if overlap else None)
+        losses.append(float(loss))
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out, 'r%d_%d.npz' % (rank, int(overlap))), p=tr.flat_p.cpu().numpy(), losses=np.array(losses),
+             flags=np.array([int(tr.tU.sum()), int(tr.tV.sum()), int(tr.gfU.sum()), int(tr.gfV.sum())]),
+             gmax=float(tr.flat_g.abs().max()))
+    dist.destroy_process_group()
+
+
+W2 = dict(U=700, I=450, D=64, F=96, S=10, A=2, B=40, steps=4)
+
+
+@pytest.mark.parametrize('overlap', [False, True])
+def test_two_ranks_hip_backend_replicas_bit_identical(tmp_path, overlap):
+    """World size 2 with the HIP backend (both ranks on this box's one GPU, gloo as the transport): the replicas end
+    bit-identical, nothing is left in the gradient buffer or the flags, and the result equals the same two batches
+    accumulated into one gradient on one GPU, to the float-atomic tolerance."""
+    import torch.multiprocessing as mp
+    from dccf_amd import _lib as L
+    port = 33000 + os.getpid() % 2000 + (11 if overlap else 0)
+    mp.spawn(_rank_main, args=(2, port, str(tmp_path), overlap), nprocs=2, join=True)
+    r0, r1 = [dict(np.load(os.path.join(str(tmp_path), 'r%d_%d.npz' % (r, int(overlap))))) for r in range(2)]
+    assert np.array_equal(r0['p'], r1['p'])
+    assert np.array_equal(r0['losses'], r1['losses'])
+    assert r0['flags'].sum() == 0 and r1['flags'].sum() == 0 and r0['gmax'] == 0 and r1['gmax'] == 0
+    # one GPU, both batches into one gradient, one optimizer step
+    c = W2
+    from dccf_amd import replicated
+    dev = torch.device('cuda', 0)
+    g = torch.Generator(device='cuda').manual_seed(1)
+    feat = torch.randn(c['I'], c['F'], generator=g, device='cuda') * 0.3
+    expo = torch.randn(c['U'], c['I'], generator=g, device='cuda')
+    tr = replicated.ReplicatedDCCF(0, 1, c['U'], c['I'], c['D'], c['S'], c['A'], 0.1, 0.2, 1e-2, 1e-4, 5,
+                                   replicated.HipBackend(dev), dev, feat, expo=expo, max_rows=2 * c['B'])
+    tr.init_params(0.1)
+    ctx = L.Context(0)
+    y = torch.cat([torch.ones(c['B'], device='cuda'), torch.zeros(c['B'], device='cuda')])
+    gen = torch.Generator(device='cuda').manual_seed(2)
+    s1, s2 = torch.zeros_like(tr.flat_p), torch.zeros_like(tr.flat_p)
+    for t in range(c['steps']):
+        X_all = torch.stack([torch.stack([torch.randint(0, c['U'], (2 * c['B'],), generator=gen, device='cuda'),
+                                          torch.randint(0, c['I'], (2 * c['B'],), generator=gen, device='cuda')], 1)
+                             for _ in range(2)])
+        total = 0.0
+        for r in range(2):
+            m = L.model_struct(tr.U, tr.V, tr.W, tr.b, feat, expo, c['S'], c['A'], 0.1)
+            _, loss = L.dccf_train_fwdbwd(ctx, m, L.rand_struct(seed=5, step=t * 2 + r), X_all[r].contiguous(), y, 1, 0.2,
+                                          tr.gU, tr.gV, tr.gW, tr.gb)
+            total += float(loss)
+        assert total == pytest.approx(float(r0['losses'][t]), rel=1e-4)
+        L.dense_opt_step('adam', tr.flat_p, tr.flat_g, s1, s2, 1e-2, 1e-4, 1e-4, 50.0, t + 1)
+    d = np.abs(tr.flat_p.cpu().numpy() - r0['p'])
+    assert d.max() <= c['steps'] * 1e-2 and (d > c['steps'] * 5e-3 * 1e-2).sum() <= 4 * c['D'] + 8
