@@ -43,8 +43,9 @@ def parse():
     p.add_argument('--cpu_baseline', type=int, default=1)
     p.add_argument('--cpu_steps', type=int, default=60)
     p.add_argument('--seed', type=int, default=2019)
-    p.add_argument('--mp', type=str, default='replicated', help='multi-GPU layout: replicated (full model per GPU, one '
-                                                                'all-gather per step) | sharded (rows mod G, 4 collectives)')
+    p.add_argument('--mp', type=str, default='auto', help='multi-GPU layout: replicated (full model per GPU, one all-gather '
+                                                          'per step) | sharded (rows mod G, 4 collectives) | auto (replicated '
+                                                          'while the redundant dense optimizer pass is cheap: <= 1e8 params)')
     p.add_argument('--dp_overlap', type=int, default=1, help='replicated path: run the optimizer pass over the rows no rank '
                                                              'touches on a side stream while the gradient exchange is in flight')
     p.add_argument('--force_replicated', type=int, default=0, help='run the replicated data-parallel pipeline even at --gpus 1')
@@ -94,6 +95,10 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    # rehearsal on a box with fewer GPUs than ranks (DCCF_DIST_BACKEND=gloo): ranks share the visible devices
+    backend = os.environ.get('DCCF_DIST_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local = local % max(torch.cuda.device_count(), 1)
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d'
@@ -109,7 +114,10 @@ def main():
             os.environ.setdefault('MASTER_PORT', '29618')
             dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
         else:
-            dist.init_process_group('nccl', device_id=dev)
+            dist.init_process_group(backend, **({'device_id': dev} if backend == 'nccl' else {}))
+        n_params = (args.users + args.items) * args.dim + args.dim * (args.dim + args.feat) + args.dim
+        if args.mp == 'auto':
+            args.mp = 'replicated' if n_params <= 1e8 else 'sharded'
         if args.mp == 'sharded' or args.force_sharded:
             from dccf_amd import sharded
             return sharded.bench_main(args, rank, world, dev)
