@@ -32,7 +32,7 @@ def build(force=False, verbose=True):
     for src in SRCS:
         obj = os.path.join(os.path.dirname(LIB), os.path.basename(src).replace('.hip', '.o'))
         c = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-result',
-             '-c', src, '-o', obj]
+             '-c', src, '-o', obj] + os.environ.get('DCCF_EXTRA_HIPCC_FLAGS', '').split()
         if verbose:
             print(' '.join(c))
         subprocess.check_call(c)

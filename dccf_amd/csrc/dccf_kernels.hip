@@ -44,8 +44,8 @@ static Lay make_layout(int64_t N, int D, int F, int S, int A) {
   y.NS = N * y.S1;
   y.L = y.NS * A;
   y.DP = D <= 32 ? 32 : (int)align_up(D, 64);
-  y.FP = (int)align_up(F, 128);
-  y.NC = y.FP / 128;
+  y.NC = (int)align_up(F, 128) / 128;
+  y.FP = (y.NC <= 2 ? 2 : (y.NC <= 6 ? 6 : 7)) * 128;      // W^T is zero-padded to the small-L forward's compile-time chunk count
   y.ND = y.DP == 32 ? 1 : 2;
   y.GY = y.DP == 32 ? 1 : y.DP / 64;
   size_t o = 0;
@@ -117,12 +117,29 @@ __global__ void k_prep(dccf_model_t M, float* __restrict__ WT, int D, int F, int
   }
 }
 
+#ifdef DCCF_TRACE
+// Development aid (never built by default): wall-clock stamps (100 MHz) of workgroup 0's waves at phase boundaries.
+__device__ long long dccf_trace[8 * 16];
+#define TRACE(slot) if (blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0) dccf_trace[(threadIdx.x >> 6) * 16 + (slot)] = wall_clock64()
+extern "C" int dccf_debug_trace_read(long long* out) {
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(dccf_trace), sizeof(long long) * 8 * 16));
+  return 0;
+}
+#else
+#define TRACE(slot)
+#endif
+
 // ================================================================================================ K1: forward
-// Workgroup = NC chunk waves + 1 item wave, one 32-row tile per iteration.
-//   chunk wave tq:  lane (row = lane&31, h = lane>>5), k-step (c2, o):  f = 128*tq + (2*c2+h) + 32*o;  ONE Philox call per
-//                   4 k-steps yields the 4 normals eps(l, f) of o = 0..3; A = feat[i0(l)][f] + eps;  B = wreg (registers).
-//   item wave:      k-step j: A = V[cand(l)][2j+h], B = W_i^T rows 2j+h (registers).
-template <int D_, int MODE>   // MODE 0: fused Philox draws, 1: injected noise / keep mask
+// Workgroup = 8 waves, one 32-row tile per iteration, K split EVENLY over the waves (two waves share a SIMD and the
+// fp32 MFMA shares the VALU pipe with the generator, so an uneven split leaves SIMDs idle: measured 15 us for the two
+// SIMDs that held two 128-wide feature chunks against 9 us for the one that held one).
+//   A "group" is 4 k-steps.  Feature groups: q = (tq, c2), tq < NC the 128-wide chunk, c2 < 16; lane (row = lane&31,
+//   h = lane>>5) handles f = 128*tq + (2*c2+h) + 32*o, o = 0..3 — ONE Philox call yields the 4 normals eps(l, f).  Wave w
+//   owns feature groups [w*2*NC, (w+1)*2*NC) (q = 16*tq + c2) and, while they last, item group w (k = 8*w + 2*o + h of
+//   V[cand]) — its slices of W^T stay in registers.  Partials meet in LDS; the epilogue adds b, applies relu + dropout,
+//   stores h and m[l] = <U[u], h[l]>; its operands (user row, dropout draw, bias) are fetched before the k-loop.
+// NCM >= NC is the compile-time number of chunks (W^T is zero-padded to it: a group past F multiplies zeros).
+template <int D_, int MODE, int NCM>   // MODE 0: fused Philox draws, 1: injected noise / keep mask
 __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT, const float* __restrict__ bias,
                                                    const float* __restrict__ U, const float* __restrict__ V,
                                                    const float* __restrict__ feat, const int64_t* X,
@@ -131,7 +148,8 @@ __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT,
                                                    float* __restrict__ m, int64_t L, int S1,
                                                    int A, int F, rng_key nkey, rng_key dkey, float nscale,
                                                    uint32_t drop_thr, float kscale, StepRef sr) {
-  extern __shared__ float zpart[];   // [NW][32][DW]
+  extern __shared__ float zpart[];   // [8][32][DW]
+  TRACE(0);
   {
     const int64_t k = step_k(sr);
     X = step_X(sr, X, k);
@@ -142,30 +160,58 @@ __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT,
   constexpr int DP = D <= 32 ? 32 : (D + 63) / 64 * 64;
   constexpr int ND = D <= 32 ? 1 : 2;
   constexpr int DW = ND * 32;
-  constexpr int KI = D / 2;          // k-steps of the item part
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, NW = blockDim.x >> 6, NC = NW - 1;
+  constexpr int NW = 8;
+  constexpr int NGF = 2 * NCM;       // feature groups per wave
+  constexpr int GI = D / 8;          // item groups in total (KI = D/2 k-steps of 2 columns)
+  constexpr int NGI = (GI + NW - 1) / NW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, c31 = lane & 31;
   const int dbase = blockIdx.y * DW;
-  const bool chunk = wave < NC;
-  // register-resident B operand: ONE array serves both roles (chunk: [c2][o][nt], item: [j][nt]; KI*ND <= 64*ND)
-  float breg[64 * ND];
-  if (chunk) {
+  // register-resident B operands
+  float bf[NGF * 4 * ND], bi[NGI * 4 * ND];
 #pragma unroll
-    for (int c2 = 0; c2 < 16; ++c2)
+  for (int g = 0; g < NGF; ++g) {
+    const int q = wave * NGF + g, tq = q >> 4, c2 = q & 15;
 #pragma unroll
-      for (int o = 0; o < 4; ++o)
+    for (int o = 0; o < 4; ++o)
 #pragma unroll
-        for (int nt = 0; nt < ND; ++nt)
-          breg[(c2 * 4 + o) * ND + nt] = WT[(int64_t)(D + wave * 128 + 2 * c2 + h + 32 * o) * DP + dbase + nt * 32 + c31];
-  } else {
+      for (int nt = 0; nt < ND; ++nt)
+        bf[(g * 4 + o) * ND + nt] = WT[(int64_t)(D + tq * 128 + 2 * c2 + h + 32 * o) * DP + dbase + nt * 32 + c31];
+  }
 #pragma unroll
-    for (int j = 0; j < KI; ++j)
+  for (int gi = 0; gi < NGI; ++gi) {
+    const int jg = wave * NGI + gi;
 #pragma unroll
-      for (int nt = 0; nt < ND; ++nt) breg[j * ND + nt] = WT[(int64_t)(2 * j + h) * DP + dbase + nt * 32 + c31];
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int nt = 0; nt < ND; ++nt)
+        bi[(gi * 4 + o) * ND + nt] = jg < GI ? WT[(int64_t)(2 * (jg * 4 + o) + h) * DP + dbase + nt * 32 + c31] : 0.f;
   }
   const uint32_t rows_per_n = (uint32_t)(S1 * A);
   const int64_t ntiles = (L + 31) / 32;
+  const int dcol = dbase + lane;
+  const bool dv = lane < DW && dcol < D;
+  const float bias_d = bias[dv ? dcol : 0];
+  TRACE(1);
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // epilogue operands of this wave's 4 rows (wave, wave+8, wave+16, wave+24): independent of the k-loop, fetched first
+    float uval[4];
+    uint32_t kbits = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t lr = tile * 32 + wave + 8 * i;
+      const int64_t lrc = lr < L ? lr : (L - 1);
+      const int64_t u = X[2 * (int64_t)((uint32_t)lrc / rows_per_n)];
+      uval[i] = U[u * D + (dv ? dcol : 0)];
+      bool kept = true;
+      if (MODE == 1) {
+        if (keep) kept = keep[lrc * D + (dv ? dcol : 0)] != 0;
+      } else if (drop_thr) {
+        const u32x4 r4 = philox4x32_10((uint32_t)(lrc >> 2), (uint32_t)(dv ? dcol : 0), dkey.s0, dkey.s1, dkey.k0, dkey.k1);
+        kept = pick4(r4, (int)(lrc & 3)) >= drop_thr;
+      }
+      kbits |= (kept ? 1u : 0u) << i;
+    }
     const int64_t l = tile * 32 + c31;
     const bool lv = l < L;
     f32x16 acc[ND];
@@ -177,39 +223,46 @@ __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT,
     // which serialises the k-steps.  Rows past L read row L-1 (their results are never stored); columns past F read
     // column F-1 (their W rows are zero).
     const int64_t lc = lv ? l : L - 1;
-    if (chunk) {
+    {
       const int64_t it0 = X[2 * (int64_t)((uint32_t)lc / rows_per_n) + 1];
       const float* frow = feat + it0 * F;
       const float* nrow = MODE == 1 ? noise + lc * F : nullptr;
-      int fbase = wave * 128 + h;
-      asm volatile("" : "+v"(fbase));               // opaque per tile: the 64 clamped offsets below must not be hoisted
+      int fbase = h;
+      asm volatile("" : "+v"(fbase));               // opaque per tile: the clamped offsets below must not be hoisted
 #pragma unroll                                      // out of the tile loop and kept live (they would spill the W slice)
-      for (int c2 = 0; c2 < 16; ++c2) {
+      for (int g = 0; g < NGF; ++g) {
+        const int q = wave * NGF + g, tq = q >> 4, c2 = q & 15;
         float a[4], fv[4];
-        const int c = 2 * c2 + h;
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-          const int f = min(fbase + 2 * c2 + 32 * o, F - 1);
+          const int f = min(fbase + tq * 128 + 2 * c2 + 32 * o, F - 1);
           fv[o] = frow[f];
           if (MODE == 1) a[o] = nrow[f];
         }
-        if (MODE == 0) noise4((uint32_t)l, (uint32_t)(wave * 32 + c), nkey, nscale, a);
+        if (MODE == 0) noise4((uint32_t)l, (uint32_t)(tq * 32 + 2 * c2 + h), nkey, nscale, a);
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
           a[o] = fv[o] + a[o];                      // sample_feature_embeddings = feature + noise (DCCF.py:87)
 #pragma unroll
-          for (int nt = 0; nt < ND; ++nt) acc[nt] = MFMA32(a[o], breg[(c2 * 4 + o) * ND + nt], acc[nt]);
+          for (int nt = 0; nt < ND; ++nt) acc[nt] = MFMA32(a[o], bf[(g * 4 + o) * ND + nt], acc[nt]);
         }
       }
-    } else {
+    }
+    {
       const float* vrow = V + (int64_t)cand[(uint32_t)lc / (uint32_t)A] * D;
 #pragma unroll
-      for (int j = 0; j < KI; ++j) {
-        const float a = vrow[2 * j + h];
+      for (int gi = 0; gi < NGI; ++gi) {
+        const int jg = min(wave * NGI + gi, GI - 1);      // waves past the item part multiply zeros (bi = 0)
 #pragma unroll
-        for (int nt = 0; nt < ND; ++nt) acc[nt] = MFMA32(a, breg[j * ND + nt], acc[nt]);
+        for (int o = 0; o < 4; ++o) {
+          const float a = vrow[2 * (jg * 4 + o) + h];
+#pragma unroll
+          for (int nt = 0; nt < ND; ++nt) acc[nt] = MFMA32(a, bi[(gi * 4 + o) * ND + nt], acc[nt]);
+        }
       }
     }
+    KEEP(acc[0][0]);
+    TRACE(2);
 #pragma unroll
     for (int nt = 0; nt < ND; ++nt)
 #pragma unroll
@@ -218,39 +271,33 @@ __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT,
         zpart[(wave * 32 + row) * DW + nt * 32 + c31] = acc[nt][r];
       }
     __syncthreads();
-    for (int row = wave; row < 32; row += NW) {
+    TRACE(3);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wave + 8 * i;
       const int64_t lr = tile * 32 + row;
-      if (lr >= L) break;
-      const int64_t ns = lr / A;
-      const int64_t n = ns / S1;
-      const int64_t u = X[2 * n];
-      float part = 0.f;
-      for (int d0 = lane; d0 < DW; d0 += 64) {
-        const int d = dbase + d0;
-        if (d < D) {
-          float z = zpart[(NC * 32 + row) * DW + d0];        // item part first, then the feature chunks in order
-          for (int w = 0; w < NC; ++w) z += zpart[(w * 32 + row) * DW + d0];
-          z += bias[d];
-          bool kept = true;
-          if (MODE == 1) {
-            if (keep) kept = keep[lr * D + d] != 0;
-          } else if (drop_thr) {
-            const u32x4 r4 = philox4x32_10((uint32_t)(lr >> 2), (uint32_t)d, dkey.s0, dkey.s1, dkey.k0, dkey.k1);
-            kept = pick4(r4, (int)(lr & 3)) >= drop_thr;
-          }
-          const float hv = (z > 0.f && kept) ? z * kscale : 0.f;
-          hbuf[lr * DP + d] = hv;
-          part = fmaf(U[u * D + d], hv, part);
+      if (lr < L) {
+        float part = 0.f;
+        if (dv) {
+          float z = zpart[row * DW + lane];
+#pragma unroll
+          for (int w = 1; w < NW; ++w) z += zpart[(w * 32 + row) * DW + lane];
+          z += bias_d;
+          const float hv = (z > 0.f && ((kbits >> i) & 1u)) ? z * kscale : 0.f;
+          hbuf[lr * DP + dcol] = hv;
+          part = uval[i] * hv;
+        }
+        part = wave_sum(part);
+        if (lane == 0) {
+          if (gridDim.y == 1) m[lr] = part;
+          else atomicAdd(&m[lr], part);
         }
       }
-      part = wave_sum(part);
-      if (lane == 0) {
-        if (gridDim.y == 1) m[lr] = part;
-        else atomicAdd(&m[lr], part);
-      }
     }
+    TRACE(4);
     __syncthreads();
   }
+  TRACE(5);
 }
 
 // ================================================================================================ K1b: forward, large L
@@ -913,18 +960,26 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
 #undef LAUNCH_FWDR
     prof_end(ctx, 2, st);
   } else {
-    const dim3 grid((unsigned)min((int64_t)1024, ntiles), y.GY), block(64 * (y.NC + 1));
-    const size_t smem = (size_t)(y.NC + 1) * 32 * y.ND * 32 * 4;
+    const dim3 grid((unsigned)min((int64_t)1024, ntiles), y.GY), block(512);
+    const size_t smem = (size_t)8 * 32 * y.ND * 32 * 4;
     prof_begin(ctx, st);
-#define LAUNCH_FWD(D_)                                                                                               \
-  if (fused)                                                                                                         \
-    hipLaunchKernelGGL((k_noise_fwd<D_, 0>), grid, block, smem, st, WT, M->b, M->U, M->V, M->feat, X, cand, rnd->noise, \
-                       rnd->keep, hbuf, m, y.L, S1, A, F, nkey, dkey, nscale, thr, kscale, sr);                  \
-  else                                                                                                               \
-    hipLaunchKernelGGL((k_noise_fwd<D_, 1>), grid, block, smem, st, WT, M->b, M->U, M->V, M->feat, X, cand, rnd->noise, \
-                       rnd->keep, hbuf, m, y.L, S1, A, F, nkey, dkey, nscale, thr, kscale, sr);
+#define LAUNCH_FWD3(D_, MODE_, NCM_)                                                                                  \
+  {                                                                                                                  \
+    static bool once = false;                                                                                        \
+    if (!once) {                                                                                                     \
+      HIP_TRY(hipFuncSetAttribute((const void*)k_noise_fwd<D_, MODE_, NCM_>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
+      once = true;                                                                                                   \
+    }                                                                                                                \
+    hipLaunchKernelGGL((k_noise_fwd<D_, MODE_, NCM_>), grid, block, smem, st, WT, M->b, M->U, M->V, M->feat, X, cand, \
+                       rnd->noise, rnd->keep, hbuf, m, y.L, S1, A, F, nkey, dkey, nscale, thr, kscale, sr);        \
+  }
+#define LAUNCH_FWD2(D_, MODE_)                                              \
+  if (y.FP == 256) LAUNCH_FWD3(D_, MODE_, 2) else if (y.FP == 768) LAUNCH_FWD3(D_, MODE_, 6) else LAUNCH_FWD3(D_, MODE_, 7)
+#define LAUNCH_FWD(D_) if (fused) LAUNCH_FWD2(D_, 0) else LAUNCH_FWD2(D_, 1)
     BY_D(D, LAUNCH_FWD)
 #undef LAUNCH_FWD
+#undef LAUNCH_FWD2
+#undef LAUNCH_FWD3
     prof_end(ctx, 2, st);
   }
   {
