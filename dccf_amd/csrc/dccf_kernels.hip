@@ -121,12 +121,19 @@ __global__ void k_prep(dccf_model_t M, float* __restrict__ WT, int D, int F, int
 // Development aid (never built by default): wall-clock stamps (100 MHz) of workgroup 0's waves at phase boundaries.
 __device__ long long dccf_trace[8 * 16];
 #define TRACE(slot) if (blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0) dccf_trace[(threadIdx.x >> 6) * 16 + (slot)] = wall_clock64()
+__device__ long long dccf_trace_b[8 * 8 * 8];     // backward: [role][wave][slot]
+#define TRACEB(role, slot) if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (role) < 8) dccf_trace_b[(((role) * 8) + (threadIdx.x >> 6)) * 8 + (slot)] = wall_clock64()
+extern "C" int dccf_debug_trace_read_b(long long* out) {
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(dccf_trace_b), sizeof(long long) * 8 * 8 * 8));
+  return 0;
+}
 extern "C" int dccf_debug_trace_read(long long* out) {
   HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(dccf_trace), sizeof(long long) * 8 * 16));
   return 0;
 }
 #else
 #define TRACE(slot)
+#define TRACEB(role, slot)
 #endif
 
 // ================================================================================================ K1: forward
@@ -554,6 +561,10 @@ __global__ __launch_bounds__(256) void k_pair_epilogue(int S1, int A, const floa
   }
 }
 
+// Waves per backward workgroup.  8 (two per SIMD, 225 VGPRs) was measured too: the dx role drops 22 -> 14 us and the chunk
+// roles 19 -> 18 us at B=128 (kernel 28.7 -> 27.7 us), but B=4096 loses 4 % (0.411 -> 0.428 ms) — the k-loop is bound by the
+// shared VALU / fp32-MFMA pipe (Philox + Box-Muller ~600 cycles + 8 MFMAs = 512 cycles per k-step), not by latency.
+#define BWD_NW 4
 // ================================================================================================ K3: backward
 // dz[l][d] = dm[l] * U[u(l)][d] * [h[l][d] > 0] * kscale is never stored: every role rebuilds the operand it needs from
 // h, dm and the user row.  grid = (row splits, roles x column halves); a workgroup has ONE role and 4 waves that split
@@ -595,7 +606,8 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
   const int S1 = p.S1, A = p.A, F = p.F;
   const int rpn = S1 * A;
   const int KS = (rpn + 1) / 2;
-  const int64_t n0 = (int64_t)blockIdx.x * 4 + wave, nstride = (int64_t)gridDim.x * 4;
+  const int64_t n0 = (int64_t)blockIdx.x * BWD_NW + wave, nstride = (int64_t)gridDim.x * BWD_NW;
+  TRACEB(role, 0);
   f32x16 acc[ND][NB];
 #pragma unroll
   for (int mt = 0; mt < ND; ++mt)
@@ -705,10 +717,12 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
       if (p.touchedU && lane == 0) p.touchedU[u] = 1;
     }
   }
+  KEEP(acc[0][0][0]);
+  TRACEB(role, 1);
   // sum the 4 waves' accumulators through LDS in rounds of 32 registers (32 KB of LDS, so several workgroups fit on
   // a CU), each wave emits a quarter of every round
   constexpr int NQ = ND * NB * 16;        // accumulator registers per lane
-  constexpr int RQ = 32;
+  constexpr int RQ = 128 / BWD_NW;        // registers per round: BWD_NW * RQ * 256 B = 32 KB of LDS
 #pragma unroll
   for (int q0 = 0; q0 < NQ; q0 += RQ) {
     __syncthreads();
@@ -718,11 +732,12 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
       red[(wave * RQ + qq) * 64 + lane] = acc[q / (NB * 16)][(q / 16) % NB][q % 16];
     }
     __syncthreads();
-    for (int qq = wave; qq < RQ; qq += 4) {
+    for (int qq = wave; qq < RQ; qq += BWD_NW) {
       const int q = q0 + qq;
       const int mt = q / (NB * 16), o = (q / 16) % NB, r = q % 16;
-      const float v = red[(0 * RQ + qq) * 64 + lane] + red[(1 * RQ + qq) * 64 + lane] + red[(2 * RQ + qq) * 64 + lane] +
-                      red[(3 * RQ + qq) * 64 + lane];
+      float v = red[qq * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < BWD_NW; ++w) v += red[(w * RQ + qq) * 64 + lane];
       const int d = dbase + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
       const int col = CHUNK ? D + role * 128 + 32 * o + c31 : o * 32 + c31;
       const bool ok = d < D && (CHUNK ? (role * 128 + 32 * o + c31 < F) : (col < D));
@@ -734,6 +749,7 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
     for (int mt = 0; mt < ND; ++mt)
       if (dok[mt]) atomicAdd(&p.gb[dbase + mt * 32 + c31], gb_acc[mt]);
   }
+  TRACEB(role, 2);
 }
 
 // role "dx": gV[cand] += dz W_i   (MFMA: M = rows of n, N = d', K = d)
@@ -746,7 +762,8 @@ __device__ __forceinline__ void bwd_dx_role(const BwdArgs& p, int dbase) {
   const int h = lane >> 5, c31 = lane & 31;
   const int S1 = p.S1, A = p.A, F = p.F;
   const int rpn = S1 * A;
-  const int64_t n0 = (int64_t)blockIdx.x * 4 + wave, nstride = (int64_t)gridDim.x * 4;
+  const int64_t n0 = (int64_t)blockIdx.x * BWD_NW + wave, nstride = (int64_t)gridDim.x * BWD_NW;
+  TRACEB(7, 0);
   float wd[KD][ND];                         // W_i rows 2j+h, this block's column half
 #pragma unroll
   for (int j = 0; j < KD; ++j)
@@ -825,8 +842,8 @@ __device__ __forceinline__ void bwd_dx_role(const BwdArgs& p, int dbase) {
 }
 
 template <int D_, int MODE>
-__global__ __launch_bounds__(256) void k_bwd(BwdArgs p) {
-  extern __shared__ float red[];          // [4 waves][32 regs][64 lanes]
+__global__ __launch_bounds__(64 * BWD_NW) void k_bwd(BwdArgs p) {
+  extern __shared__ float red[];          // [BWD_NW waves][128 / BWD_NW regs][64 lanes]
   {
     const int64_t k = step_k(p.sr);
     p.X = step_X(p.sr, p.X, k);
@@ -839,6 +856,7 @@ __global__ __launch_bounds__(256) void k_bwd(BwdArgs p) {
   if (role < p.NC) bwd_col_role<D_, MODE, true>(p, red, role, dbase);
   else if (role == p.NC) bwd_col_role<D_, MODE, false>(p, red, role, dbase);
   else bwd_dx_role<D_>(p, dbase);
+  if (role > p.NC) TRACEB(7, 2);
 }
 
 // ================================================================================================ host side
@@ -999,7 +1017,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     // wave) per workgroup at least
     const int roles = (y.NC + 2) * y.GY;
     // small batches: ~1 workgroup per CU; large ones: ~4 per CU (4 waves per SIMD fill the shared VALU / fp32-MFMA pipe)
-    const int64_t gx = max((int64_t)1, min((N + 3) / 4, (int64_t)max(1, (N >= 2048 ? 1024 : 256) / roles)));
+    const int64_t gx = max((int64_t)1, min((N + BWD_NW - 1) / BWD_NW, (int64_t)max(1, (N >= 2048 ? 1024 : 256) / roles)));
     const dim3 grid((unsigned)gx, (unsigned)roles);
     const size_t smem = (size_t)4 * 32 * 64 * 4;
     prof_begin(ctx, st);
@@ -1010,14 +1028,14 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
       HIP_TRY(hipFuncSetAttribute((const void*)k_bwd<D_, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
       once0 = true;                                                                                                 \
     }                                                                                                               \
-    hipLaunchKernelGGL((k_bwd<D_, 0>), grid, dim3(256), smem, st, ba);                                              \
+    hipLaunchKernelGGL((k_bwd<D_, 0>), grid, dim3(64 * BWD_NW), smem, st, ba);                                              \
   } else {                                                                                                          \
     static bool once1 = false;                                                                                      \
     if (!once1) {                                                                                                   \
       HIP_TRY(hipFuncSetAttribute((const void*)k_bwd<D_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
       once1 = true;                                                                                                 \
     }                                                                                                               \
-    hipLaunchKernelGGL((k_bwd<D_, 1>), grid, dim3(256), smem, st, ba);                                              \
+    hipLaunchKernelGGL((k_bwd<D_, 1>), grid, dim3(64 * BWD_NW), smem, st, ba);                                              \
   }
     BwdArgs ba;
     ba.W = M->W; ba.U = M->U; ba.V = M->V; ba.feat = M->feat; ba.X = X; ba.cand = cand; ba.dmns = dmns; ba.hbuf = hbuf;
