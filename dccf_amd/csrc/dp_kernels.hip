@@ -7,8 +7,8 @@
 //                       tail [dW | db] and the loss.
 //   dp_import_touched   after the all-gather: g[row] = sum over ranks IN RANK ORDER of the received rows (so that every
 //                       replica computes bit-identical sums and the replicas never drift apart), sets the "touched" bytes,
-//                       dense tail = sum over ranks in rank order.  No atomics on data: a workgroup owns the destination
-//                       rows with (row + segment) mod #workgroups == its index.
+//                       dense tail = sum over ranks in rank order.  No atomics on data: a per-row bit mask of the
+//                       contributing ranks + a where-table make the rank-ordered walk possible.
 //
 // Buffer of one rank (32-bit words): [count | loss | pad pad | ids int64[cap] | rows fp32[cap][D] | dense fp32[nd]].
 #include "common.hpp"
@@ -16,7 +16,6 @@
 
 #define DP_HDR 4
 #define DP_GMAX 16
-#define DP_LCAP 64
 
 struct DpLay {
   int64_t cap, nd, ids_off, rows_off, dense_off, words;
@@ -137,14 +136,57 @@ extern "C" int dp_export_touched(float* g, int64_t n, int32_t nseg, const int64_
 }
 
 // ---------------------------------------------------------------------------------------------- import
-__global__ __launch_bounds__(256) void k_dp_import(const float* __restrict__ bufs, int G, float* __restrict__ g, RowSegs sg,
-                                                   int64_t dense_begin, float* __restrict__ loss_sum, DpLay y, int row_blocks,
-                                                   int lcap, float* reset_buf) {
-  __shared__ int64_t lid[DP_GMAX][DP_LCAP];      // ids of the entries this workgroup owns, per source rank
-  __shared__ int lent[DP_GMAX][DP_LCAP];         // their entry index in the rank's buffer
-  __shared__ int lcnt[DP_GMAX];
-  __shared__ int overflow;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// Two launches.  (A) one thread per received entry (r, e): records where rank r keeps destination row x
+// (where[r][x] = e), sets bit r of mask[x]; the first arriver (any rank) appends x to the step's leader list.
+// (B) a 16-lane group per listed row walks the set bits of mask[x] in ASCENDING rank order and sums the rows — the order
+// of the floating-point additions is the same on every replica, whatever the arrival order in (A) was — stores the sum
+// (the row was zero: exported rows are zeroed), sets the "touched" byte and clears mask[x] for the next step.  Extra
+// workgroups of (B) sum the dense tails and the losses in rank order.
+struct DpRows {
+  int64_t begin[4];      // element offset of segment q in g
+  int64_t rowoff[4];     // first global row index of segment q
+  uint8_t* flags[4];
+  int n;
+};
+
+__global__ __launch_bounds__(256) void k_dp_scatter_ids(const float* __restrict__ bufs, int G, DpLay y, DpRows sg, int64_t R,
+                                                        uint32_t* __restrict__ mask, int* __restrict__ where,
+                                                        int64_t* __restrict__ leaders, int* __restrict__ cnt,
+                                                        int* __restrict__ cnt_next) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *cnt_next = 0;
+  const int lane = threadIdx.x & 63;
+  const int64_t total = (int64_t)G * y.cap;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (total + 63) / 64 * 64; i += (int64_t)gridDim.x * blockDim.x) {
+    bool first = false;
+    int64_t id = 0;
+    if (i < total) {
+      const int r = (int)(i / y.cap);
+      const int e = (int)(i % y.cap);
+      const float* b = bufs + (int64_t)r * y.words;
+      const int n = min((int64_t)reinterpret_cast<const int*>(b)[0], y.cap);
+      if (e < n) {
+        id = reinterpret_cast<const int64_t*>(b + y.ids_off)[e];
+        const int64_t gid = sg.rowoff[(int)(id >> 40)] + (id & ((1LL << 40) - 1));
+        where[(int64_t)r * R + gid] = e;
+        first = atomicOr(&mask[gid], 1u << r) == 0u;
+      }
+    }
+    const uint64_t bal = __ballot(first);
+    if (bal) {
+      const int leader = __ffsll((unsigned long long)bal) - 1;
+      int base = 0;
+      if (lane == leader) base = atomicAdd(cnt, __popcll(bal));
+      base = __shfl(base, leader, 64);
+      if (first) leaders[base + __popcll(bal & ((1ull << lane) - 1))] = id;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_dp_sum_rows(const float* __restrict__ bufs, int G, float* __restrict__ g, DpRows sg,
+                                                     int64_t dense_begin, float* __restrict__ loss_sum, DpLay y, int64_t R,
+                                                     uint32_t* __restrict__ mask, const int* __restrict__ where,
+                                                     const int64_t* __restrict__ leaders, const int* __restrict__ cnt,
+                                                     int row_blocks, float* reset_buf) {
   if ((int)blockIdx.x >= row_blocks) {           // dense tail: sum in rank order
     const int64_t tid = (int64_t)(blockIdx.x - row_blocks) * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)(gridDim.x - row_blocks) * blockDim.x;
@@ -161,107 +203,66 @@ __global__ __launch_bounds__(256) void k_dp_import(const float* __restrict__ buf
     }
     return;
   }
-  if (threadIdx.x < DP_GMAX) lcnt[threadIdx.x] = 0;
-  if (threadIdx.x == 0) overflow = 0;
-  __syncthreads();
-  // 1. collect the entries whose destination row this workgroup owns
-  for (int r = 0; r < G; ++r) {
-    const float* b = bufs + (int64_t)r * y.words;
-    const int n = min((int64_t)reinterpret_cast<const int*>(b)[0], y.cap);
-    const int64_t* ids = reinterpret_cast<const int64_t*>(b + y.ids_off);
-    for (int e = threadIdx.x; e < n; e += blockDim.x) {
-      const int64_t id = ids[e];
-      if ((int)(((id & ((1LL << 40) - 1)) + (id >> 40)) % row_blocks) == (int)blockIdx.x) {
-        const int pos = atomicAdd(&lcnt[r], 1);
-        if (pos < lcap) { lid[r][pos] = id; lent[r][pos] = e; }
-        else overflow = 1;
-      }
-    }
-  }
-  __syncthreads();
-  if (overflow) {
-    // slow but order-preserving fallback (a list did not fit): rank after rank, re-scanning the ids
-    for (int r = 0; r < G; ++r) {
-      const float* b = bufs + (int64_t)r * y.words;
-      const int n = min((int64_t)reinterpret_cast<const int*>(b)[0], y.cap);
-      const int64_t* ids = reinterpret_cast<const int64_t*>(b + y.ids_off);
-      for (int e = wave; e < n; e += 4) {
-        const int64_t id = ids[e];
-        const int q = (int)(id >> 40);
-        const int64_t row = id & ((1LL << 40) - 1);
-        if ((int)((row + q) % row_blocks) != (int)blockIdx.x) continue;
-        float* grow = g + sg.begin[q] + row * sg.width[q];
-        for (int c = lane; c < y.D; c += 64) grow[c] += b[y.rows_off + (int64_t)e * y.D + c];
-        if (lane == 0) sg.flags[q][row] = 1;
-      }
-      __syncthreads();
-    }
-    return;
-  }
-  // 2. every owned entry looks for the same row in lower ranks (then it is not the leader) and, as leader, adds the
-  //    matching rows of the higher ranks in rank order
-  int total = 0;
-  for (int r = 0; r < G; ++r) total += lcnt[r];
-  for (int t = wave; t < total; t += 4) {
-    int r = 0, j = t;
-    while (j >= lcnt[r]) { j -= lcnt[r]; ++r; }
-    const int64_t id = lid[r][j];
-    bool dup = false;
-    for (int r2 = 0; r2 < r && !dup; ++r2)
-      for (int k0 = 0; k0 < lcnt[r2]; k0 += 64) {
-        const bool hit = k0 + lane < lcnt[r2] && lid[r2][k0 + lane] == id;
-        if (__ballot(hit)) { dup = true; break; }
-      }
-    if (dup) continue;
+  const int n = *cnt;
+  const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;       // 16 lanes x float4 per row
+  const int d4 = y.D >> 2;
+  for (int t = blockIdx.x * 16 + grp; t < n; t += row_blocks * 16) {
+    const int64_t id = leaders[t];
     const int q = (int)(id >> 40);
     const int64_t row = id & ((1LL << 40) - 1);
-    float acc[2] = {0.f, 0.f};                        // D <= 128: two columns per lane
-    {
-      const float* src = bufs + (int64_t)r * y.words + y.rows_off + (int64_t)lent[r][j] * y.D;
-      for (int c = lane, i = 0; c < y.D; c += 64, ++i) acc[i] = src[c];
-    }
-    for (int r2 = r + 1; r2 < G; ++r2) {
-      int found = -1;
-      for (int k0 = 0; k0 < lcnt[r2] && found < 0; k0 += 64) {
-        const bool hit = k0 + lane < lcnt[r2] && lid[r2][k0 + lane] == id;
-        const uint64_t m = __ballot(hit);
-        if (m) found = k0 + __ffsll((unsigned long long)m) - 1;
+    const int64_t gid = sg.rowoff[q] + row;
+    uint32_t m = mask[gid];
+    float4 acc[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};      // D <= 128: two float4 per lane
+    bool firstr = true;
+    while (m) {
+      const int r = __ffs(m) - 1;
+      m &= m - 1;
+      const float4* src = reinterpret_cast<const float4*>(bufs + (int64_t)r * y.words + y.rows_off +
+                                                           (int64_t)where[(int64_t)r * R + gid] * y.D);
+      for (int c = sub, i = 0; c < d4; c += 16, ++i) {
+        const float4 v = src[c];
+        if (firstr) acc[i] = v;
+        else { acc[i].x += v.x; acc[i].y += v.y; acc[i].z += v.z; acc[i].w += v.w; }
       }
-      if (found >= 0) {
-        const float* src = bufs + (int64_t)r2 * y.words + y.rows_off + (int64_t)lent[r2][found] * y.D;
-        for (int c = lane, i = 0; c < y.D; c += 64, ++i) acc[i] += src[c];
-      }
+      firstr = false;
     }
-    float* grow = g + sg.begin[q] + row * sg.width[q];
-    for (int c = lane, i = 0; c < y.D; c += 64, ++i) grow[c] = acc[i];     // the row was zero: exported rows are zeroed
-    if (lane == 0) sg.flags[q][row] = 1;
+    float4* dst = reinterpret_cast<float4*>(g + sg.begin[q] + row * y.D);
+    for (int c = sub, i = 0; c < d4; c += 16, ++i) dst[c] = acc[i];
+    if (sub == 0) {
+      sg.flags[q][row] = 1;
+      mask[gid] = 0u;
+    }
   }
 }
 
 extern "C" int dp_import_touched(const float* bufs, int32_t G, float* g, int64_t n, int32_t nseg, const int64_t* seg_begin,
                                  const int64_t* seg_rows, const int32_t* seg_width, uint8_t* const* seg_flags,
-                                 int64_t dense_begin, float* loss_sum, int64_t cap, int32_t D, int32_t list_cap,
-                                 float* reset_buf, void* stream) {
+                                 int64_t dense_begin, float* loss_sum, int64_t cap, int32_t D, uint32_t* mask, int32_t* where,
+                                 int64_t* leaders, int32_t* cnt, int32_t* cnt_next, float* reset_buf, void* stream) {
   ARG_CHECK(bufs && g && G >= 1 && G <= DP_GMAX, "1..16 ranks");
   ARG_CHECK(nseg >= 1 && nseg <= 4 && seg_begin && seg_rows && seg_width && seg_flags, "bad segments");
-  ARG_CHECK(D >= 1 && D <= 128 && cap >= 1 && dense_begin >= 0 && dense_begin <= n, "bad D / cap / dense_begin");
-  ARG_CHECK(list_cap >= 0 && list_cap <= DP_LCAP, "list_cap in [0, 64] (0 = default)");
-  RowSegs sg;
+  ARG_CHECK(D >= 4 && D <= 128 && D % 4 == 0 && cap >= 1 && dense_begin >= 0 && dense_begin <= n, "bad D / cap / dense_begin");
+  ARG_CHECK(mask && where && leaders && cnt && cnt_next, "NULL scratch");
+  DpRows sg;
   memset(&sg, 0, sizeof(sg));
   sg.n = nseg;
+  int64_t R = 0;
   for (int q = 0; q < nseg; ++q) {
     ARG_CHECK(seg_width[q] == D && seg_flags[q], "every row segment must have width D and flags");
     sg.begin[q] = seg_begin[q];
-    sg.end[q] = seg_begin[q] + seg_rows[q] * D;
-    sg.width[q] = D;
+    sg.rowoff[q] = R;
     sg.flags[q] = seg_flags[q];
+    R += seg_rows[q];
   }
   const DpLay y = dp_layout(cap, D, n - dense_begin);
-  // about 4 owned entries per (workgroup, rank): lists of 64 overflow only in adversarial cases (handled, slowly)
-  const int row_blocks = (int)max((int64_t)64, min((int64_t)2048, cap / 4));
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t total = (int64_t)G * cap;
+  hipLaunchKernelGGL(k_dp_scatter_ids, dim3((unsigned)min((int64_t)1024, (total + 255) / 256)), dim3(256), 0, st, bufs, G, y, sg,
+                     R, mask, where, leaders, cnt, cnt_next);
+  const int row_blocks = (int)max((int64_t)1, min((int64_t)2048, (total + 15) / 16));
   const int dense_blocks = (int)max((int64_t)1, min((int64_t)256, (y.nd + 255) / 256));
-  hipLaunchKernelGGL(k_dp_import, dim3(row_blocks + dense_blocks), dim3(256), 0, (hipStream_t)stream, bufs, G, g, sg,
-                     dense_begin, loss_sum, y, row_blocks, list_cap > 0 ? list_cap : DP_LCAP, reset_buf);
+  hipLaunchKernelGGL(k_dp_sum_rows, dim3(row_blocks + dense_blocks), dim3(256), 0, st, bufs, G, g, sg, dense_begin, loss_sum, y,
+                     R, mask, where, leaders, cnt, row_blocks, reset_buf);
   HIP_TRY(hipGetLastError());
   return 0;
 }
