@@ -91,7 +91,7 @@ def load():
         'dccf_dense_opt_phase': [i32, vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, i32, C.POINTER(i64), C.POINTER(i64),
                                  C.POINTER(i32), C.POINTER(vp), i32, vp, vp, i64, vp],
         'dp_export_touched': [vp, i64, i32, vp, vp, vp, vp, i64, vp, vp, i64, i32, i32, vp],
-        'dp_import_touched': [vp, i32, vp, i64, i32, vp, vp, vp, vp, i64, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp],
+        'dp_import_touched': [vp, i32, vp, i64, i32, vp, vp, vp, vp, i64, vp, i64, i32, vp, vp, vp, vp],
         'dccf_train_step': [vp, C.POINTER(ModelT), C.POINTER(RandT), vp, vp, i64, i32, f32, C.POINTER(GradsT),
                             C.POINTER(OptT), vp, vp, vp],
         'rank_eval_topk': [vp, vp, vp, vp, i64, C.POINTER(i32), vp, i32, vp, vp],
@@ -429,25 +429,19 @@ def dp_export_touched(g, segments, dense_begin, loss, buf, cap, D, reset=True):
 
 
 class DpScratch(object):
-    """Scratch of dp_import_touched for R rows, G ranks, `cap` entries per rank."""
+    """Scratch of dp_import_touched for R rows and G ranks."""
 
-    def __init__(self, R, G, cap, device):
+    def __init__(self, R, G, device):
         self.mask = torch.zeros(R, dtype=torch.int32, device=device)
         self.where = torch.empty(G * R, dtype=torch.int32, device=device)
-        self.leaders = torch.empty(G * cap, dtype=torch.int64, device=device)
-        self.cnt = torch.zeros(2, dtype=torch.int32, device=device)
-        self.parity = 0
 
 
 def dp_import_touched(bufs, G, g, segments, dense_begin, loss_sum, cap, D, scratch, reset_buf=None):
     """g <- rank-ordered sum of the G gathered buffers (rows, dense tail); sets the touched bytes."""
     n, beg, rows, wid, fl = _seg_arrays(segments)
-    c = ptr(scratch.cnt, torch.int32)
     check(load().dp_import_touched(ptr(bufs, torch.float32), int(G), ptr(g, torch.float32), g.numel(), n, beg, rows, wid, fl,
                                    int(dense_begin), ptr(loss_sum), int(cap), int(D), ptr(scratch.mask, torch.int32),
-                                   ptr(scratch.where, torch.int32), ptr(scratch.leaders, torch.int64),
-                                   c + 4 * scratch.parity, c + 4 * (1 - scratch.parity), ptr(reset_buf), stream()))
-    scratch.parity ^= 1
+                                   ptr(scratch.where, torch.int32), ptr(reset_buf), stream()))
 
 
 def dp_mark_global(X_all, S, item_num, seed, step0, flagsU, flagsV, list_, cnt, parity, segU=0, segV=1):

@@ -15,6 +15,7 @@
 #include "opt_device.hpp"
 
 #define DP_HDR 4
+#define KEEPI(x) asm volatile("" ::"v"(x))
 #define DP_GMAX 16
 
 struct DpLay {
@@ -137,11 +138,10 @@ extern "C" int dp_export_touched(float* g, int64_t n, int32_t nseg, const int64_
 
 // ---------------------------------------------------------------------------------------------- import
 // Two launches.  (A) one thread per received entry (r, e): records where rank r keeps destination row x
-// (where[r][x] = e), sets bit r of mask[x]; the first arriver (any rank) appends x to the step's leader list.
-// (B) a 16-lane group per listed row walks the set bits of mask[x] in ASCENDING rank order and sums the rows — the order
-// of the floating-point additions is the same on every replica, whatever the arrival order in (A) was — stores the sum
-// (the row was zero: exported rows are zeroed), sets the "touched" byte and clears mask[x] for the next step.  Extra
-// workgroups of (B) sum the dense tails and the losses in rank order.
+// (where[r][x] = e) and sets bit r of mask[x].  (B) a 16-lane group per entry; the entry of the lowest contributing rank
+// walks the other set bits of mask[x] in ASCENDING rank order and sums the rows — the order of the floating-point
+// additions is the same on every replica — stores the sum (the row was zero: exported rows are zeroed), sets the
+// "touched" byte and clears mask[x] for the next step.  Extra workgroups of (B) sum the dense tails and losses likewise.
 struct DpRows {
   int64_t begin[4];      // element offset of segment q in g
   int64_t rowoff[4];     // first global row index of segment q
@@ -150,42 +150,40 @@ struct DpRows {
 };
 
 __global__ __launch_bounds__(256) void k_dp_scatter_ids(const float* __restrict__ bufs, int G, DpLay y, DpRows sg, int64_t R,
-                                                        uint32_t* __restrict__ mask, int* __restrict__ where,
-                                                        int64_t* __restrict__ leaders, int* __restrict__ cnt,
-                                                        int* __restrict__ cnt_next) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) *cnt_next = 0;
-  const int lane = threadIdx.x & 63;
-  const int64_t total = (int64_t)G * y.cap;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (total + 63) / 64 * 64; i += (int64_t)gridDim.x * blockDim.x) {
-    bool first = false;
-    int64_t id = 0;
-    if (i < total) {
-      const int r = (int)(i / y.cap);
-      const int e = (int)(i % y.cap);
-      const float* b = bufs + (int64_t)r * y.words;
-      const int n = min((int64_t)reinterpret_cast<const int*>(b)[0], y.cap);
-      if (e < n) {
-        id = reinterpret_cast<const int64_t*>(b + y.ids_off)[e];
-        const int64_t gid = sg.rowoff[(int)(id >> 40)] + (id & ((1LL << 40) - 1));
-        where[(int64_t)r * R + gid] = e;
-        first = atomicOr(&mask[gid], 1u << r) == 0u;
-      }
-    }
-    const uint64_t bal = __ballot(first);
-    if (bal) {
-      const int leader = __ffsll((unsigned long long)bal) - 1;
-      int base = 0;
-      if (lane == leader) base = atomicAdd(cnt, __popcll(bal));
-      base = __shfl(base, leader, 64);
-      if (first) leaders[base + __popcll(bal & ((1ull << lane) - 1))] = id;
+                                                        uint32_t* __restrict__ mask, int* __restrict__ where) {
+  __shared__ int scnt[DP_GMAX];
+  if (threadIdx.x < G) scnt[threadIdx.x] = min((int64_t)reinterpret_cast<const int*>(bufs + (int64_t)threadIdx.x * y.words)[0], y.cap);
+  __syncthreads();
+  const int cap = (int)y.cap, total = G * cap;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int r = i / cap;
+    const int e = i - r * cap;
+    const float* b = bufs + (int64_t)r * y.words;
+    if (e < scnt[r]) {
+      const int64_t id = reinterpret_cast<const int64_t*>(b + y.ids_off)[e];
+      const int64_t gid = sg.rowoff[(int)(id >> 40)] + (id & ((1LL << 40) - 1));
+      where[(int64_t)r * R + gid] = e;
+      atomicOr(&mask[gid], 1u << r);
     }
   }
 }
 
+// One 16-lane group per received entry (r, e).  The entry of the LOWEST contributing rank owns the destination row: it adds
+// the other ranks' rows in ascending rank order, stores the sum, sets the byte and clears the mask (a later reader of a
+// cleared mask is a non-owner and skips, as it would have anyway).
+#ifdef DCCF_TRACE
+__device__ long long dp_trace[16];
+#define DPT(k) if (blockIdx.x == 0 && threadIdx.x == 0) dp_trace[k] = wall_clock64()
+extern "C" int dp_debug_trace_read(long long* out) {
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(dp_trace), sizeof(long long) * 16));
+  return 0;
+}
+#else
+#define DPT(k)
+#endif
 __global__ __launch_bounds__(256) void k_dp_sum_rows(const float* __restrict__ bufs, int G, float* __restrict__ g, DpRows sg,
                                                      int64_t dense_begin, float* __restrict__ loss_sum, DpLay y, int64_t R,
                                                      uint32_t* __restrict__ mask, const int* __restrict__ where,
-                                                     const int64_t* __restrict__ leaders, const int* __restrict__ cnt,
                                                      int row_blocks, float* reset_buf) {
   if ((int)blockIdx.x >= row_blocks) {           // dense tail: sum in rank order
     const int64_t tid = (int64_t)(blockIdx.x - row_blocks) * blockDim.x + threadIdx.x;
@@ -203,46 +201,73 @@ __global__ __launch_bounds__(256) void k_dp_sum_rows(const float* __restrict__ b
     }
     return;
   }
-  const int n = *cnt;
+  DPT(0);
   const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;       // 16 lanes x float4 per row
   const int d4 = y.D >> 2;
-  for (int t = blockIdx.x * 16 + grp; t < n; t += row_blocks * 16) {
-    const int64_t id = leaders[t];
+  const int cap = (int)y.cap, total = G * cap;              // < 2^31 (checked on the host): 32-bit index arithmetic
+  const int t = blockIdx.x * 16 + grp;                      // one group per entry, no loop
+  if (t >= total) return;
+  {
+    const int r = t / cap;
+    const int e = t - r * cap;
+    const float* b = bufs + (int64_t)r * y.words;
+    DPT(1);
+    // No entry count is read here (a header word read by every group of the grid is a hot spot): an entry is live iff
+    // this step's scatter pass registered exactly it — bit r of the row's mask set and where[r][row] == e.  Slots past a
+    // rank's count hold ids of earlier steps (or zeros) and fail that test.
+    const int64_t id = reinterpret_cast<const int64_t*>(b + y.ids_off)[e];
+    DPT(2);
     const int q = (int)(id >> 40);
     const int64_t row = id & ((1LL << 40) - 1);
+    if (q >= sg.n) return;
     const int64_t gid = sg.rowoff[q] + row;
     uint32_t m = mask[gid];
-    float4 acc[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};      // D <= 128: two float4 per lane
-    bool firstr = true;
-    while (m) {
-      const int r = __ffs(m) - 1;
-      m &= m - 1;
-      const float4* src = reinterpret_cast<const float4*>(bufs + (int64_t)r * y.words + y.rows_off +
-                                                           (int64_t)where[(int64_t)r * R + gid] * y.D);
-      for (int c = sub, i = 0; c < d4; c += 16, ++i) {
-        const float4 v = src[c];
-        if (firstr) acc[i] = v;
-        else { acc[i].x += v.x; acc[i].y += v.y; acc[i].z += v.z; acc[i].w += v.w; }
-      }
-      firstr = false;
+    const int we = where[(int64_t)r * R + gid];
+    DPT(3);
+    if (m == 0u || (__ffs(m) - 1) != r || we != e || sub >= d4) return;   // stale slot, or not the owner of this row
+    // D <= 128: two float4 per lane (columns sub and sub + 16), in named registers — an indexed array here ends up in LDS
+    const bool two = sub + 16 < d4;
+    float4 a0, a1 = make_float4(0, 0, 0, 0);
+    {
+      const float4* src = reinterpret_cast<const float4*>(b + y.rows_off + (int64_t)e * y.D);
+      a0 = src[sub];
+      if (two) a1 = src[sub + 16];
     }
+    m &= m - 1;
+    while (m) {
+      const int r2 = __ffs(m) - 1;
+      m &= m - 1;
+      const float4* src = reinterpret_cast<const float4*>(bufs + (int64_t)r2 * y.words + y.rows_off +
+                                                           (int64_t)where[(int64_t)r2 * R + gid] * y.D);
+      const float4 v0 = src[sub];
+      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+      if (two) {
+        const float4 v1 = src[sub + 16];
+        a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+      }
+    }
+    DPT(4);
     float4* dst = reinterpret_cast<float4*>(g + sg.begin[q] + row * y.D);
-    for (int c = sub, i = 0; c < d4; c += 16, ++i) dst[c] = acc[i];
+    dst[sub] = a0;
+    if (two) dst[sub + 16] = a1;
     if (sub == 0) {
       sg.flags[q][row] = 1;
       mask[gid] = 0u;
     }
+    DPT(5);
   }
+  DPT(6);
 }
 
 extern "C" int dp_import_touched(const float* bufs, int32_t G, float* g, int64_t n, int32_t nseg, const int64_t* seg_begin,
                                  const int64_t* seg_rows, const int32_t* seg_width, uint8_t* const* seg_flags,
                                  int64_t dense_begin, float* loss_sum, int64_t cap, int32_t D, uint32_t* mask, int32_t* where,
-                                 int64_t* leaders, int32_t* cnt, int32_t* cnt_next, float* reset_buf, void* stream) {
+                                 float* reset_buf, void* stream) {
   ARG_CHECK(bufs && g && G >= 1 && G <= DP_GMAX, "1..16 ranks");
   ARG_CHECK(nseg >= 1 && nseg <= 4 && seg_begin && seg_rows && seg_width && seg_flags, "bad segments");
   ARG_CHECK(D >= 4 && D <= 128 && D % 4 == 0 && cap >= 1 && dense_begin >= 0 && dense_begin <= n, "bad D / cap / dense_begin");
-  ARG_CHECK(mask && where && leaders && cnt && cnt_next, "NULL scratch");
+  ARG_CHECK(mask && where, "NULL scratch");
+  ARG_CHECK((int64_t)G * cap < 2147483647LL, "G * cap must be < 2^31");
   DpRows sg;
   memset(&sg, 0, sizeof(sg));
   sg.n = nseg;
@@ -258,11 +283,11 @@ extern "C" int dp_import_touched(const float* bufs, int32_t G, float* g, int64_t
   hipStream_t st = (hipStream_t)stream;
   const int64_t total = (int64_t)G * cap;
   hipLaunchKernelGGL(k_dp_scatter_ids, dim3((unsigned)min((int64_t)1024, (total + 255) / 256)), dim3(256), 0, st, bufs, G, y, sg,
-                     R, mask, where, leaders, cnt, cnt_next);
-  const int row_blocks = (int)max((int64_t)1, min((int64_t)2048, (total + 15) / 16));
+                     R, mask, where);
+  const int row_blocks = (int)((total + 15) / 16);          // one 16-lane group per entry
   const int dense_blocks = (int)max((int64_t)1, min((int64_t)256, (y.nd + 255) / 256));
   hipLaunchKernelGGL(k_dp_sum_rows, dim3(row_blocks + dense_blocks), dim3(256), 0, st, bufs, G, g, sg, dense_begin, loss_sum, y,
-                     R, mask, where, leaders, cnt, row_blocks, reset_buf);
+                     R, mask, where, row_blocks, reset_buf);
   HIP_TRY(hipGetLastError());
   return 0;
 }

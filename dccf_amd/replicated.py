@@ -53,10 +53,8 @@ class HipBackend(object):
         self.mp, self.rp, self.gp = C.byref(self.m), C.byref(self.r), C.byref(self.g)
         self.a_export = (L.ptr(tr.flat_g, f32), tr.flat_g.numel()) + self.seg + (
             int(tr.dense_begin), L.ptr(tr.loss, f32), L.ptr(tr.buf, f32), int(tr.cap), int(tr.D), 0)
-        self.scratch = L.DpScratch(tr.user_num + tr.item_num, tr.G, tr.cap, tr.flat_g.device)
-        sc = (L.ptr(self.scratch.mask, torch.int32), L.ptr(self.scratch.where, torch.int32),
-              L.ptr(self.scratch.leaders, torch.int64))
-        self.p_icnt = L.ptr(self.scratch.cnt, torch.int32)
+        self.scratch = L.DpScratch(tr.user_num + tr.item_num, tr.G, tr.flat_g.device)
+        sc = (L.ptr(self.scratch.mask, torch.int32), L.ptr(self.scratch.where, torch.int32))
         self.a_import = (L.ptr(tr.bufs, f32), int(tr.G), L.ptr(tr.flat_g, f32), tr.flat_g.numel()) + self.seg + (
             int(tr.dense_begin), L.ptr(tr.loss_sum, f32), int(tr.cap), int(tr.D)) + sc
         self.a_opt = (L.OPT_KIND['adam'], L.ptr(tr.flat_p, f32), L.ptr(tr.flat_g, f32), L.ptr(tr.s1, f32), L.ptr(tr.s2, f32),
@@ -89,10 +87,7 @@ class HipBackend(object):
         self.L.check(self.f_export(*self.a_export, self.L.stream()))
 
     def import_(self, tr, global_flags=False):
-        c, par = self.p_icnt, self.scratch.parity
-        self.L.check(self.f_import(*(self.a_import_g if global_flags else self.a_import), c + 4 * par, c + 4 * (1 - par),
-                                   self.p_buf, self.L.stream()))
-        self.scratch.parity ^= 1
+        self.L.check(self.f_import(*(self.a_import_g if global_flags else self.a_import), self.p_buf, self.L.stream()))
 
     def mark_global(self, tr, X_all, step0):
         if self.ready is not tr:

@@ -223,8 +223,7 @@ int rank_eval_topk(const float* pred, const float* label, const int64_t* indptr,
  * ranks' rows IN RANK ORDER (bit-identical on every replica, no float atomics), sets the bytes again and sums the dense
  * tails and losses in rank order — g is then exactly what one GPU would hold after a backward over the G batches, and
  * dccf_dense_opt_step_rows finishes the step.  Scratch (R = total rows of the segments): mask uint32 [R] zero-initialised
- * (the import leaves it zero), where int32 [G*R], leaders int64 [G*cap], cnt / cnt_next two alternating device counters
- * (*cnt zero on entry; *cnt_next is zeroed).
+ * (the import leaves it zero), where int32 [G*R].
  * The export appends behind the counter in buf[0]: reset != 0 zeroes it first (one more launch); a training loop passes its
  * local buffer as reset_buf to the import instead, which zeroes the counter for the next step's export. */
 int64_t dp_buffer_words(int64_t cap, int32_t D, int64_t nd);
@@ -240,8 +239,7 @@ int dp_export_touched(float* g, int64_t n, int32_t nseg, const int64_t* seg_begi
                       int64_t cap, int32_t D, int32_t reset, void* stream);
 int dp_import_touched(const float* bufs, int32_t G, float* g, int64_t n, int32_t nseg, const int64_t* seg_begin,
                       const int64_t* seg_rows, const int32_t* seg_width, uint8_t* const* seg_flags, int64_t dense_begin,
-                      float* loss_sum, int64_t cap, int32_t D, uint32_t* mask, int32_t* where, int64_t* leaders, int32_t* cnt,
-                      int32_t* cnt_next, float* reset_buf, void* stream);
+                      float* loss_sum, int64_t cap, int32_t D, uint32_t* mask, int32_t* where, float* reset_buf, void* stream);
 
 /* ---- row movers of the row-sharded multi-GPU path (dccf_amd/sharded.py; no reference counterpart — the reference is
  * single-GPU, src/main.py:106,153-155).  `tables` / `widths` are HOST arrays of up to 4 device pointers / row widths. */

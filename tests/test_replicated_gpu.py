@@ -67,7 +67,7 @@ def test_export_import_rank_ordered_sum(D):
     g, segs, dense_begin, tU, tV = make_state(U, I, D, nd, [], [], 99)
     g.zero_()
     loss_sum = torch.zeros(1, device='cuda')
-    scratch = L.DpScratch(U + I, G, cap, 'cuda')
+    scratch = L.DpScratch(U + I, G, 'cuda')
     for rep in range(2):                                 # the scratch cleans itself: a second import must work as well
         g.zero_(); tU.zero_(); tV.zero_()
         L.dp_import_touched(bufs, G, g, segs, dense_begin, loss_sum, cap, D, scratch)
