@@ -220,15 +220,23 @@ extern "C" int mf_train_fwdbwd(dccf_ctx* ctx, const mf_model_t* M, const int64_t
 // ------------------------------------------------------------------------------------------------ full U x I matrix
 // out[u][i] = (P[u].Q[i] + bu[u] + bi[i] + b0) / max(prop[i], M): 128 x 128 tile per block, 4 waves x (64 x 64),
 // fp32 MFMA 32x32x2 over K = D, operands staged in LDS with a one-float row pad (conflict-free ds_read_b32).
-// Output-write bound (U*I*4 bytes) for D <= 64.
+// Output-write bound (U*I*4 bytes) for D <= 64, so the stores decide: the finished tile goes back through LDS and
+// leaves as whole 512-B row segments (a wave instruction = 256 contiguous bytes), and consecutive tiles of a row band
+// are given to the SAME XCD (workgroups are dealt to the 8 XCDs round-robin, each with its own L2), so the two cache
+// lines a tile shares with its left/right neighbours (item_num is not a multiple of 32) are completed in one L2.
 #define FT 128
-__global__ __launch_bounds__(256) void k_mf_full(mf_model_t M, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_mf_full(mf_model_t M, float* __restrict__ out, int64_t nblk) {
   extern __shared__ float sm[];
   const int D = M.D, LD = D + 1;
   float* Ps = sm;              // [FT][LD]
   float* Qs = Ps + FT * LD;    // [FT][LD]
+  float* Cs = sm;              // [FT][FT + 1] after the k-loop (the launch sizes LDS for the larger of the two uses)
   const int64_t gx = (M.item_num + FT - 1) / FT;
-  const int64_t u0 = ((int64_t)blockIdx.x / gx) * FT, i0 = ((int64_t)blockIdx.x % gx) * FT;
+  // XCD-aware order: physical block b runs on XCD b % 8; XCD x walks the contiguous tile range [x * per, (x + 1) * per)
+  const int64_t per = (nblk + 7) / 8;
+  const int64_t tile = ((int64_t)blockIdx.x % 8) * per + (int64_t)blockIdx.x / 8;
+  if (tile >= nblk) return;
+  const int64_t u0 = (tile / gx) * FT, i0 = (tile % gx) * FT;
   for (int idx = threadIdx.x; idx < FT * D; idx += 256) {
     const int r = idx / D, k = idx % D;
     Ps[r * LD + k] = (u0 + r < M.user_num) ? M.P[(u0 + r) * D + k] : 0.f;
@@ -256,25 +264,139 @@ __global__ __launch_bounds__(256) void k_mf_full(mf_model_t M, float* __restrict
 #pragma unroll
       for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
   }
+  __syncthreads();               // every wave is done reading Ps / Qs: the space becomes the output tile
   const float b0 = M.kind >= 1 ? M.b0[0] : 0.f;
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
-    const int64_t i = i0 + wi + b * 32 + c31;
-    if (i >= M.item_num) continue;
+    const int ci = wi + b * 32 + c31;
+    const int64_t i = min(i0 + ci, M.item_num - 1);
     const float bi = M.kind >= 1 ? M.bi[i] : 0.f;
     const float pr = M.kind == 2 ? fmaxf(M.prop[i], M.M) : 1.f;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int64_t u = u0 + wu + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (u >= M.user_num) continue;
+        const int ru = wu + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         float v = acc[a][b][r];
-        if (M.kind >= 1) v = v + M.bu[u] + bi + b0;
+        if (M.kind >= 1) v = v + M.bu[min(u0 + ru, M.user_num - 1)] + bi + b0;
         if (M.kind == 2) v = v / pr;
-        out[u * M.item_num + i] = v;
+        Cs[ru * (FT + 1) + ci] = v;
       }
   }
+  __syncthreads();
+  // row segments out: wave w writes rows w, w + 4, ...; two 256-B instructions per row
+  const int64_t ncol = min((int64_t)FT, M.item_num - i0);
+  for (int ru = wave; ru < FT; ru += 4) {
+    const int64_t u = u0 + ru;
+    if (u >= M.user_num) break;
+    float* orow = out + u * M.item_num + i0;
+    if (lane < ncol) orow[lane] = Cs[ru * (FT + 1) + lane];
+    if (lane + 64 < ncol) orow[lane + 64] = Cs[ru * (FT + 1) + lane + 64];
+  }
+}
+
+// Persistent form for D in {16, 32, 64, 128}: a workgroup (8 waves) keeps ONE band of 128 users in LDS and walks a range
+// of 64-item tiles of it.  Per tile: the next Q tile (and its bias / propensity columns) is prefetched into registers
+// while the current one is multiplied (fp32 MFMA 32x32x2, wave w = user rows 32(w>>1).. x items 32(w&1)..), the finished
+// tile goes through LDS and leaves as 256-B row segments — one wave store instruction per row.  The stores are issued
+// AFTER the prefetched registers were consumed: on gfx9 a store counts in vmcnt like a load, so waiting for the prefetch
+// behind them would wait for the stores to be acknowledged.  Neighbouring tiles of a band are written by the same CU a
+// few us apart, so the cache lines they share (item_num is not a multiple of 32) are completed in one L2.
+#define FI 64
+template <int D, int FU>
+__global__ __launch_bounds__(FU * 4) void k_mf_full_band(mf_model_t M, float* __restrict__ out, int splits) {
+  extern __shared__ float sm[];
+  constexpr int LD = D + 1;
+  constexpr int NT = FU * 4;                // threads: one wave per 32 x 32 MFMA tile of the FU x 64 output tile
+  constexpr int QR = (FI * D + NT - 1) / NT;  // floats of a Q tile per thread
+  float* Ps = sm;                           // [FU][LD]
+  float* Qs = Ps + FU * LD;                 // [FI][LD]
+  float* Cs = Qs + FI * LD;                 // [FU][FI]   the output tile
+  float* Bu = Cs + FU * FI;                 // [FU]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, c31 = lane & 31;
+  const int wu = (wave >> 1) * 32, wi = (wave & 1) * 32;
+  const int64_t gi = (M.item_num + FI - 1) / FI;
+  const int64_t band = blockIdx.x / splits, sp = blockIdx.x % splits;
+  const int64_t t0 = gi * sp / splits, t1 = gi * (sp + 1) / splits;
+  const int64_t u0 = band * FU;
+  if (t0 >= t1) return;
+  for (int idx = threadIdx.x; idx < FU * D; idx += NT) {
+    const int r = idx / D, k = idx % D;
+    Ps[r * LD + k] = M.P[min(u0 + r, M.user_num - 1) * D + k];
+  }
+  if (threadIdx.x < FU) Bu[threadIdx.x] = M.kind >= 1 ? M.bu[min(u0 + threadIdx.x, M.user_num - 1)] : 0.f;
+  const float b0 = M.kind >= 1 ? M.b0[0] : 0.f;
+  float qreg[QR], bin, prn;
+  auto prefetch = [&](int64_t t) {
+    const int64_t i0 = t * FI;
+#pragma unroll
+    for (int j = 0; j < QR; ++j) {
+      const int idx = min((int)threadIdx.x + j * NT, FI * D - 1);
+      qreg[j] = M.Q[min(i0 + idx / D, M.item_num - 1) * D + idx % D];
+    }
+    const int64_t i = min(i0 + wi + c31, M.item_num - 1);
+    bin = M.kind >= 1 ? M.bi[i] : 0.f;
+    prn = M.kind == 2 ? fmaxf(M.prop[i], M.M) : 1.f;
+  };
+  auto commit = [&]() {                      // prefetched registers -> the Q tile in LDS
+#pragma unroll
+    for (int j = 0; j < QR; ++j) {
+      const int idx = threadIdx.x + j * NT;
+      if (idx < FI * D) Qs[(idx / D) * LD + idx % D] = qreg[j];
+    }
+  };
+  prefetch(t0);
+  commit();
+  float bic = bin, prc = prn;
+  __syncthreads();
+  for (int64_t t = t0; t < t1; ++t) {
+    const int64_t i0 = t * FI;
+    if (t + 1 < t1) prefetch(t + 1);          // in flight during the k-loop
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < D; k += 2) {
+      const float av = Ps[(wu + c31) * LD + k + h];
+      const float bv = Qs[(wi + c31) * LD + k + h];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ru = wu + (r & 3) + 8 * (r >> 2) + 4 * h;
+      float v = acc[r];
+      if (M.kind >= 1) v = v + Bu[ru] + bic + b0;
+      if (M.kind == 2) v = v / prc;
+      Cs[ru * FI + wi + c31] = v;
+    }
+    __syncthreads();                          // the Q tile has been read by every wave, the output tile is complete
+    if (t + 1 < t1) {
+      commit();                               // waits for the prefetch (no store is outstanding behind it)
+      bic = bin;
+      prc = prn;
+    }
+    const int64_t ncol = min((int64_t)FI, M.item_num - i0);
+    for (int ru = wave; ru < FU; ru += NT / 64) {
+      const int64_t u = u0 + ru;
+      if (u >= M.user_num) break;
+      if (lane < ncol) out[u * M.item_num + i0 + lane] = Cs[ru * FI + lane];
+    }
+    __syncthreads();                          // next Q tile visible; the output tile may be overwritten
+  }
+}
+
+template <int D, int FU>
+static int launch_full_band(const mf_model_t* M, float* out, hipStream_t st) {
+  constexpr int LD = D + 1;
+  const size_t smem = (size_t)(FU * LD + FI * LD + FU * FI + FU) * 4;
+  const int64_t bands = (M->user_num + FU - 1) / FU, gi = (M->item_num + FI - 1) / FI;
+  const int splits = (int)max((int64_t)1, min(gi, (4096 + bands - 1) / bands));
+  ARG_CHECK(bands * splits < 2147483647LL, "matrix too large for one launch");
+  HIP_TRY(hipFuncSetAttribute((const void*)k_mf_full_band<D, FU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL((k_mf_full_band<D, FU>), dim3((unsigned)(bands * splits)), dim3(FU * 4), smem, st, *M, out, splits);
+  HIP_TRY(hipGetLastError());
+  return 0;
 }
 
 extern "C" int mf_predict_full(const mf_model_t* M, float* out, void* stream) {
@@ -282,12 +404,21 @@ extern "C" int mf_predict_full(const mf_model_t* M, float* out, void* stream) {
   ARG_CHECK(M->P && M->Q && M->D >= 2 && M->D % 2 == 0 && M->D <= 128 && M->kind >= 0 && M->kind <= 2, "bad model");
   ARG_CHECK(M->kind == 0 || (M->bu && M->bi && M->b0), "bias pointers missing");
   ARG_CHECK(M->kind != 2 || M->prop, "propensity missing");
+  ARG_CHECK(M->user_num > 0 && M->item_num > 0, "empty matrix");
+  switch (M->D) {
+    // band height per D as measured (CDs-shaped 75k x 64k): D=64 wants 3 workgroups per CU (50 KB of LDS each)
+    case 16: return launch_full_band<16, 128>(M, out, (hipStream_t)stream);
+    case 32: return launch_full_band<32, 128>(M, out, (hipStream_t)stream);
+    case 64: return launch_full_band<64, 64>(M, out, (hipStream_t)stream);
+    case 128: return launch_full_band<128, 128>(M, out, (hipStream_t)stream);
+    default: break;                            // other even D: the one-tile-per-workgroup form below
+  }
   const int64_t nblk = ((M->item_num + FT - 1) / FT) * ((M->user_num + FT - 1) / FT);
   ARG_CHECK(nblk < 2147483647LL, "matrix too large for one launch");
-  const dim3 grid((unsigned)nblk);
-  const size_t smem = (size_t)2 * FT * (M->D + 1) * 4;
+  const dim3 grid((unsigned)((nblk + 7) / 8 * 8));
+  const size_t smem = max((size_t)2 * FT * (M->D + 1) * 4, (size_t)FT * (FT + 1) * 4);
   HIP_TRY(hipFuncSetAttribute((const void*)k_mf_full, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  hipLaunchKernelGGL(k_mf_full, grid, dim3(256), smem, (hipStream_t)stream, *M, out);
+  hipLaunchKernelGGL(k_mf_full, grid, dim3(256), smem, (hipStream_t)stream, *M, out, nblk);
   HIP_TRY(hipGetLastError());
   return 0;
 }
