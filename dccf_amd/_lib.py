@@ -54,7 +54,7 @@ class MFModelT(C.Structure):
 
 
 class MFGradsT(C.Structure):
-    _fields_ = [('gP', _f), ('gQ', _f), ('gbu', _f), ('gbi', _f), ('gb0', _f)]
+    _fields_ = [('gP', _f), ('gQ', _f), ('gbu', _f), ('gbi', _f), ('gb0', _f), ('touchedP', _f), ('touchedQ', _f)]
 
 
 _lib = None
@@ -316,13 +316,14 @@ def mf_predict(m, X, out=None):
     return out
 
 
-def mf_train_fwdbwd(ctx, m, X, Y, rank, gP, gQ, gbu=None, gbi=None, gb0=None, pred=None, loss=None):
+def mf_train_fwdbwd(ctx, m, X, Y, rank, gP, gQ, gbu=None, gbi=None, gb0=None, pred=None, loss=None, touchedP=None,
+                    touchedQ=None):
     N = X.shape[0]
     if pred is None:
         pred = torch.empty(N, dtype=torch.float32, device=X.device)
     if loss is None:
         loss = torch.empty(1, dtype=torch.float32, device=X.device)
-    g = MFGradsT(ptr(gP), ptr(gQ), ptr(gbu), ptr(gbi), ptr(gb0))
+    g = MFGradsT(ptr(gP), ptr(gQ), ptr(gbu), ptr(gbi), ptr(gb0), ptr(touchedP, torch.uint8), ptr(touchedQ, torch.uint8))
     check(load().mf_train_fwdbwd(ctx.h if ctx is not None else None, C.byref(m), ptr(X, torch.int64), ptr(Y), N,
                                  int(rank), C.byref(g), ptr(pred), ptr(loss), stream()))
     return pred, loss

@@ -160,6 +160,7 @@ __global__ __launch_bounds__(256) void k_mf_train(mf_model_t M, mf_grads_t G, co
           for (int j = s; j >= 0; j = nxtU[j]) v = fmaf(gs[j], Qr[j * D + d], v);
           atomicAdd(&G.gP[uid[s] * D + d], v);
         }
+        if (G.touchedP && lane == 0) G.touchedP[uid[s]] = 1;
         if (M.kind >= 1 && lane == 0) {
           float v = 0.f;
           for (int j = s; j >= 0; j = nxtU[j]) v += gs[j];
@@ -172,6 +173,7 @@ __global__ __launch_bounds__(256) void k_mf_train(mf_model_t M, mf_grads_t G, co
           for (int j = s; j >= 0; j = nxtI[j]) v = fmaf(gs[j], Pr[j * D + d], v);
           atomicAdd(&G.gQ[iid[s] * D + d], v);
         }
+        if (G.touchedQ && lane == 0) G.touchedQ[iid[s]] = 1;
         if (M.kind >= 1 && lane == 0) {
           float v = 0.f;
           for (int j = s; j >= 0; j = nxtI[j]) v += gs[j];

@@ -229,6 +229,14 @@ class RecModel(BaseModel):
         BaseModel._allocate(self)
         p = self.params
         self._modules = [_ParamModule('embedding', p[k]) for k in p if k.endswith('embeddings.weight') or k.endswith('_bias.weight')]
+        # one "touched" byte per embedding row (set by the backward) for the row-aware dense optimizer step; the bias
+        # vectors and the global bias stay dense
+        self.touchedP = self.touchedQ = None
+        if self.ui_vector_size in (16, 32, 64, 128):
+            self.touchedP = torch.zeros((self.user_num + 3) // 4 * 4, dtype=torch.uint8, device=self.device)[:self.user_num]
+            self.touchedQ = torch.zeros((self.item_num + 3) // 4 * 4, dtype=torch.uint8, device=self.device)[:self.item_num]
+            self.row_segments = [(self.offsets['uid_embeddings.weight'], self.user_num, self.ui_vector_size, self.touchedP),
+                                 (self.offsets['iid_embeddings.weight'], self.item_num, self.ui_vector_size, self.touchedQ)]
 
     propensity = None
     M = 0.1
@@ -255,12 +263,13 @@ class RecModel(BaseModel):
         X = feed_dict['X'].contiguous()
         if self.kind == 'RecModel':
             pred, loss = _lib.mf_train_fwdbwd(self.ctx, self._struct(), X, feed_dict['Y'], feed_dict['rank'],
-                                              g['uid_embeddings.weight'], g['iid_embeddings.weight'])
+                                              g['uid_embeddings.weight'], g['iid_embeddings.weight'],
+                                              touchedP=self.touchedP, touchedQ=self.touchedQ)
         else:
             pred, loss = _lib.mf_train_fwdbwd(self.ctx, self._struct(), X, feed_dict['Y'], feed_dict['rank'],
                                               g['uid_embeddings.weight'], g['iid_embeddings.weight'],
                                               g['user_bias.weight'].view(-1), g['item_bias.weight'].view(-1),
-                                              g['global_bias'].view(-1))
+                                              g['global_bias'].view(-1), touchedP=self.touchedP, touchedQ=self.touchedQ)
         return {'prediction': pred, 'check': [], 'loss': loss[0]}
 
     def full_matrix(self):

@@ -190,7 +190,9 @@ typedef struct {
   float reserved;
 } mf_model_t;
 
-typedef struct { float* gP; float* gQ; float* gbu; float* gbi; float* gb0; } mf_grads_t;
+typedef struct { float* gP; float* gQ; float* gbu; float* gbi; float* gb0;
+                 uint8_t* touchedP; uint8_t* touchedQ;   /* optional, as in dccf_grads_t: one byte per gP / gQ row */
+} mf_grads_t;
 
 int mf_predict(const mf_model_t* model, const int64_t* X, int64_t N, float* prediction, void* stream);
 int mf_train_fwdbwd(dccf_ctx* ctx, const mf_model_t* model, const int64_t* X, const float* Y, int64_t N, int32_t rank,

@@ -586,3 +586,36 @@ def test_overlapped_train_step_equals_split_step(L, opt_name, B, l2):
                     d = (a - b).abs()
                     assert int((d > 6 * STEP_FRAC * 0.01).sum()) <= 4 * D + 8 and float(d.max()) <= 6 * 0.01
         close(other[4], states[0][4].cpu().numpy(), 1e-6, 1e-7, 'first prediction')
+
+
+@pytest.mark.parametrize('D', [64, 24])
+def test_mf_row_aware_optimizer_equals_dense(L, D):
+    """BiasedMF training steps: the row-aware dense optimizer (touched bytes set by k_mf_train; D = 24 has no row path
+    and must fall back to the dense one) against the plain dense step."""
+    from dccf_amd.models import BiasedMF, FusedOptimizer
+    U, I, B = 1203, 877, 96
+    runs = []
+    for rows in (True, False):
+        m = BiasedMF(label_min=0, label_max=1, feature_num=0, user_num=U, item_num=I, u_vector_size=D, i_vector_size=D,
+                     random_seed=4, model_path='/tmp/mf.pt')
+        torch.manual_seed(1)
+        m.apply(m.init_paras)
+        assert (getattr(m, 'row_segments', None) is not None) == (D == 64)
+        if not rows:
+            m.row_segments, m.touchedP, m.touchedQ = None, None, None
+        m.optimizer = FusedOptimizer(m, 'adam', 0.01, 1e-4)
+        m.train()
+        gen = torch.Generator(device='cuda').manual_seed(2)
+        y = torch.cat([torch.ones(B, device='cuda'), torch.zeros(B, device='cuda')])
+        for k in range(5):
+            u = torch.randint(0, U, (B,), generator=gen, device='cuda')
+            X = torch.stack([torch.cat([u, u]), torch.randint(0, I, (2 * B,), generator=gen, device='cuda')], 1)
+            m({'X': X, 'Y': y, 'rank': 1, 'train': True, 'dropout': 0.0})
+            m.optimizer.step()
+        torch.cuda.synchronize()
+        assert float(m.flat_g.abs().max()) == 0.0
+        if m.touchedP is not None:
+            assert int(m.touchedP.sum()) == 0 and int(m.touchedQ.sum()) == 0
+        runs.append(m.flat_p.clone())
+    d = (runs[0] - runs[1]).abs()
+    assert float(d.max()) <= 5 * 0.01 and int((d > 5 * STEP_FRAC * 0.01).sum()) <= 4 * D + 8
