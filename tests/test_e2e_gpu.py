@@ -74,9 +74,23 @@ def test_exposure_pipeline_ipsbiasedmf_then_dccf(tmp_path):
     synth.write_dataset(os.path.join(tmp, 'dataset'), 'toy', 300, 200, 5000, feat_dim=32, seed=3, write_expo=False)
     common = ['--rank', '1', '--dataset', 'toy', '--path', '../dataset/', '--metric', 'ndcg@5,recall@5', '--test_neg_n', '50',
               '--u_vector_size', '16', '--i_vector_size', '16', '--check_epoch', '0', '--optimizer', 'Adam', '--lr', '0.01']
-    r = run_cli(tmp, ['--model_name', 'IPSBiasedMF', '--epoch', '3'] + common)
-    assert r.valid_results[-1][0] > 0
-    # rebuild the trained model from its checkpoint and write the exposure matrix
+    # the exposure tool: generates the propensity vector (removed here on purpose), trains IPSBiasedMF through the CLI
+    # mirror and writes <ds>.ips_expo_prob.npy
+    prop_file = os.path.join(tmp, 'dataset', 'toy', 'toy.propensity.npy')
+    prop_synth = np.load(prop_file)
+    os.remove(prop_file)
+    from dccf_amd import exposure
+    cwd = os.getcwd()
+    os.makedirs(os.path.join(tmp, 'src'), exist_ok=True)
+    os.chdir(os.path.join(tmp, 'src'))
+    try:
+        expo_file = os.path.abspath(exposure.main(['--epoch', '3'] + common))
+    finally:
+        os.chdir(cwd)
+    prop = np.load(prop_file)
+    assert prop.shape == prop_synth.shape and prop.max() == 1.0 and prop.min() >= 0.0
+    expo_written = np.load(expo_file)
+    # rebuild the trained model from its checkpoint and compare with the written matrix
     from dccf_amd.models import IPSBiasedMF
     pts = [os.path.join(rt, f) for rt, _, fs in os.walk(os.path.join(tmp, 'model', 'IPSBiasedMF')) for f in fs]
     m = IPSBiasedMF(path=os.path.join(tmp, 'dataset', 'toy'), dataset='toy', M=0.1, label_min=0, label_max=1, feature_num=0,
@@ -86,7 +100,8 @@ def test_exposure_pipeline_ipsbiasedmf_then_dccf(tmp_path):
     X = torch.tensor([[5, 7], [299, 199], [0, 0]], dtype=torch.int64, device=full.device)
     pair = m.predict({'X': X})['prediction']
     assert torch.allclose(full[X[:, 0], X[:, 1]], pair, rtol=1e-5, atol=1e-6)
-    np.save(os.path.join(tmp, 'dataset', 'toy', 'toy.ips_expo_prob.npy'), full.cpu().numpy())
+    assert expo_written.shape == (300, 200)
+    np.testing.assert_allclose(expo_written, full.cpu().numpy(), rtol=1e-5, atol=1e-6)
     r2 = run_cli(tmp, ['--model_name', 'DCCF', '--epoch', '2', '--fused_sampling', '0', '--model_path', '../model/DCCF/x.pt'] + common)
     assert len(r2.valid_results) == 2 and np.isfinite(r2.valid_results[-1][0])
     r3 = run_cli(tmp, ['--model_name', 'DCCF', '--epoch', '1', '--load', '1', '--model_path', '../model/DCCF/x.pt'] + common)
