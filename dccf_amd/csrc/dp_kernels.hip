@@ -181,17 +181,49 @@ extern "C" int dp_debug_trace_read(long long* out) {
 #else
 #define DPT(k)
 #endif
+// APPLY < 0: the sums go to g (+ "touched" bytes set) and a dense optimizer pass follows.  APPLY = optimizer kind: the
+// optimizer is applied right here to the summed rows and the dense tail (phase 2 of the two-phase step: every row a rank
+// touched has an entry, so this covers exactly the rows the untouched-row phase skipped) — g stays zero, the bytes of
+// `sg.flags` (the global marks) are cleared.
+template <int APPLY>
+__device__ __forceinline__ void dp_apply4(const OptJob& j, int64_t i4, float4 gsum) {
+  constexpr int K = APPLY < 0 ? 0 : APPLY;
+  float4 pv = reinterpret_cast<float4*>(j.p)[i4];
+  float4 av = make_float4(0, 0, 0, 0), bv = make_float4(0, 0, 0, 0);
+  if (K != DCCF_OPT_GD) av = reinterpret_cast<float4*>(j.s1)[i4];
+  if (K == DCCF_OPT_ADAM) bv = reinterpret_cast<float4*>(j.s2)[i4];
+  opt_elem<K>(pv.x, gsum.x, av.x, bv.x, j.a);
+  opt_elem<K>(pv.y, gsum.y, av.y, bv.y, j.a);
+  opt_elem<K>(pv.z, gsum.z, av.z, bv.z, j.a);
+  opt_elem<K>(pv.w, gsum.w, av.w, bv.w, j.a);
+  reinterpret_cast<float4*>(j.p)[i4] = pv;
+  if (K != DCCF_OPT_GD) reinterpret_cast<float4*>(j.s1)[i4] = av;
+  if (K == DCCF_OPT_ADAM) reinterpret_cast<float4*>(j.s2)[i4] = bv;
+}
+
+template <int APPLY>
 __global__ __launch_bounds__(256) void k_dp_sum_rows(const float* __restrict__ bufs, int G, float* __restrict__ g, DpRows sg,
                                                      int64_t dense_begin, float* __restrict__ loss_sum, DpLay y, int64_t R,
                                                      uint32_t* __restrict__ mask, const int* __restrict__ where,
-                                                     int row_blocks, float* reset_buf) {
+                                                     int row_blocks, float* reset_buf, OptJob job) {
   if ((int)blockIdx.x >= row_blocks) {           // dense tail: sum in rank order
     const int64_t tid = (int64_t)(blockIdx.x - row_blocks) * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)(gridDim.x - row_blocks) * blockDim.x;
     for (int64_t i = tid; i < y.nd; i += stride) {
       float s = bufs[y.dense_off + i];
       for (int r = 1; r < G; ++r) s += bufs[(int64_t)r * y.words + y.dense_off + i];
-      g[dense_begin + i] = s;
+      if (APPLY < 0) {
+        g[dense_begin + i] = s;
+      } else {
+        constexpr int K = APPLY < 0 ? 0 : APPLY;
+        float pv = job.p[dense_begin + i], av = 0.f, bv = 0.f;
+        if (K != DCCF_OPT_GD) av = job.s1[dense_begin + i];
+        if (K == DCCF_OPT_ADAM) bv = job.s2[dense_begin + i];
+        opt_elem<K>(pv, s, av, bv, job.a);
+        job.p[dense_begin + i] = pv;
+        if (K != DCCF_OPT_GD) job.s1[dense_begin + i] = av;
+        if (K == DCCF_OPT_ADAM) job.s2[dense_begin + i] = bv;
+      }
     }
     if (tid == 0 && reset_buf) reinterpret_cast<int*>(reset_buf)[0] = 0;      // the local export buffer's counter
     if (tid == 0 && loss_sum) {
@@ -247,11 +279,17 @@ __global__ __launch_bounds__(256) void k_dp_sum_rows(const float* __restrict__ b
       }
     }
     DPT(4);
-    float4* dst = reinterpret_cast<float4*>(g + sg.begin[q] + row * y.D);
-    dst[sub] = a0;
-    if (two) dst[sub + 16] = a1;
+    const int64_t i4 = (sg.begin[q] + row * y.D) >> 2;
+    if (APPLY < 0) {
+      float4* dst = reinterpret_cast<float4*>(g) + i4;
+      dst[sub] = a0;
+      if (two) dst[sub + 16] = a1;
+    } else {
+      dp_apply4<APPLY>(job, i4 + sub, a0);
+      if (two) dp_apply4<APPLY>(job, i4 + sub + 16, a1);
+    }
     if (sub == 0) {
-      sg.flags[q][row] = 1;
+      sg.flags[q][row] = APPLY < 0 ? 1 : 0;
       mask[gid] = 0u;
     }
     DPT(5);
@@ -259,11 +297,11 @@ __global__ __launch_bounds__(256) void k_dp_sum_rows(const float* __restrict__ b
   DPT(6);
 }
 
-extern "C" int dp_import_touched(const float* bufs, int32_t G, float* g, int64_t n, int32_t nseg, const int64_t* seg_begin,
-                                 const int64_t* seg_rows, const int32_t* seg_width, uint8_t* const* seg_flags,
-                                 int64_t dense_begin, float* loss_sum, int64_t cap, int32_t D, uint32_t* mask, int32_t* where,
-                                 float* reset_buf, void* stream) {
-  ARG_CHECK(bufs && g && G >= 1 && G <= DP_GMAX, "1..16 ranks");
+static int dp_import_impl(const float* bufs, int32_t G, float* g, int64_t n, int32_t nseg, const int64_t* seg_begin,
+                          const int64_t* seg_rows, const int32_t* seg_width, uint8_t* const* seg_flags, int64_t dense_begin,
+                          float* loss_sum, int64_t cap, int32_t D, uint32_t* mask, int32_t* where, float* reset_buf,
+                          const OptJob* job, hipStream_t st) {
+  ARG_CHECK(bufs && (g || job) && G >= 1 && G <= DP_GMAX, "1..16 ranks");
   ARG_CHECK(nseg >= 1 && nseg <= 4 && seg_begin && seg_rows && seg_width && seg_flags, "bad segments");
   ARG_CHECK(D >= 4 && D <= 128 && D % 4 == 0 && cap >= 1 && dense_begin >= 0 && dense_begin <= n, "bad D / cap / dense_begin");
   ARG_CHECK(mask && where, "NULL scratch");
@@ -274,22 +312,54 @@ extern "C" int dp_import_touched(const float* bufs, int32_t G, float* g, int64_t
   int64_t R = 0;
   for (int q = 0; q < nseg; ++q) {
     ARG_CHECK(seg_width[q] == D && seg_flags[q], "every row segment must have width D and flags");
+    ARG_CHECK(seg_begin[q] % 4 == 0, "segments must start on a 16-byte boundary");
     sg.begin[q] = seg_begin[q];
     sg.rowoff[q] = R;
     sg.flags[q] = seg_flags[q];
     R += seg_rows[q];
   }
   const DpLay y = dp_layout(cap, D, n - dense_begin);
-  hipStream_t st = (hipStream_t)stream;
   const int64_t total = (int64_t)G * cap;
   hipLaunchKernelGGL(k_dp_scatter_ids, dim3((unsigned)min((int64_t)1024, (total + 255) / 256)), dim3(256), 0, st, bufs, G, y, sg,
                      R, mask, where);
   const int row_blocks = (int)((total + 15) / 16);          // one 16-lane group per entry
   const int dense_blocks = (int)max((int64_t)1, min((int64_t)256, (y.nd + 255) / 256));
-  hipLaunchKernelGGL(k_dp_sum_rows, dim3(row_blocks + dense_blocks), dim3(256), 0, st, bufs, G, g, sg, dense_begin, loss_sum, y,
-                     R, mask, where, row_blocks, reset_buf);
+  const dim3 grid(row_blocks + dense_blocks);
+  OptJob none;
+  memset(&none, 0, sizeof(none));
+#define DP_SUM(APPLY_, JOB_)                                                                                          \
+  hipLaunchKernelGGL(k_dp_sum_rows<APPLY_>, grid, dim3(256), 0, st, bufs, G, g, sg, dense_begin, loss_sum, y, R, mask, where, \
+                     row_blocks, reset_buf, JOB_)
+  if (!job) DP_SUM(-1, none);
+  else if (job->kind == DCCF_OPT_GD) DP_SUM(DCCF_OPT_GD, *job);
+  else if (job->kind == DCCF_OPT_ADAGRAD) DP_SUM(DCCF_OPT_ADAGRAD, *job);
+  else DP_SUM(DCCF_OPT_ADAM, *job);
+#undef DP_SUM
   HIP_TRY(hipGetLastError());
   return 0;
+}
+
+extern "C" int dp_import_touched(const float* bufs, int32_t G, float* g, int64_t n, int32_t nseg, const int64_t* seg_begin,
+                                 const int64_t* seg_rows, const int32_t* seg_width, uint8_t* const* seg_flags,
+                                 int64_t dense_begin, float* loss_sum, int64_t cap, int32_t D, uint32_t* mask, int32_t* where,
+                                 float* reset_buf, void* stream) {
+  ARG_CHECK(g != nullptr, "g is NULL");
+  return dp_import_impl(bufs, G, g, n, nseg, seg_begin, seg_rows, seg_width, seg_flags, dense_begin, loss_sum, cap, D, mask,
+                        where, reset_buf, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int dp_import_apply(const float* bufs, int32_t G, int32_t kind, float* p, float* s1, float* s2, int64_t n, float lr,
+                               float wd, float l2, float clip, int64_t step, int32_t nseg, const int64_t* seg_begin,
+                               const int64_t* seg_rows, const int32_t* seg_width, uint8_t* const* seg_flags,
+                               int64_t dense_begin, float* loss_sum, int64_t cap, int32_t D, uint32_t* mask, int32_t* where,
+                               float* reset_buf, void* stream) {
+  OptJob job;
+  // (g is not used by the applying form: pass p as a stand-in for the validation of the job)
+  if (int e = opt_make_job(kind, p, p, s1, s2, n, lr, wd, l2, clip, step, nullptr, nseg, seg_begin, seg_rows, seg_width,
+                           seg_flags, &job))
+    return e;
+  return dp_import_impl(bufs, G, nullptr, n, nseg, seg_begin, seg_rows, seg_width, seg_flags, dense_begin, loss_sum, cap, D, mask,
+                        where, reset_buf, &job, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------- global marking

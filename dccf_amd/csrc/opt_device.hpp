@@ -60,3 +60,8 @@ struct OptJob {
   OptArgs a;
   RowSegs sg;
 };
+
+// opt_kernels.hip: validation + bias corrections (host side) of one optimizer step
+int opt_make_job(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t n, float lr, float wd, float l2, float clip,
+                 int64_t step, const int64_t* k_dev, int32_t nseg, const int64_t* seg_begin, const int64_t* seg_rows,
+                 const int32_t* seg_width, uint8_t* const* seg_flags, OptJob* out);

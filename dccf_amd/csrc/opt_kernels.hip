@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void k_opt_touched(float* __restrict__ p, floa
     }
 }
 
-static int make_job(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t n, float lr, float wd, float l2,
+int opt_make_job(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t n, float lr, float wd, float l2,
                     float clip, int64_t step, const int64_t* k_dev, int32_t nseg, const int64_t* seg_begin,
                     const int64_t* seg_rows, const int32_t* seg_width, uint8_t* const* seg_flags, OptJob* out) {
   ARG_CHECK(p && g && n >= 0 && step >= 1, "NULL p/g, n < 0 or step < 1");
@@ -377,7 +377,7 @@ static int opt_rows_impl(int32_t kind, float* p, float* g, float* s1, float* s2,
                          float clip, int64_t step, const int64_t* k_dev, int32_t nseg, const int64_t* seg_begin,
                          const int64_t* seg_rows, const int32_t* seg_width, uint8_t* const* seg_flags, void* stream) {
   OptJob j;
-  if (int e = make_job(kind, p, g, s1, s2, n, lr, wd, l2, clip, step, k_dev, nseg, seg_begin, seg_rows, seg_width, seg_flags, &j))
+  if (int e = opt_make_job(kind, p, g, s1, s2, n, lr, wd, l2, clip, step, k_dev, nseg, seg_begin, seg_rows, seg_width, seg_flags, &j))
     return e;
   return launch_job(j, OPT_PHASE_ALL, nullptr, nullptr, 0, (hipStream_t)stream);
 }
@@ -385,7 +385,7 @@ static int opt_rows_impl(int32_t kind, float* p, float* g, float* s1, float* s2,
 static int opt_job(const void* ov, OptJob* out) {
   const dccf_opt_t* o = (const dccf_opt_t*)ov;
   ARG_CHECK(o != nullptr, "opt is NULL");
-  return make_job(o->kind, o->p, o->g, o->s1, o->s2, o->n, o->lr, o->wd, o->l2, o->clip, o->step, nullptr, o->nseg,
+  return opt_make_job(o->kind, o->p, o->g, o->s1, o->s2, o->n, o->lr, o->wd, o->l2, o->clip, o->step, nullptr, o->nseg,
                   o->seg_begin, o->seg_rows, o->seg_width, o->seg_flags, out);
 }
 
@@ -409,7 +409,7 @@ extern "C" int dccf_dense_opt_phase(int32_t kind, float* p, float* g, float* s1,
                                     int32_t phase, const int64_t* list, const int32_t* cnt, int64_t max_rows, void* stream) {
   ARG_CHECK(phase == OPT_PHASE_UNTOUCHED || phase == OPT_PHASE_TOUCHED, "phase must be 1 (untouched rows) or 2 (listed rows + dense)");
   OptJob j;
-  if (int e = make_job(kind, p, g, s1, s2, n, lr, wd, l2, clip, step, nullptr, nseg, seg_begin, seg_rows, seg_width, seg_flags, &j))
+  if (int e = opt_make_job(kind, p, g, s1, s2, n, lr, wd, l2, clip, step, nullptr, nseg, seg_begin, seg_rows, seg_width, seg_flags, &j))
     return e;
   return launch_job(j, phase, list, cnt, max_rows, (hipStream_t)stream);
 }

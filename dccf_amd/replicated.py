@@ -69,7 +69,11 @@ class HipBackend(object):
         self.a_mark = (int(tr.S), int(tr.item_num), int(tr.seed) & 0xFFFFFFFFFFFFFFFF)
         self.p_flags = (L.ptr(tr.gfU, u8), L.ptr(tr.gfV, u8), 0, 1, L.ptr(tr.glist, torch.int64))
         self.p_cnt = L.ptr(tr.gcnt, torch.int32)
-        self.f_mark, self.f_phase = lib.dp_mark_global, lib.dccf_dense_opt_phase
+        self.f_mark, self.f_phase, self.f_apply = lib.dp_mark_global, lib.dccf_dense_opt_phase, lib.dp_import_apply
+        self.a_apply_head = (L.ptr(tr.bufs, f32), int(tr.G), L.OPT_KIND['adam'], L.ptr(tr.flat_p, f32), L.ptr(tr.s1, f32),
+                             L.ptr(tr.s2, f32), tr.flat_p.numel(), float(tr.lr), float(tr.l2), float(tr.l2), 50.0)
+        self.a_apply_tail = self.gseg + (int(tr.dense_begin), L.ptr(tr.loss_sum, f32), int(tr.cap), int(tr.D)) + sc + (
+            L.ptr(tr.buf, f32),)
         self.ready = tr
 
     def local_step(self, tr, X, Y, step, pred):
@@ -100,6 +104,10 @@ class HipBackend(object):
         """Phase 1 on the current stream: enqueued right after the all-gather was handed to RCCL's stream, so the
         collective's kernel is already resident when this pass starts to fill the GPU."""
         self.L.check(self.f_phase(*self.a_opt, t, *self.gseg, 1, None, None, 0, self.L.stream()))
+
+    def import_apply(self, tr, t):
+        """Import and phase 2 in one pass: rank-ordered sums go straight into the optimizer (dp_import_apply)."""
+        self.L.check(self.f_apply(*self.a_apply_head, t, *self.a_apply_tail, self.L.stream()))
 
     def opt_touched(self, tr, t):
         self.L.check(self.f_phase(*self.a_opt, t, *self.gseg, 2, self.p_flags[4], self.p_cnt + 4 * tr.parity, tr.glist.numel(),
@@ -177,8 +185,6 @@ class ReplicatedDCCF(object):
         be = self.be
         ov = self.overlap and X_all is not None
         step0, t = self.t * self.G, self.t + 1
-        if ov:
-            be.mark_global(self, X_all, step0)
         pred, _ = be.local_step(self, X, Y, step0 + self.rank, pred)
         be.export(self)
         work = None
@@ -186,16 +192,17 @@ class ReplicatedDCCF(object):
             work = dist.all_gather_into_tensor(self.bufs, self.buf, group=self.group, async_op=ov)
         else:
             self.bufs.copy_(self.buf)
-        if ov:
-            be.opt_untouched(self, t)          # rows no rank touches: runs while RCCL moves the buffers
-            if work is not None:
-                work.wait()
-        be.import_(self, global_flags=ov)
         self.t = t
         if ov:
-            be.opt_touched(self, t)
+            # while RCCL moves the buffers: mark the rows ANY rank touches, then the optimizer pass over all the others
+            be.mark_global(self, X_all, step0)
+            be.opt_untouched(self, t)
+            if work is not None:
+                work.wait()
+            be.import_apply(self, t)           # rank-ordered sums -> optimizer for the marked rows + W, b
             self.parity ^= 1
         else:
+            be.import_(self)
             be.opt_step(self)
         return pred, self.loss_sum
 

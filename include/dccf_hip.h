@@ -229,6 +229,14 @@ int rank_eval_topk(const float* pred, const float* label, const int64_t* indptr,
  * The export appends behind the counter in buf[0]: reset != 0 zeroes it first (one more launch); a training loop passes its
  * local buffer as reset_buf to the import instead, which zeroes the counter for the next step's export. */
 int64_t dp_buffer_words(int64_t cap, int32_t D, int64_t nd);
+/* dp_import_touched + phase 2 of the two-phase optimizer step in one pass: the rank-ordered sums are not stored to g but fed
+ * straight into the optimizer (kind, lr, ... as in dccf_dense_opt_step) for the summed rows and the dense tail; seg_flags
+ * are the bytes that marked those rows for phase 1 (dccf_dense_opt_phase(1)) and are cleared.  Every row some rank touched
+ * has an entry, so together with phase 1 every parameter is updated exactly once. */
+int dp_import_apply(const float* bufs, int32_t G, int32_t kind, float* p, float* s1, float* s2, int64_t n, float lr, float wd,
+                    float l2, float clip, int64_t step, int32_t nseg, const int64_t* seg_begin, const int64_t* seg_rows,
+                    const int32_t* seg_width, uint8_t* const* seg_flags, int64_t dense_begin, float* loss_sum, int64_t cap,
+                    int32_t D, uint32_t* mask, int32_t* where, float* reset_buf, void* stream);
 /* Marks (bytes + de-duplicated list, as dccf_dense_opt_phase wants them) every row ANY of the G ranks will touch in the step
  * whose rank-0 Philox step word is step0: X_all int64 [G][N][2] is the replicated schedule, rank r's S candidates per row
  * are the STREAM_CAND draws of (seed, step0 + r) — what dccf_train_fwdbwd draws on rank r in fused mode.  segU / segV: the

@@ -83,6 +83,10 @@ class OracleBackend(object):
         for _, _, _, flags in tr.gsegments:
             flags.zero_()
 
+    def import_apply(self, tr, t):
+        self.import_(tr, global_flags=True)
+        self.opt_touched(tr, t)
+
     def import_(self, tr, global_flags=False):
         D, cap, W = tr.D, tr.cap, tr.words
         segments = tr.gsegments if global_flags else tr.segments
