@@ -108,7 +108,7 @@ def load():
         'dccf_debug_workspace': [vp, i64, i32, i32, i32, i32, i32, vp, C.POINTER(C.c_int64), vp],
         'shard_pack_rows': [vp, vp, i64, C.POINTER(vp), C.POINTER(i32), i32, vp, i32, vp],
         'shard_unpack_rows': [vp, i32, i64, vp, C.POINTER(vp), C.POINTER(i32), i32, vp],
-        'shard_scatter_add': [vp, i64, vp, i32, vp, vp],
+        'shard_scatter_add': [vp, i64, vp, i32, vp, vp, vp],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)
@@ -395,9 +395,9 @@ def shard_unpack_rows(payload, n, dst, tables):
                                    widths, k, stream()))
 
 
-def shard_scatter_add(idx, n, rows, g):
+def shard_scatter_add(idx, n, rows, g, flags=None):
     check(load().shard_scatter_add(ptr(idx, torch.int32), int(n), ptr(rows, torch.float32), int(g.shape[1]),
-                                   ptr(g, torch.float32), stream()))
+                                   ptr(g, torch.float32), ptr(flags, torch.uint8), stream()))
 
 
 def rank_eval_topk(pred, label, indptr, rows, ks):

@@ -45,12 +45,13 @@ __global__ __launch_bounds__(256) void k_unpack(const float* __restrict__ in, in
 
 // g[idx[j], :] += rows[j, :]
 __global__ __launch_bounds__(256) void k_scatter_add(const int* __restrict__ idx, int64_t n, const float* __restrict__ rows,
-                                                     int width, float* __restrict__ g) {
+                                                     int width, float* __restrict__ g, uint8_t* __restrict__ flags) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t j = wave; j < n; j += nw) {
     const int64_t r = idx[j];
     for (int c = lane; c < width; c += 64) atomicAdd(&g[r * width + c], rows[j * width + c]);
+    if (flags && lane == 0) flags[r] = 1;          // "touched" byte of the row-aware optimizer step
   }
 }
 
@@ -91,11 +92,12 @@ extern "C" int shard_unpack_rows(const float* in, int32_t ld, int64_t n, const i
   return 0;
 }
 
-extern "C" int shard_scatter_add(const int32_t* idx, int64_t n, const float* rows, int32_t width, float* g, void* stream) {
+extern "C" int shard_scatter_add(const int32_t* idx, int64_t n, const float* rows, int32_t width, float* g, uint8_t* flags,
+                                 void* stream) {
   ARG_CHECK(n >= 0 && width > 0 && (n == 0 || (idx && rows && g)), "bad arguments");
   if (n == 0) return 0;
   const int grid = (int)min((int64_t)2048, (n + 3) / 4);
-  hipLaunchKernelGGL(k_scatter_add, dim3(grid), dim3(256), 0, (hipStream_t)stream, idx, n, rows, width, g);
+  hipLaunchKernelGGL(k_scatter_add, dim3(grid), dim3(256), 0, (hipStream_t)stream, idx, n, rows, width, g, flags);
   HIP_TRY(hipGetLastError());
   return 0;
 }

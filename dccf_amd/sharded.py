@@ -43,16 +43,19 @@ class HipBackend(object):
     def unpack_rows(self, payload, n, dst, tables):
         self.L.shard_unpack_rows(payload, n, dst, tables)
 
-    def scatter_add(self, idx, n, rows, g):
-        self.L.shard_scatter_add(idx, n, rows, g)
+    def scatter_add(self, idx, n, rows, g, flags=None):
+        self.L.shard_scatter_add(idx, n, rows, g, flags)
 
     def local_step(self, Uc, Vc, W, b, featc, ips, Xc, cand_c, Y, S, A, std, dropout, seed, step, gU, gV, gW, gb):
         m = self.L.model_struct(Uc, Vc, W, b, featc, None, S, A, std, ips=ips)
         r = self.L.rand_struct(sample_item=cand_c, seed=seed, step=step)
         return self.L.dccf_train_fwdbwd(self.ctx, m, r, Xc, Y, 1, dropout, gU, gV, gW, gb)
 
-    def opt_step(self, p, g, s1, s2, lr, l2, t):
-        self.L.dense_opt_step('adam', p, g, s1, s2, lr, l2, l2, 50.0, t, zero_grad=True)
+    def opt_step(self, p, g, s1, s2, lr, l2, t, segments=None):
+        if segments:       # rows no peer sent a gradient for: g neither read nor re-zeroed (24 instead of 32 B/param)
+            self.L.dense_opt_step_rows('adam', p, g, s1, s2, lr, l2, l2, 50.0, t, segments)
+        else:
+            self.L.dense_opt_step('adam', p, g, s1, s2, lr, l2, l2, 50.0, t, zero_grad=True)
 
 
 def _first_n(mask, values, nmax):
@@ -122,6 +125,11 @@ class ShardedDCCF(object):
         self.gU, self.gV, self.gW, self.gb = gviews
         self.g_rows = self.flat_g[:pads[0] + pads[1]].view(-1, D)          # [dU ; dV] shards as rows of width D
         self.row_off_v = pads[0] // D
+        # one "touched" byte per row of [dU ; dV] (set by the scatter-add of the received gradient rows) for the row-aware
+        # optimizer step; the two shards are ONE segment (the padding rows between them are never flagged)
+        n_rows = (pads[0] + pads[1]) // D
+        self.touched = torch.zeros((n_rows + 3) // 4 * 4, dtype=torch.uint8, device=device)[:n_rows]
+        self.segments = [(0, n_rows, D, self.touched)] if D in (16, 32, 64, 128) else None
         self.g_dense = self.flat_g[pads[0] + pads[1]:pads[0] + pads[1] + sizes[2] + D]      # [dW | db], contiguous
         self.user_pad = torch.ones((max(self.nU, 1), 1), dtype=f32, device=device)           # the "prop" column of user rows
         self.t = 0
@@ -204,10 +212,10 @@ class ShardedDCCF(object):
                                    p['gc'], p['gc'], self.gW, self.gb)
         # gradient rows back (compact order == receive order: nothing to permute), summed at the owner
         self._a2a(p['gback'][:ne], p['gc'], re.send_splits[k], re.recv_splits[k])
-        be.scatter_add(re.g_row[k], ne, p['gback'], self.g_rows)
+        be.scatter_add(re.g_row[k], ne, p['gback'], self.g_rows, self.touched if self.segments else None)
         dist.all_reduce(self.g_dense, group=self.group)
         self.t += 1
-        be.opt_step(self.flat_p, self.flat_g, self.s1, self.s2, self.lr, self.l2, self.t)
+        be.opt_step(self.flat_p, self.flat_g, self.s1, self.s2, self.lr, self.l2, self.t, self.segments)
         return pred, loss
 
 

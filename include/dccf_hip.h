@@ -261,7 +261,8 @@ int shard_pack_rows(const int32_t* idx, const int32_t* dst, int64_t n, const flo
 int shard_unpack_rows(const float* in, int32_t ld, int64_t n, const int32_t* dst, float* const* tables,
                       const int32_t* widths, int32_t ntables, void* stream);
 /* g[idx[j], :] += rows[j, :]  — received gradient rows into the owner's gradient shard (float atomics) */
-int shard_scatter_add(const int32_t* idx, int64_t n, const float* rows, int32_t width, float* g, void* stream);
+int shard_scatter_add(const int32_t* idx, int64_t n, const float* rows, int32_t width, float* g, uint8_t* flags,
+                      void* stream);   /* flags: optional "touched" byte per row of g (dccf_dense_opt_step_rows) */
 
 /* ---- the fused-mode random streams written out (for parity tests: fused == injected on the same draws) ---------- */
 int dccf_debug_candidates(int64_t N, int32_t S, int64_t item_num, uint64_t seed, uint64_t step, int64_t* out, void* stream);

@@ -40,7 +40,7 @@ class OracleBackend(object):
             t[rows] = payload[:n, o:o + t.shape[1]]
             o += t.shape[1]
 
-    def scatter_add(self, idx, n, rows, g):
+    def scatter_add(self, idx, n, rows, g, flags=None):
         if n:
             g.index_add_(0, idx[:n].long(), rows[:n])
 
@@ -61,7 +61,7 @@ class OracleBackend(object):
         gb += torch.from_numpy(g[KEYS[3]])
         return torch.from_numpy(fw['prediction']), torch.tensor([float(loss)])
 
-    def opt_step(self, p, g, s1, s2, lr, l2, t):
+    def opt_step(self, p, g, s1, s2, lr, l2, t, segments=None):
         if not hasattr(self, 'opt'):
             self.opt = O.DenseOptimizer('adam', lr, l2)
         P, _ = O.train_step({'p': p.numpy().copy()}, self.opt, l2, {'p': g.numpy()})
