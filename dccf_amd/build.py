@@ -31,7 +31,11 @@ def build(force=False, verbose=True):
     objs = []
     for src in SRCS:
         obj = os.path.join(os.path.dirname(LIB), os.path.basename(src).replace('.hip', '.o'))
-        c = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-result',
+        # -ffp-contract=off: a*b+c written as two operations stays two roundings in EVERY kernel (explicit fmaf() calls are
+        # still FMAs).  The `#pragma clang fp contract(off)` in the sources says the same, but hipcc was seen to contract
+        # inside a template instantiated from a header anyway (k_dense_opt_rows: s2*b2 + (1-b2)*g*g became v_pk_fma_f32
+        # and the row-aware optimizer stopped matching the dense one bit for bit).
+        c = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-result', '-ffp-contract=off',
              '-c', src, '-o', obj] + os.environ.get('DCCF_EXTRA_HIPCC_FLAGS', '').split()
         if verbose:
             print(' '.join(c))
