@@ -15,7 +15,8 @@ EXPORTS = ['dccf_ctx_create', 'dccf_ctx_destroy', 'dccf_ctx_reserve', 'dccf_last
            'mf_predict_full', 'dccf_sample_train_negatives', 'dccf_debug_candidates', 'dccf_debug_noise',
            'dccf_debug_keep', 'dccf_debug_workspace', 'dccf_profile', 'dccf_profile_read',
            'shard_pack_rows', 'shard_unpack_rows', 'shard_scatter_add', 'dccf_dense_opt_step_rows', 'dccf_dense_opt_step_dev', 'dccf_advance', 'rank_eval_topk', 'dccf_train_step', 'dp_buffer_words',
-           'dp_export_touched', 'dp_import_touched', 'dp_mark_global', 'dccf_dense_opt_phase', 'dccf_ctx_side_stream', 'dp_import_apply']
+           'dp_export_touched', 'dp_import_touched', 'dp_mark_global', 'dccf_dense_opt_phase', 'dccf_ctx_side_stream', 'dp_import_apply',
+           'dccf_sample_eval_negatives']
 
 OPT_KIND = {'gd': 0, 'adagrad': 1, 'adam': 2}
 MF_KIND = {'RecModel': 0, 'BiasedMF': 1, 'IPSBiasedMF': 2}
@@ -86,6 +87,7 @@ def load():
         'dccf_dense_opt_step_dev': [i32, vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, vp, i32, C.POINTER(i64), C.POINTER(i64),
                                     C.POINTER(i32), C.POINTER(vp), vp],
         'dccf_advance': [vp, vp],
+        'dccf_sample_eval_negatives': [vp, i64, vp, vp, i64, i32, u64, u64, vp, vp],
         'dp_import_apply': [vp, i32, i32, vp, vp, vp, i64, f32, f32, f32, f32, i64, i32, vp, vp, vp, vp, i64, vp, i64, i32, vp,
                             vp, vp, vp],
         'dccf_ctx_side_stream': [vp, C.POINTER(vp)],
@@ -463,3 +465,13 @@ def dense_opt_phase(kind, p, g, s1, s2, lr, wd, l2, clip, step, segments, phase,
                                       p.numel(), float(lr), float(wd), float(l2), float(clip), int(step), n, beg, rows, wid, fl,
                                       int(phase), ptr(list_, torch.int64), (c + 4 * parity) if c else None, int(max_rows),
                                       stream()))
+
+
+def sample_eval_negatives(users, hist_indptr, hist_items, item_num, neg_n, seed, tag):
+    """int64 [n_users, neg_n]: the eval negatives of every distinct user (see dccf_sample_eval_negatives)."""
+    i64 = torch.int64
+    out = torch.empty((users.shape[0], int(neg_n)), dtype=i64, device=users.device)
+    check(load().dccf_sample_eval_negatives(ptr(users, i64), users.shape[0], ptr(hist_indptr, i64), ptr(hist_items, i64),
+                                            int(item_num), int(neg_n), int(seed) & 0xFFFFFFFFFFFFFFFF, int(tag), ptr(out, i64),
+                                            stream()))
+    return out

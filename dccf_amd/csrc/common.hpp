@@ -93,6 +93,7 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 #define STREAM_NOISE 2u
 #define STREAM_DROP 3u
 #define STREAM_NEG 4u
+#define STREAM_EVALNEG 6u
 
 struct u32x4 {
   uint32_t x, y, z, w;

@@ -479,3 +479,100 @@ extern "C" int dccf_sample_train_negatives(const int64_t* rows_indptr, const int
   HIP_TRY(hipGetLastError());
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ eval negatives
+// neg_n negatives per DISTINCT user of an eval split (src/data_processor/DataProcessor.py:408-444, first-occurrence rule
+// :420-426): uniform over the items, outside the user's train + validation/test history (sorted CSR -> binary search) and
+// distinct among themselves (:446-524, train=False).  Draw j of user u is word j%4 of Philox(c0=u, c1=j/4, c2=tag) on
+// STREAM_EVALNEG; draws are consumed IN ORDER: draw j is accepted iff its item is admissible and no earlier accepted draw
+// has it; the first neg_n accepted draws, in draw order, are the result (oracle/philox.py::eval_negatives restates it).
+// One wave per user, 64 draws per round; a 4096-slot LDS hash table per wave holds the accepted items, `owner` the
+// lowest draw index that proposed each item, so duplicates inside a round resolve to the earliest draw.
+#define EN_SLOTS 4096
+__global__ __launch_bounds__(256) void k_sample_eval_neg(const int64_t* __restrict__ users, int64_t n_users,
+                                                         const int64_t* __restrict__ hist_indptr,
+                                                         const int64_t* __restrict__ hist_items, int64_t item_num, int neg_n,
+                                                         rng_key key, int64_t* __restrict__ out) {
+  extern __shared__ int en_lds[];                 // [4 waves][keys EN_SLOTS | owner EN_SLOTS]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int* keys = en_lds + wave * 2 * EN_SLOTS;
+  int* owner = keys + EN_SLOTS;
+  for (int64_t w = (int64_t)blockIdx.x * 4 + wave; w < n_users; w += (int64_t)gridDim.x * 4) {
+    const int64_t u = users[w];
+    const int64_t h0 = hist_indptr[u], h1 = hist_indptr[u + 1];
+    for (int i = lane; i < EN_SLOTS; i += 64) { keys[i] = -1; owner[i] = 0x7fffffff; }
+    __builtin_amdgcn_wave_barrier();
+    int64_t remain = item_num - (h1 - h0);
+    const bool low = 5 * remain < item_num;       // remain / item_num < 0.2: the reference then never draws item 0 (:490-493)
+    if (low) {                                    // ... so item 0 does not count as available
+      int64_t lo = h0, hi = h1;
+      while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (hist_items[mid] < 0) lo = mid + 1; else hi = mid; }
+      if (!(lo < h1 && hist_items[lo] == 0)) remain -= 1;
+    }
+    if (remain < neg_n) {                         // reference asserts (:488)
+      for (int i = lane; i < neg_n; i += 64) out[w * neg_n + i] = -1;
+      continue;
+    }
+    int need = neg_n, outpos = 0;
+    for (uint32_t j0 = 0; need > 0 && j0 < (1u << 24); j0 += 64) {      // the round cap is an exit every wave reaches
+      const uint32_t j = j0 + lane;
+      const u32x4 r = philox4x32_10((uint32_t)u, j >> 2, key.s0, key.s1, key.k0, key.k1);
+      const int c = (int)(((uint64_t)pick4(r, j & 3) * (uint64_t)item_num) >> 32);
+      bool ok = !(low && c == 0);
+      if (ok) {
+        int64_t lo = h0, hi = h1;
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (hist_items[mid] < c) lo = mid + 1; else hi = mid; }
+        ok = !(lo < h1 && hist_items[lo] == c);
+      }
+      int slot = 0;
+      if (ok) {
+        uint32_t h = ((uint32_t)c * 2654435761u) >> 20;          // 12 bits
+        for (;;) {
+          const int k = keys[h];
+          if (k == c) break;
+          if (k == -1) {
+            const int old = atomicCAS(&keys[h], -1, c);
+            if (old == -1 || old == c) break;
+          }
+          h = (h + 1) & (EN_SLOTS - 1);
+        }
+        slot = (int)h;
+        atomicMin(&owner[slot], (int)j);
+      }
+      __builtin_amdgcn_wave_barrier();
+      const bool acc = ok && owner[slot] == (int)j;               // items accepted in earlier rounds have owner < j0
+      const uint64_t bal = __ballot(acc);
+      const int rank = __popcll(bal & ((1ull << lane) - 1));
+      if (acc && rank < need) out[w * neg_n + outpos + rank] = c;
+      const int cnt = min((int)__popcll(bal), need);
+      outpos += cnt;
+      need -= cnt;
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (need > 0)
+      for (int i = lane; i < need; i += 64) out[w * neg_n + outpos + i] = -1;
+  }
+}
+
+extern "C" int dccf_sample_eval_negatives(const int64_t* users, int64_t n_users, const int64_t* hist_indptr,
+                                          const int64_t* hist_items, int64_t item_num, int32_t neg_n, uint64_t seed,
+                                          uint64_t tag, int64_t* out, void* stream) {
+  ARG_CHECK(n_users >= 0 && (n_users == 0 || (users && hist_indptr && hist_items && out)), "NULL argument");
+  ARG_CHECK(item_num > 0 && item_num < 2147483647LL, "bad item_num");
+  ARG_CHECK(neg_n >= 1 && neg_n <= EN_SLOTS / 2, "neg_n must be in [1, 2048]");
+  if (n_users == 0) return 0;
+  const size_t smem = (size_t)4 * 2 * EN_SLOTS * sizeof(int);       // 128 KB
+  static bool once = false;
+  if (!once) {
+    HIP_TRY(hipFuncSetAttribute((const void*)k_sample_eval_neg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    once = true;
+  }
+  rng_key key = make_key(seed, STREAM_EVALNEG, 0);
+  key.s0 = (uint32_t)tag;
+  key.s1 = 0;
+  const int grid = (int)min((int64_t)1024, (n_users + 3) / 4);
+  hipLaunchKernelGGL(k_sample_eval_neg, dim3(grid), dim3(256), smem, (hipStream_t)stream, users, n_users, hist_indptr,
+                     hist_items, item_num, neg_n, key, out);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}

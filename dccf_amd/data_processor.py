@@ -28,8 +28,11 @@ class DataProcessor(object):
                             help='Negative sample num for each instance in test/validation set.')
         return parser
 
-    def __init__(self, data_loader, model, rank, test_neg_n, seed=2019):
+    def __init__(self, data_loader, model, rank, test_neg_n, seed=2019, fused_eval=False):
+        """fused_eval: draw the evaluation negatives on the GPU (dccf_sample_eval_negatives) instead of the reference's
+        per-user Python loop (:446-524) — minutes of host time per split at Electronics size."""
         self.data_loader, self.model, self.rank, self.test_neg_n = data_loader, model, rank, test_neg_n
+        self.fused_eval = fused_eval
         self.train_data, self.validation_data, self.test_data = None, None, None
         self.seed = seed
         if self.rank == 1:
@@ -71,8 +74,41 @@ class DataProcessor(object):
             utils.shuffle_in_unison_scary(self.train_data)
         return self.train_data
 
-    def _eval_data(self, df):
+    def _eval_data_device(self, df, tag):
+        """_eval_data with the negatives drawn on the GPU: same first-occurrence rule (:420-426), same admissible set
+        (outside train + validation/test history, distinct), Philox stream `tag` instead of numpy's global generator."""
+        dl = self.data_loader
+        uid, iid = df['uid'].values.astype(np.int64), df['iid'].values.astype(np.int64)
+        _, first = np.unique(uid, return_index=True)
+        users = uid[np.sort(first)]                              # distinct users in first-occurrence order
+        if getattr(self, '_eval_hist', None) is None:            # CSR of train + validation/test history, items sorted
+            hu, hi = [], []
+            for d in (self.train_history_dict, self.vt_history_dict):
+                for u, items in d.items():
+                    hu.append(np.full(len(items), u, dtype=np.int64))
+                    hi.append(np.fromiter(items, dtype=np.int64, count=len(items)))
+            hu = np.concatenate(hu) if hu else np.zeros(0, np.int64)
+            hi = np.concatenate(hi) if hi else np.zeros(0, np.int64)
+            key = np.unique(hu * dl.item_num + hi)
+            indptr = np.searchsorted(key // dl.item_num, np.arange(dl.user_num + 1)).astype(np.int64)
+            dev = utils.device()
+            self._eval_hist = (torch.as_tensor(indptr).to(dev), torch.as_tensor((key % dl.item_num).astype(np.int64)).to(dev))
+        indptr, items = self._eval_hist
+        negs = _lib.sample_eval_negatives(torch.as_tensor(users).to(indptr.device), indptr, items, dl.item_num,
+                                          self.test_neg_n, self.seed, tag).cpu().numpy()
+        assert negs.min() >= 0, 'a user has fewer than test_neg_n admissible items'          # :488
+        label = np.array(df[dl.label], dtype=np.float32) if dl.label in df.columns else np.zeros(len(df), np.float32)
+        n_uid, n_iid = np.repeat(users, self.test_neg_n), negs.reshape(-1)
+        data = {'uid': np.concatenate([uid, n_uid]), 'iid': np.concatenate([iid, n_iid]),
+                'Y': np.concatenate([label, np.zeros(len(n_uid), np.float32)])}
+        data['X'] = np.stack([data['uid'], data['iid']], 1)
+        data[utils.K_SAMPLE_ID] = np.arange(0, len(data['Y']))
+        return data
+
+    def _eval_data(self, df, tag=1):
         import pandas as pd
+        if self.rank == 1 and self.fused_eval:
+            return self._eval_data_device(df, tag)
         if self.rank == 1:
             neg_df = self.generate_neg_df(df['uid'].tolist(), df['iid'].tolist(), df, self.test_neg_n, train=False)
             df = pd.concat([df, neg_df], ignore_index=True)
@@ -83,13 +119,13 @@ class DataProcessor(object):
     def get_validation_data(self):
         if self.validation_data is None:
             logging.info('Prepare Validation Data...')
-            self.validation_data = self._eval_data(self.data_loader.validation_df)
+            self.validation_data = self._eval_data(self.data_loader.validation_df, tag=1)
         return self.validation_data
 
     def get_test_data(self):
         if self.test_data is None:
             logging.info('Prepare Test Data...')
-            self.test_data = self._eval_data(self.data_loader.test_df)
+            self.test_data = self._eval_data(self.data_loader.test_df, tag=2)
         return self.test_data
 
     # ------------------------------------------------------------------ negatives (host, reference algorithm)

@@ -111,7 +111,8 @@ def main(argv=None):
     model = model.cuda()
     if init_args.rank == 1:
         data_loader.drop_neg()
-    data_processor = dp_cls(data_loader, model, rank=init_args.rank, test_neg_n=args.test_neg_n, seed=args.random_seed)
+    data_processor = dp_cls(data_loader, model, rank=init_args.rank, test_neg_n=args.test_neg_n, seed=args.random_seed,
+                            fused_eval=bool(args.fused_sampling))
     runner = runner_cls(optimizer=args.optimizer, learning_rate=args.lr, epoch=args.epoch, batch_size=args.batch_size,
                         eval_batch_size=args.eval_batch_size, dropout=args.dropout, l2=args.l2, metrics=args.metric,
                         check_epoch=args.check_epoch, early_stop=args.early_stop, fused_sampling=args.fused_sampling,

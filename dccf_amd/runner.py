@@ -31,7 +31,8 @@ class BaseRunner(object):
         parser.add_argument('--metric', type=str, default='RMSE', help='metrics: RMSE, MAE, AUC, F1, Accuracy, Precision, Recall')
         parser.add_argument('--skip_eval', type=int, default=0, help='number of epochs without evaluation')
         parser.add_argument('--fused_sampling', type=int, default=1,
-                            help='1: train negatives and batches stay on the GPU (Philox); 0: the reference host path')
+                            help='1: train negatives, batches and evaluation negatives are drawn on the GPU (Philox); '
+                                 '0: the reference host path (numpy, bit-identical batches for the same seed)')
         parser.add_argument('--device_eval', type=int, default=1,
                             help='1: predictions, top-k selection and ndcg/hit/precision/recall/f1@k (k <= 16) stay on the '
                                  'GPU; 0: the reference host path (pandas-free numpy restatement)')

@@ -206,6 +206,14 @@ int mf_predict_full(const mf_model_t* model, float* out, void* stream);
 int dccf_sample_train_negatives(const int64_t* rows_indptr, const int64_t* rows, const int64_t* hist_indptr,
                                 const int64_t* hist_items, int64_t user_num, int64_t item_num, uint64_t seed,
                                 uint64_t epoch, int64_t* neg_out, void* stream);
+/* Eval negatives (src/data_processor/DataProcessor.py:408-444,446-524 with train=False): neg_n items per DISTINCT user of a
+ * split (users [n_users], first-occurrence order), uniform over the items, outside the user's train + validation/test
+ * history (hist CSR by user id, items sorted) and distinct.  Draw j of user u = word j%4 of Philox(c0=u, c1=j/4, c2=tag)
+ * on stream 6; draws are consumed in order (accepted iff admissible and not accepted before), the first neg_n accepted
+ * ones, in draw order, go to out [n_users, neg_n] (-1 where the reference would assert: fewer than neg_n items left).
+ * tag separates the splits (1 validation, 2 test).  neg_n <= 2048. */
+int dccf_sample_eval_negatives(const int64_t* users, int64_t n_users, const int64_t* hist_indptr, const int64_t* hist_items,
+                               int64_t item_num, int32_t neg_n, uint64_t seed, uint64_t tag, int64_t* out, void* stream);
 
 /* ---- ranking metrics on the device: replaces the sort / groupby('uid') / per-group loops of BaseModel.evaluate_method
  * (src/models/BaseModel.py:83-126) with dcg/ndcg(method=1)/precision/recall/hit of src/utils/rank_metrics.py:61-87,130-201.

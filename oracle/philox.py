@@ -17,6 +17,7 @@ therefore established with *injected* draws (tests/golden); this module pins the
                   (x0,x1) -> o=0 (cos), o=1 (sin); (x2,x3) -> o=2, o=3), multiplied by std
     STREAM_DROP   c0 = l//4, c1 = d             -> row l%4 of the group, column d, is dropped iff u32 < floor(p * 2^32)
     STREAM_NEG    c0 = uid, c1 = draw//4, c2 = epoch -> draw%4-th u32, item = mulhi(u32, item_num)
+    STREAM_EVALNEG  same counters with c2 = tag (1 validation, 2 test)
 """
 import numpy as np
 
@@ -26,7 +27,7 @@ W0 = 0x9E3779B9
 W1 = 0xBB67AE85
 MASK = np.uint64(0xFFFFFFFF)
 
-STREAM_CAND, STREAM_NOISE, STREAM_DROP, STREAM_NEG, STREAM_INIT = 1, 2, 3, 4, 5
+STREAM_CAND, STREAM_NOISE, STREAM_DROP, STREAM_NEG, STREAM_INIT, STREAM_EVALNEG = 1, 2, 3, 4, 5, 6
 
 
 def philox4x32(c0, c1, c2, c3, k0, k1, rounds=10):
@@ -137,4 +138,37 @@ def train_negatives(seed, epoch, uids, item_num, hist_indptr, hist_items):
                 break
             drawn.append(it)
             out[order[r]] = it
+    return out
+
+
+def eval_negatives(seed, tag, users, item_num, hist_indptr, hist_items, neg_n):
+    """Device restatement of data_processor/DataProcessor.py:408-444,446-524 for train=False: neg_n negatives per distinct
+    user, uniform over items, outside the user's train + validation/test history and distinct.  Draws of user u are the
+    words of Philox(c0=u, c1=j//4, c2=tag) on STREAM_EVALNEG, consumed in order: draw j is accepted iff its item is
+    admissible and not accepted before; the first neg_n accepted draws, in draw order, are the result.  When fewer than
+    20 % of the items remain the reference never draws item 0 (:490-493), mirrored by rejecting item 0 in that regime.
+    -> int64 [len(users), neg_n] (-1 where fewer than neg_n admissible items exist)"""
+    k0, k1 = _key(seed, STREAM_EVALNEG)
+    out = np.full((len(users), neg_n), -1, dtype=np.int64)
+    for w, u in enumerate(np.asarray(users, dtype=np.int64)):
+        hist = set(hist_items[hist_indptr[u]:hist_indptr[u + 1]].tolist())
+        remain = item_num - len(hist)
+        low = 5 * remain < item_num
+        if low and 0 not in hist:
+            remain -= 1
+        if remain < neg_n:
+            continue
+        acc, seen, j = [], set(), 0
+        while len(acc) < neg_n:
+            xs = philox4x32(int(u), np.arange(j // 4, j // 4 + 64), tag, 0, k0, k1)       # 256 draws at a time
+            cand = np.stack([mulhi(x, item_num) for x in xs], axis=1).reshape(-1)
+            for c in cand.tolist():
+                j += 1
+                if (low and c == 0) or c in hist or c in seen:
+                    continue
+                seen.add(c)
+                acc.append(c)
+                if len(acc) == neg_n:
+                    break
+        out[w] = acc
     return out

@@ -619,3 +619,39 @@ def test_mf_row_aware_optimizer_equals_dense(L, D):
         runs.append(m.flat_p.clone())
     d = (runs[0] - runs[1]).abs()
     assert float(d.max()) <= 5 * 0.01 and int((d > 5 * STEP_FRAC * 0.01).sum()) <= 4 * D + 8
+
+
+def test_eval_negative_sampler_matches_oracle(L):
+    """dccf_sample_eval_negatives vs oracle/philox.py::eval_negatives (bit-exact) + the properties the reference's
+    sampler guarantees: neg_n distinct items per user, none from the user's train / validation / test history."""
+    rng = np.random.RandomState(4)
+    U_, I_, neg_n = 300, 257, 30
+    hist = []
+    for u in range(U_):
+        k = rng.randint(0, 40)
+        if u == 5:
+            k = 215                       # < 20 % of the items remain: item 0 is then never drawn
+        if u == 7:
+            k = 240                       # fewer than neg_n items remain -> -1 (the reference asserts)
+        hist.append(np.sort(rng.choice(I_, k, replace=False)))
+    indptr = np.r_[0, np.cumsum([len(h) for h in hist])].astype(np.int64)
+    items = np.concatenate(hist).astype(np.int64)
+    users = rng.permutation(U_)[:120].astype(np.int64)
+    users[:2] = [5, 7]
+    for tag in (1, 2):
+        got = L.sample_eval_negatives(T(users), T(indptr), T(items), I_, neg_n, 99, tag).cpu().numpy()
+        want = PH.eval_negatives(99, tag, users, I_, indptr, items, neg_n)
+        assert np.array_equal(got, want)
+        for w, u in enumerate(users):
+            if u == 7:
+                assert (got[w] == -1).all()
+                continue
+            assert len(set(got[w].tolist())) == neg_n and got[w].min() >= 0 and got[w].max() < I_
+            assert not set(got[w].tolist()) & set(hist[u].tolist())
+            if u == 5:
+                assert 0 not in got[w]
+    a = L.sample_eval_negatives(T(users), T(indptr), T(items), I_, neg_n, 99, 1).cpu().numpy()
+    b = L.sample_eval_negatives(T(users), T(indptr), T(items), I_, neg_n, 99, 2).cpu().numpy()
+    assert not np.array_equal(a, b)          # the two splits draw from different streams
+    big = L.sample_eval_negatives(T(np.arange(50, dtype=np.int64)), T(indptr), T(items), 63001, 1000, 3, 1).cpu().numpy()
+    assert big.shape == (50, 1000) and all(len(set(r.tolist())) == 1000 for r in big)
