@@ -5,10 +5,10 @@
 // width D+F and pushes them through Linear(D+F -> D): z = x W^T + b.  Here the rows are never materialised:
 //
 //   forward  (k_noise_fwd)  Z = X W^T on the fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32).  A workgroup owns 32 rows l;
-//            wave w < NC owns the 128-wide feature chunk w of K and keeps its slice of W_f in registers; its A operand
-//            feat + eps is produced in registers (Philox4x32-10 + Box-Muller, in the lane layout the MFMA wants); one more
-//            wave owns the item part of K (V[cand] rows, W_i in registers).  Partials meet in LDS; the epilogue adds b,
-//            applies relu + dropout, stores h [L,D] and the row dot m[l] = <U[u], h[l]>.
+//            K (the NC feature chunks of 128 + the item part) is split evenly over its 8 waves, each keeps its slices of
+//            W^T in registers; the A operand feat + eps is produced in registers (Philox4x32-10 + Box-Muller, in the lane
+//            layout the MFMA wants).  Partials meet in LDS; the epilogue adds b, applies relu + dropout, stores h [L,D]
+//            and the row dot m[l] = <U[u], h[l]>.  (k_fwd_rows: the rows-per-wave form for eval-size batches.)
 //   epilogue (k_pair_epilogue)  softmax over the candidates of Expo[u, cand] (one lane per candidate), prediction,
 //            BPR / MSE loss and d loss / d m.
 //   backward (k_bwd)  one barrier-free kernel of role waves that walk the batch rows: dW_f += dz^T eps with eps
@@ -18,7 +18,8 @@
 //
 // HBM layout (fp32 row-major): U [user_num,D], V [item_num,D], W [D,D+F], b [D], feat [item_num,F], expo [user_num,
 // item_num].  Workspace per call (ctx slab): cand int32 [N,S1]; WT [(D+FP),DP] = W transposed, zero padded (DP = D
-// rounded to 32/64, FP = F rounded to 128); h [L,DP]; m [L]; dmns [N*S1].
+// rounded to 32/64, FP = F rounded up to 2, 6 or 7 chunks of 128); h [L,DP]; m [L]; dmns [N*S1] (holds the gathered
+// exposures Expo[u, cand] between k_prep and k_pair_epilogue, d loss / d mean_a m afterwards).
 #include "common.hpp"
 
 // No implicit FMA contraction in this file: a*b+c written as two operations stays two roundings (explicit fmaf() calls
@@ -863,7 +864,7 @@ __global__ __launch_bounds__(64 * BWD_NW) void k_bwd(BwdArgs p) {
 static int check_model(const dccf_model_t* M) {
   ARG_CHECK(M != nullptr, "model is NULL");
   ARG_CHECK(M->D == 16 || M->D == 32 || M->D == 64 || M->D == 128, "D must be 16, 32, 64 or 128");
-  ARG_CHECK(M->F >= 1 && M->F <= 896, "F must be in [1, 896] (7 feature-chunk waves + 1 item wave per workgroup)");
+  ARG_CHECK(M->F >= 1 && M->F <= 896, "F must be in [1, 896] (at most 7 feature chunks of 128)");
   ARG_CHECK(M->S >= 0 && M->S <= 63 && M->A >= 1 && M->A <= 64, "S in [0,63], A in [1,64]");
   ARG_CHECK(M->user_num > 0 && M->item_num > 0 && M->item_num < 2147483647LL, "bad user_num / item_num");
   ARG_CHECK(M->U && M->V && M->W && M->b && M->feat, "NULL parameter / feature pointer");
