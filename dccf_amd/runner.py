@@ -258,10 +258,33 @@ class BaseRunner(object):
             return self.evaluate_device(model, data, data_processor, metrics)
         predictions = self.predict(model, data, data_processor)
         if write_rank:
-            df = pd.DataFrame({'uid': data['uid'], 'iid': data['iid'], 'score': predictions, 'label': data['Y']})
-            df = df.sort_values(by='uid')
-            df.to_csv(os.path.join(data_processor.data_loader.path, utils.RANK_FILE_NAME), sep='\t', index=False)
+            self._write_rank(os.path.join(data_processor.data_loader.path, utils.RANK_FILE_NAME), data, predictions)
         return model.evaluate_method(predictions, data, metrics=metrics)
+
+    @staticmethod
+    def _write_rank(path, data, predictions):
+        """rank.csv of src/runners/BaseRunner.py:315-323: tab-separated uid, iid, score, label sorted by uid.  With
+        --test_neg_n 1000 the test split of an Electronics-size dataset is ~2e8 rows: pandas needs minutes for the sort
+        and the text conversion, so large frames go through a stable numpy argsort and pyarrow's CSV writer."""
+        n = len(predictions)
+        if n >= 2000000:
+            try:
+                import pyarrow as pa
+                import pyarrow.csv as pacsv
+                order = np.argsort(np.asarray(data['uid']), kind='stable')
+                label = np.asarray(data['Y'])[order]
+                table = pa.table({'uid': np.asarray(data['uid'])[order], 'iid': np.asarray(data['iid'])[order],
+                                  'score': np.asarray(predictions, dtype=np.float32)[order],
+                                  'label': pa.array(label, type=pa.float32()).cast(pa.float64())})
+                with open(path, 'wb') as f:            # pandas' header (unquoted)
+                    f.write(b'uid\tiid\tscore\tlabel\n')
+                    pacsv.write_csv(table, f, pacsv.WriteOptions(delimiter='\t', quoting_style='none', include_header=False))
+                return
+            except ImportError:
+                pass
+        df = pd.DataFrame({'uid': data['uid'], 'iid': data['iid'], 'score': predictions, 'label': data['Y']})
+        df = df.sort_values(by='uid')
+        df.to_csv(path, sep='\t', index=False)
 
     def check(self, model, out_dict):
         """src/runners/BaseRunner.py:334-355."""
