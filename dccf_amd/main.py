@@ -125,7 +125,11 @@ def main(argv=None):
         runner.train(model, data_processor, skip_eval=args.skip_eval)
     logging.info('Test After Training = ' + utils.format_metric(
         runner.evaluate(model, data_processor.get_test_data(), data_processor, write_rank=True)) + ' ' + ','.join(runner.metrics))
-    np.save(args.result_file, runner.predict(model, data_processor.get_test_data(), data_processor))
+    if runner.device_eval:
+        result = runner.predict_device(model, data_processor.get_test_data(), data_processor).cpu().numpy()
+    else:
+        result = runner.predict(model, data_processor.get_test_data(), data_processor)
+    np.save(args.result_file, result)
     logging.info('Save Test Results to ' + args.result_file)
     runner.model, runner.data_processor = model, data_processor      # for callers that keep working with the trained model
     return runner

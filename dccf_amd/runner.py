@@ -219,7 +219,14 @@ class BaseRunner(object):
             ks.add(int(k))
         return len(ks) <= 4
 
-    def evaluate_device(self, model, data, data_processor, metrics):
+    def predict_device(self, model, data, data_processor):
+        """BaseRunner.predict (:134-157) from the resident split: predictions in sample-id order, on the GPU."""
+        es = data_processor.device_eval_set(data)
+        model.eval()
+        preds = [model.predict(b)['prediction'] for b in es.batches(self.eval_batch_size, self.no_dropout)]
+        return torch.cat(preds) if preds else torch.zeros(0, dtype=torch.float32, device=es.Y.device)
+
+    def evaluate_device(self, model, data, data_processor, metrics, return_predictions=False):
         """evaluate() without leaving the GPU: batched predict straight from the resident split, then one wave per user
         selects the top-k and scores it (rank_eval_topk) — replaces BaseRunner.py:134-157 + BaseModel.py:55-128."""
         es = data_processor.device_eval_set(data)
@@ -248,14 +255,18 @@ class BaseRunner(object):
                 else:       # f1@k = 2 * hits / (k + positives)
                     vals = 2.0 * per_user[:, j, 2] * k / (k + per_user[:, len(ks), 0])
                 out.append(float(vals.mean()))
-        return out
+        return (out, p) if return_predictions else out
 
     def evaluate(self, model, data, data_processor, metrics=None, write_rank=False):
         """src/runners/BaseRunner.py:305-332."""
         if metrics is None:
             metrics = self.metrics
-        if self.device_eval and not write_rank and self._device_metrics_ok(metrics):
-            return self.evaluate_device(model, data, data_processor, metrics)
+        if self.device_eval and self._device_metrics_ok(metrics):
+            if not write_rank:
+                return self.evaluate_device(model, data, data_processor, metrics)
+            res, p = self.evaluate_device(model, data, data_processor, metrics, return_predictions=True)
+            self._write_rank(os.path.join(data_processor.data_loader.path, utils.RANK_FILE_NAME), data, p.cpu().numpy())
+            return res
         predictions = self.predict(model, data, data_processor)
         if write_rank:
             self._write_rank(os.path.join(data_processor.data_loader.path, utils.RANK_FILE_NAME), data, predictions)
