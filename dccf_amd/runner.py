@@ -171,7 +171,10 @@ class BaseRunner(object):
         try:
             for epoch in range(self.epoch):
                 self._check_time()
-                epoch_train_data = data_processor.get_train_data(epoch=epoch)
+                # the host-side shuffle of the train dict (src/runners/BaseRunner.py:246, utils.py:82-92) only feeds the host
+                # batch path; with fused sampling the epoch's permutation is drawn on the GPU (DeviceTrainSet)
+                fused = self.fused_sampling and data_processor.rank == 1
+                epoch_train_data = train_data if fused else data_processor.get_train_data(epoch=epoch)
                 last_batch = self.fit(model, epoch_train_data, data_processor, epoch=epoch)
                 if self.check_epoch > 0 and (epoch == 1 or epoch % self.check_epoch == 0):
                     self.check(model, last_batch)
