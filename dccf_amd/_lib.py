@@ -16,7 +16,7 @@ EXPORTS = ['dccf_ctx_create', 'dccf_ctx_destroy', 'dccf_ctx_reserve', 'dccf_last
            'dccf_debug_keep', 'dccf_debug_workspace', 'dccf_profile', 'dccf_profile_read',
            'shard_pack_rows', 'shard_unpack_rows', 'shard_scatter_add', 'dccf_dense_opt_step_rows', 'dccf_dense_opt_step_dev', 'dccf_advance', 'rank_eval_topk', 'dccf_train_step', 'dp_buffer_words',
            'dp_export_touched', 'dp_import_touched', 'dp_mark_global', 'dccf_dense_opt_phase', 'dccf_ctx_side_stream', 'dp_import_apply',
-           'dccf_sample_eval_negatives']
+           'dccf_sample_eval_negatives', 'dccf_eval_prepare', 'dccf_predict_projected']
 
 OPT_KIND = {'gd': 0, 'adagrad': 1, 'adam': 2}
 MF_KIND = {'RecModel': 0, 'BiasedMF': 1, 'IPSBiasedMF': 2}
@@ -87,6 +87,8 @@ def load():
         'dccf_dense_opt_step_dev': [i32, vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, vp, i32, C.POINTER(i64), C.POINTER(i64),
                                     C.POINTER(i32), C.POINTER(vp), vp],
         'dccf_advance': [vp, vp],
+        'dccf_eval_prepare': [vp, C.POINTER(ModelT), vp, vp, vp],
+        'dccf_predict_projected': [vp, C.POINTER(ModelT), C.POINTER(RandT), vp, i64, f32, vp, vp, vp, vp],
         'dccf_sample_eval_negatives': [vp, i64, vp, vp, i64, i32, u64, u64, vp, vp],
         'dp_import_apply': [vp, i32, i32, vp, vp, vp, i64, f32, f32, f32, f32, i64, i32, vp, vp, vp, vp, i64, vp, i64, i32, vp,
                             vp, vp, vp],
@@ -474,4 +476,25 @@ def sample_eval_negatives(users, hist_indptr, hist_items, item_num, neg_n, seed,
     check(load().dccf_sample_eval_negatives(ptr(users, i64), users.shape[0], ptr(hist_indptr, i64), ptr(hist_items, i64),
                                             int(item_num), int(neg_n), int(seed) & 0xFFFFFFFFFFFFFFFF, int(tag), ptr(out, i64),
                                             stream()))
+    return out
+
+
+def dccf_eval_prepare(ctx, m, Pf=None, Lt=None):
+    """Pf [item_num, D] = feat W_f^T and Lt [D, D] (Cholesky factor of std^2 W_f W_f^T, transposed) for
+    dccf_predict_projected; call after the parameters changed."""
+    dev = m._refs[0].device
+    if Pf is None:
+        Pf = torch.empty((m.item_num, m.D), dtype=torch.float32, device=dev)
+    if Lt is None:
+        Lt = torch.empty((m.D, m.D), dtype=torch.float32, device=dev)
+    check(load().dccf_eval_prepare(ctx.h, C.byref(m), ptr(Pf, torch.float32), ptr(Lt, torch.float32), stream()))
+    return Pf, Lt
+
+
+def dccf_predict_projected(ctx, m, r, X, dropout, Pf, Lt, out=None):
+    N = X.shape[0]
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=X.device)
+    check(load().dccf_predict_projected(ctx.h, C.byref(m), C.byref(r), ptr(X, torch.int64), N, float(dropout),
+                                        ptr(Pf, torch.float32), ptr(Lt, torch.float32), ptr(out), stream()))
     return out

@@ -94,6 +94,7 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 #define STREAM_DROP 3u
 #define STREAM_NEG 4u
 #define STREAM_EVALNEG 6u
+#define STREAM_XI 7u
 
 struct u32x4 {
   uint32_t x, y, z, w;

@@ -1100,6 +1100,281 @@ extern "C" int dccf_train_step(dccf_ctx* ctx, const dccf_model_t* M, const dccf_
   return run_dccf(ctx, M, rnd, X, Y, N, rank, dropout, G, prediction, loss, true, (hipStream_t)stream, &plan);
 }
 
+// ================================================================================================ projected-noise predict
+// Evaluation only (no gradient is taken): z_noise = W_f eps with eps ~ N(0, std^2 I_F) iid per row IS a D-dimensional
+// Gaussian N(0, std^2 W_f W_f^T).  Drawing xi ~ N(0, I_D) and forming Lt^T xi with L L^T = std^2 W_f W_f^T samples exactly
+// that distribution with D instead of F normals and a K = D instead of K = F product per row; the deterministic part
+// W_f feat[i] is one row of a table computed once per evaluation.  The output has the distribution of DCCF.predict
+// (src/models/DCCF.py:84-97) — not its random stream, which no implementation can reproduce anyway.
+//   k_feat_proj   Pf[i][d] = sum_f feat[i][f] W[d][D+f]                      (fp32 MFMA, one wave per 32 items)
+//   k_gram_chol   G = std^2 W_f W_f^T in fp64, pivot-clamped Cholesky, Lt[k][d] = L[d][k]   (one workgroup)
+//   k_fwd_proj    z = V[cand] W_i^T + xi Lt + Pf[i0] + b, relu, dropout, m = <U[u], h>   (rows-per-wave, K = 2D)
+template <int D_>
+__global__ __launch_bounds__(256) void k_feat_proj(const float* __restrict__ WT, const float* __restrict__ feat, int64_t item_num,
+                                                   int F, float* __restrict__ Pf) {
+  constexpr int D = D_;
+  constexpr int DP = D <= 32 ? 32 : (D + 63) / 64 * 64;
+  constexpr int NT = DP / 32;
+  const int lane = threadIdx.x & 63, h = lane >> 5, c31 = lane & 31;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int64_t ntiles = (item_num + 31) / 32;
+  for (int64_t t = wave; t < ntiles; t += nw) {
+    const int64_t i = min(t * 32 + c31, item_num - 1);
+    const float* frow = feat + i * F;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    for (int k = 0; k < F; k += 8) {                  // 4 k-steps per batch of loads
+      float a[4], b[4][NT];
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const int f = min(k + 2 * o + h, F - 1);
+        a[o] = frow[f];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[o][nt] = WT[(int64_t)(D + f) * DP + nt * 32 + c31];
+      }
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const float av = (k + 2 * o + h < F) ? a[o] : 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = MFMA32(av, b[o][nt], acc[nt]);
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int d = nt * 32 + c31;
+        if (row < item_num && d < D) Pf[row * D + d] = acc[nt][r];
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_gram_chol(const float* __restrict__ W, int D, int F, float std, float* __restrict__ Lt) {
+  extern __shared__ double gd[];                      // [D][D + 1]
+  const int LD = D + 1;
+  for (int idx = threadIdx.x; idx < D * D; idx += blockDim.x) {
+    const int a = idx / D, b = idx % D;
+    if (b > a) continue;                              // lower triangle
+    const float* wa = W + (int64_t)a * (D + F) + D;
+    const float* wb = W + (int64_t)b * (D + F) + D;
+    double s = 0.0;
+    for (int f = 0; f < F; ++f) s += (double)wa[f] * (double)wb[f];
+    gd[a * LD + b] = s * (double)std * (double)std;
+  }
+  __syncthreads();
+  for (int k = 0; k < D; ++k) {                       // right-looking Cholesky; a non-positive pivot (rank-deficient W_f)
+    if (threadIdx.x == 0) {                           // gives a zero column: no variance in that direction, as it should be
+      const double p = gd[k * LD + k];
+      gd[k * LD + k] = p > 0.0 ? sqrt(p) : 0.0;
+    }
+    __syncthreads();
+    const double piv = gd[k * LD + k];
+    for (int a = k + 1 + threadIdx.x; a < D; a += blockDim.x) gd[a * LD + k] = piv > 0.0 ? gd[a * LD + k] / piv : 0.0;
+    __syncthreads();
+    const int n = D - k - 1;
+    for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
+      const int a = k + 1 + idx / n, b = k + 1 + idx % n;
+      if (b <= a) gd[a * LD + b] -= gd[a * LD + k] * gd[b * LD + k];
+    }
+    __syncthreads();
+  }
+  for (int idx = threadIdx.x; idx < D * D; idx += blockDim.x) {
+    const int k = idx / D, d = idx % D;
+    Lt[idx] = d >= k ? (float)gd[d * LD + k] : 0.f;   // Lt[k][d] = L[d][k]
+  }
+}
+
+template <int D_>
+__global__ __launch_bounds__(512) void k_fwd_proj(const float* __restrict__ WT, const float* __restrict__ Lt,
+                                                  const float* __restrict__ Pf, const float* __restrict__ bias,
+                                                  const float* __restrict__ U, const float* __restrict__ V, const int64_t* X,
+                                                  const int* __restrict__ cand, float* __restrict__ m, int64_t L, int S1, int A,
+                                                  rng_key xkey, rng_key dkey, uint32_t drop_thr, float kscale) {
+  extern __shared__ float wl[];                       // [2D][DW]: rows 0..D-1 = W_i^T, rows D..2D-1 = Lt
+  constexpr int D = D_;
+  constexpr int DP = D <= 32 ? 32 : (D + 63) / 64 * 64;
+  constexpr int ND = D <= 32 ? 1 : 2;
+  constexpr int DW = ND * 32;
+  constexpr int NWV = 8;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, c31 = lane & 31;
+  const int dbase = blockIdx.y * DW;
+  const uint32_t rows_per_n = (uint32_t)(S1 * A);
+  for (int idx = threadIdx.x; idx < 2 * D * DW; idx += blockDim.x) {
+    const int k = idx / DW, c = idx % DW;
+    const int d = dbase + c;
+    wl[idx] = k < D ? WT[(int64_t)k * DP + d] : (d < D ? Lt[(k - D) * D + d] : 0.f);
+  }
+  __syncthreads();
+  const int64_t ntiles = (L + 31) / 32;
+  const float one = -2.0f * 0.69314718055994530942f;  // noise4's scale for unit variance
+  for (int64_t tile = (int64_t)blockIdx.x * NWV + wave; tile < ntiles; tile += (int64_t)gridDim.x * NWV) {
+    const int64_t l = tile * 32 + c31;
+    const int64_t lc = l < L ? l : L - 1;
+    const float* vrow = V + (int64_t)cand[(uint32_t)lc / (uint32_t)A] * D;
+    f32x16 acc[ND];
+#pragma unroll
+    for (int nt = 0; nt < ND; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll 2
+    for (int g = 0; g < D / 8; ++g) {                 // 4 k-steps: k = 8g + 2o + h
+      float av[4], xi[4];
+#pragma unroll
+      for (int o = 0; o < 4; ++o) av[o] = vrow[8 * g + 2 * o + h];
+      noise4((uint32_t)l, (uint32_t)(2 * g + h), xkey, one, xi);
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const int k = 8 * g + 2 * o + h;
+#pragma unroll
+        for (int nt = 0; nt < ND; ++nt) {
+          acc[nt] = MFMA32(av[o], wl[k * DW + nt * 32 + c31], acc[nt]);
+          acc[nt] = MFMA32(xi[o], wl[(D + k) * DW + nt * 32 + c31], acc[nt]);
+        }
+      }
+    }
+    const int64_t base = tile * 32;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      float part[4] = {0.f, 0.f, 0.f, 0.f};
+      int64_t urow[4], prow[4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const int64_t lr = base + w + 8 * g4 + 4 * h;
+        const int64_t n = (int64_t)((uint32_t)(lr < L ? lr : L - 1) / rows_per_n);
+        urow[w] = X[2 * n] * D;
+        prow[w] = X[2 * n + 1] * D;
+      }
+#pragma unroll
+      for (int nt = 0; nt < ND; ++nt) {
+        const int d = dbase + nt * 32 + c31;
+        const bool dv = d < D;
+        const int dc = dv ? d : 0;
+        const float bd = bias[dc];
+        u32x4 r4{0, 0, 0, 0};
+        if (drop_thr) r4 = philox4x32_10((uint32_t)((base >> 2) + 2 * g4 + h), (uint32_t)d, dkey.s0, dkey.s1, dkey.k0, dkey.k1);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const bool kept = drop_thr ? pick4(r4, w) >= drop_thr : true;
+          const float z = acc[nt][g4 * 4 + w] + Pf[prow[w] + dc] + bd;
+          const float hv = (dv && z > 0.f && kept) ? z * kscale : 0.f;
+          part[w] = fmaf(U[urow[w] + dc], hv, part[w]);
+        }
+      }
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        float v = part[w];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 1, 64);
+        const int64_t lr = base + w + 8 * g4 + 4 * h;
+        if (c31 == 0 && lr < L) {
+          if (gridDim.y == 1) m[lr] = v;
+          else atomicAdd(&m[lr], v);
+        }
+      }
+    }
+  }
+}
+
+extern "C" int dccf_eval_prepare(dccf_ctx* ctx, const dccf_model_t* M, float* Pf, float* Lt, void* stream) {
+  ARG_CHECK(ctx && Pf && Lt, "NULL argument");
+  if (int e = check_model(M)) return e;
+  hipStream_t st = (hipStream_t)stream;
+  const int D = M->D, F = M->F;
+  const Lay y = make_layout(0, D, F, M->S, M->A);
+  if (int e = dccf_ws_ensure(ctx, y.total)) return e;
+  float* WT = (float*)(ctx->ws + y.WT);
+  {
+    const int64_t total = (int64_t)(D + y.FP) * y.DP + 1;
+    StepRef sr;
+    memset(&sr, 0, sizeof(sr));
+    sr.x_steps = 1;
+    MarkPlan mark;
+    memset(&mark, 0, sizeof(mark));
+    rng_key k0 = make_key(0, STREAM_CAND, 0);
+    hipLaunchKernelGGL(k_prep, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, *M, WT, D, F, y.DP, y.FP, (const int64_t*)nullptr,
+                       (const int64_t*)nullptr, (int*)nullptr, (float*)nullptr, (int64_t)0, M->S, M->item_num, 0, k0,
+                       (float*)nullptr, (int64_t)0, (float*)nullptr, sr, mark);
+  }
+  const int grid = (int)min((int64_t)2048, ((M->item_num + 31) / 32 + 3) / 4);
+#define LAUNCH_FP(D_) hipLaunchKernelGGL(k_feat_proj<D_>, dim3(grid), dim3(256), 0, st, WT, M->feat, M->item_num, F, Pf)
+  BY_D(D, LAUNCH_FP)
+#undef LAUNCH_FP
+  const size_t smem = (size_t)D * (D + 1) * sizeof(double);
+  static bool once = false;
+  if (!once) {
+    HIP_TRY(hipFuncSetAttribute((const void*)k_gram_chol, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+    once = true;
+  }
+  hipLaunchKernelGGL(k_gram_chol, dim3(1), dim3(256), smem, st, M->W, D, F, M->std, Lt);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int dccf_predict_projected(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd, const int64_t* X, int64_t N,
+                                      float dropout, const float* Pf, const float* Lt, float* prediction, void* stream) {
+  ARG_CHECK(ctx && rnd && Pf && Lt, "NULL argument");
+  if (int e = check_model(M)) return e;
+  ARG_CHECK(rnd->mode == 1 && rnd->k_dev == nullptr, "projected predict draws everything on the device (rnd.mode = 1)");
+  ARG_CHECK(N >= 0 && N * (int64_t)(M->S + 1) * M->A < 4294967296LL, "N*(S+1)*A must be < 2^32");
+  ARG_CHECK(N == 0 || (X && prediction), "NULL X / prediction");
+  ARG_CHECK(dropout >= 0.f && dropout < 1.f, "dropout must be in [0,1)");
+  if (N == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int D = M->D, F = M->F, S1 = M->S + 1, A = M->A;
+  const Lay y = make_layout(N, D, F, M->S, A);
+  if (int e = dccf_ws_ensure(ctx, y.total)) return e;
+  char* ws = ctx->ws;
+  int* cand = (int*)(ws + y.cand);
+  float* WT = (float*)(ws + y.WT);
+  float* m = (float*)(ws + y.m);
+  float* dmns = (float*)(ws + y.dmns);
+  StepRef sr;
+  memset(&sr, 0, sizeof(sr));
+  sr.x_steps = 1;
+  MarkPlan mark;
+  memset(&mark, 0, sizeof(mark));
+  {
+    const int64_t total = (int64_t)(D + y.FP) * y.DP + y.NS + (y.GY > 1 ? y.L : 0) + 1;
+    hipLaunchKernelGGL(k_prep, dim3((unsigned)min((int64_t)2048, (total + 255) / 256)), dim3(256), 0, st, *M, WT, D, F, y.DP, y.FP, X,
+                       rnd->sample_item, cand, dmns, N, M->S, M->item_num, 1, make_key(rnd->seed, STREAM_CAND, rnd->step), m,
+                       y.GY > 1 ? y.L : (int64_t)0, (float*)nullptr, sr, mark);
+  }
+  const float kscale = dropout > 0.f ? 1.0f / (float)(1.0 - (double)dropout) : 1.0f;
+  const uint32_t thr = dropout > 0.f ? drop_threshold(dropout) : 0u;
+  const int64_t ntiles = (y.L + 31) / 32;
+  const dim3 grid((unsigned)min((int64_t)1024, (ntiles + 7) / 8), y.GY);
+  const size_t smem = (size_t)2 * D * (y.ND * 32) * 4;
+#define LAUNCH_PJ(D_)                                                                                               \
+  {                                                                                                                  \
+    static bool once = false;                                                                                        \
+    if (!once) {                                                                                                     \
+      HIP_TRY(hipFuncSetAttribute((const void*)k_fwd_proj<D_>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); \
+      once = true;                                                                                                   \
+    }                                                                                                                \
+    hipLaunchKernelGGL(k_fwd_proj<D_>, grid, dim3(512), smem, st, WT, Lt, Pf, M->b, M->U, M->V, X, cand, m, y.L, S1, A, \
+                       make_key(rnd->seed, STREAM_XI, rnd->step), make_key(rnd->seed, STREAM_DROP, rnd->step), thr, kscale); \
+  }
+  BY_D(D, LAUNCH_PJ)
+#undef LAUNCH_PJ
+  {
+    const int GS = S1 <= 16 ? 16 : (S1 <= 32 ? 32 : 64);
+    const int grid2 = (int)min((int64_t)2048, (N * GS + 255) / 256);
+#define LAUNCH_PE2(GS_) hipLaunchKernelGGL((k_pair_epilogue<GS_>), dim3(grid2), dim3(256), 0, st, S1, A, (const float*)nullptr, m, dmns, prediction, (float*)nullptr, N, 1, 0)
+    if (GS == 16) LAUNCH_PE2(16); else if (GS == 32) LAUNCH_PE2(32); else LAUNCH_PE2(64);
+#undef LAUNCH_PE2
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 extern "C" int dccf_predict(dccf_ctx* ctx, const dccf_model_t* model, const dccf_rand_t* rnd, const int64_t* X,
                             int64_t N, float dropout, float* prediction, void* stream) {
   return run_dccf(ctx, model, rnd, X, nullptr, N, 1, dropout, nullptr, prediction, nullptr, false, (hipStream_t)stream);

@@ -109,6 +109,8 @@ def main(argv=None):
         return
     model.apply(model.init_paras)
     model = model.cuda()
+    if hasattr(model, 'eval_noise'):
+        model.eval_noise = args.eval_noise
     if init_args.rank == 1:
         data_loader.drop_neg()
     data_processor = dp_cls(data_loader, model, rank=init_args.rank, test_neg_n=args.test_neg_n, seed=args.random_seed,

@@ -400,8 +400,21 @@ class DCCF(DMF):
         self._rs.step = self._next_step()
         return self._rs
 
+    eval_noise = 'full'       # 'projected': evaluation draws the D-dim projected noise (same distribution, K = D instead of F)
+
+    def begin_eval(self):
+        """Called once per evaluation pass: with eval_noise == 'projected' refreshes the tables of dccf_predict_projected
+        (the parameters changed since the last pass)."""
+        if self.eval_noise == 'projected':
+            self._proj = _lib.dccf_eval_prepare(self.ctx, self._struct(), *(getattr(self, '_proj', None) or (None, None)))
+
     def predict(self, feed_dict):
         """src/models/DCCF.py:66-107.  Fresh candidates and noise on every call, also in eval mode, as in the reference."""
+        if (self.eval_noise == 'projected' and not self.training and feed_dict.get('inject') is None
+                and getattr(self, '_proj', None) is not None):
+            pred = _lib.dccf_predict_projected(self.ctx, self._struct(), self._rand(feed_dict), feed_dict['X'].contiguous(),
+                                               feed_dict['dropout'], *self._proj)
+            return {'prediction': pred, 'check': [('prediction', pred)]}
         pred = _lib.dccf_predict(self.ctx, self._struct(), self._rand(feed_dict), feed_dict['X'].contiguous(),
                                  feed_dict['dropout'])
         return {'prediction': pred, 'check': [('prediction', pred)]}

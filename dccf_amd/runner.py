@@ -36,6 +36,9 @@ class BaseRunner(object):
         parser.add_argument('--device_eval', type=int, default=1,
                             help='1: predictions, top-k selection and ndcg/hit/precision/recall/f1@k (k <= 16) stay on the '
                                  'GPU; 0: the reference host path (pandas-free numpy restatement)')
+        parser.add_argument('--eval_noise', type=str, default='full',
+                            help='DCCF evaluation: full = the 768-d noise of DCCF.predict, op for op; projected = its exact '
+                                 'D-dimensional projection N(0, std^2 W_f W_f^T) (same output distribution, ~5x faster)')
         parser.add_argument('--overlap_opt', type=int, default=0,
                             help='1: the optimizer pass over the embedding rows a DCCF batch does not touch runs on a '
                                  'low-priority side stream beside forward/backward (dccf_train_step overlap); measured '
@@ -83,6 +86,8 @@ class BaseRunner(object):
         """src/runners/BaseRunner.py:134-157: batched predict, reordered by sample_id."""
         batches = self.batches_add_control(data_processor.prepare_batches(data, self.eval_batch_size, train=False), train=False)
         model.eval()
+        if hasattr(model, 'begin_eval'):
+            model.begin_eval()
         preds = [model.predict(b)['prediction'] for b in batches]
         predictions = torch.cat(preds).cpu().numpy() if preds else np.zeros(0, dtype=np.float32)
         sample_ids = np.concatenate([b[utils.K_SAMPLE_ID] for b in batches])
@@ -226,6 +231,8 @@ class BaseRunner(object):
         """BaseRunner.predict (:134-157) from the resident split: predictions in sample-id order, on the GPU."""
         es = data_processor.device_eval_set(data)
         model.eval()
+        if hasattr(model, 'begin_eval'):
+            model.begin_eval()
         preds = [model.predict(b)['prediction'] for b in es.batches(self.eval_batch_size, self.no_dropout)]
         return torch.cat(preds) if preds else torch.zeros(0, dtype=torch.float32, device=es.Y.device)
 
@@ -233,9 +240,7 @@ class BaseRunner(object):
         """evaluate() without leaving the GPU: batched predict straight from the resident split, then one wave per user
         selects the top-k and scores it (rank_eval_topk) — replaces BaseRunner.py:134-157 + BaseModel.py:55-128."""
         es = data_processor.device_eval_set(data)
-        model.eval()
-        preds = [model.predict(b)['prediction'] for b in es.batches(self.eval_batch_size, self.no_dropout)]
-        p = torch.cat(preds) if preds else torch.zeros(0, dtype=torch.float32, device=es.Y.device)
+        p = self.predict_device(model, data, data_processor)
         ks = sorted({int(m.split('@')[1]) for m in metrics if '@' in m})
         per_user = None
         if ks:

@@ -96,6 +96,17 @@ typedef struct {             /* dense-shaped gradients of the LOSS term, accumul
 int dccf_predict(dccf_ctx* ctx, const dccf_model_t* model, const dccf_rand_t* rnd, const int64_t* X, int64_t N,
                  float dropout, float* prediction, void* stream);
 
+/* Evaluation-only predict with PROJECTED noise (an option; dccf_predict is the op-for-op path).  No gradient is taken at
+ * evaluation, and z_noise = W_f eps with eps ~ N(0, std^2 I_F) iid per row is exactly N(0, std^2 W_f W_f^T): drawing D
+ * normals xi and forming L xi (L L^T = std^2 W_f W_f^T) samples the same distribution with a K = D product instead of
+ * K = F, and W_f feat[i] becomes a row of a table.  dccf_eval_prepare fills Pf [item_num, D] = feat W_f^T and
+ * Lt [D, D] (Lt[k][d] = L[d][k], pivot-clamped fp64 Cholesky) — call it once after the parameters changed;
+ * dccf_predict_projected then has the DISTRIBUTION of DCCF.predict (src/models/DCCF.py:66-107), not the same draws
+ * (rnd.mode must be 1: candidates, xi and dropout from the Philox streams). */
+int dccf_eval_prepare(dccf_ctx* ctx, const dccf_model_t* model, float* Pf, float* Lt, void* stream);
+int dccf_predict_projected(dccf_ctx* ctx, const dccf_model_t* model, const dccf_rand_t* rnd, const int64_t* X, int64_t N,
+                           float dropout, const float* Pf, const float* Lt, float* prediction, void* stream);
+
 /* DCCF.forward + loss.backward() (src/models/DCCF.py:109-127, src/runners/BaseRunner.py:180-183) for the loss term:
  * rank==1: rows [0,N/2) positives, [N/2,N) their negatives, loss = -sum log sigmoid(pos-neg); rank==0: MSE vs Y.
  * Writes prediction [N], loss [1] (device scalar) and accumulates the four gradients. */

@@ -24,6 +24,7 @@ def main():
     p.add_argument('--test_neg_n', type=int, default=1000)
     p.add_argument('--eval_batch_size', type=int, default=128 * 128)
     p.add_argument('--reps', type=int, default=2)
+    p.add_argument('--eval_noise', type=str, default='full', help='full | projected (see dccf_predict_projected)')
     a = p.parse_args()
     from dccf_amd import _lib
     from dccf_amd.models import DCCF
@@ -39,6 +40,7 @@ def main():
              feature_num=0, user_num=a.users, item_num=a.items, u_vector_size=a.dim, i_vector_size=a.dim, n_layers=1,
              random_seed=1, model_path='/tmp/e.pt', feature_embedding=feat, ips_factors=ips)
     m.apply(m.init_paras)
+    m.eval_noise = a.eval_noise
     rng = np.random.RandomState(0)
     per = 1 + a.test_neg_n
     users = rng.choice(a.users, a.eval_users, replace=False)
@@ -75,7 +77,7 @@ def main():
     t_rank = (time.time() - t0) / 5
     print(json.dumps({'metric': 'eval_rows_per_s', 'value': es.n / dt, 'rows': es.n, 'users': a.eval_users, 'per_user': per,
                       'eval_s': dt, 'first_eval_s_incl_upload_and_csr': t_first, 'rank_kernel_s': t_rank,
-                      'full_split_estimate_s': dt * a.users / a.eval_users, 'result': res}))
+                      'full_split_estimate_s': dt * a.users / a.eval_users, 'eval_noise': a.eval_noise, 'result': res}))
 
 
 if __name__ == '__main__':

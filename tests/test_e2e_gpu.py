@@ -104,5 +104,6 @@ def test_exposure_pipeline_ipsbiasedmf_then_dccf(tmp_path):
     np.testing.assert_allclose(expo_written, full.cpu().numpy(), rtol=1e-5, atol=1e-6)
     r2 = run_cli(tmp, ['--model_name', 'DCCF', '--epoch', '2', '--fused_sampling', '0', '--model_path', '../model/DCCF/x.pt'] + common)
     assert len(r2.valid_results) == 2 and np.isfinite(r2.valid_results[-1][0])
-    r3 = run_cli(tmp, ['--model_name', 'DCCF', '--epoch', '1', '--load', '1', '--model_path', '../model/DCCF/x.pt'] + common)
-    assert np.isfinite(r3.valid_results[-1][0])
+    r3 = run_cli(tmp, ['--model_name', 'DCCF', '--epoch', '1', '--load', '1', '--model_path', '../model/DCCF/x.pt',
+                       '--eval_noise', 'projected'] + common)       # evaluation through dccf_predict_projected
+    assert np.isfinite(r3.valid_results[-1][0]) and r3.valid_results[-1][0] > 0.5 * r2.valid_results[-1][0]

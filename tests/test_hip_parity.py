@@ -655,3 +655,40 @@ def test_eval_negative_sampler_matches_oracle(L):
     assert not np.array_equal(a, b)          # the two splits draw from different streams
     big = L.sample_eval_negatives(T(np.arange(50, dtype=np.int64)), T(indptr), T(items), 63001, 1000, 3, 1).cpu().numpy()
     assert big.shape == (50, 1000) and all(len(set(r.tolist())) == 1000 for r in big)
+
+
+@pytest.mark.parametrize('D,F', [(64, 768), (16, 96), (128, 160)])
+def test_projected_eval_tables_and_distribution(L, ctx, D, F):
+    """dccf_eval_prepare / dccf_predict_projected: Pf == feat W_f^T, Lt^T Lt... (L L^T == std^2 W_f W_f^T), and the
+    predictions of the projected-noise path have the distribution of the op-for-op path: for a batch that repeats the
+    SAME (user, item) row, both paths produce iid samples of one random variable — their means and standard deviations
+    agree within 5 standard errors, and their quartiles agree."""
+    rng = np.random.RandomState(D + F)
+    U_, I_, S, A, std = 40, 60, 10, 2, 0.3
+    Ut, Vt = T((rng.randn(U_, D) * 0.3).astype(np.float32)), T((rng.randn(I_, D) * 0.3).astype(np.float32))
+    W, b = T((rng.randn(D, D + F) * 0.1).astype(np.float32)), T((rng.randn(D) * 0.1).astype(np.float32))
+    feat, expo = T((rng.randn(I_, F) * 0.5).astype(np.float32)), T(rng.randn(U_, I_).astype(np.float32))
+    m = L.model_struct(Ut, Vt, W, b, feat, expo, S, A, std)
+    Pf, Lt = L.dccf_eval_prepare(ctx, m)
+    Wf = W[:, D:].double()
+    close(Pf, (feat.double() @ Wf.T).cpu().numpy(), 2e-5, 1e-6, 'Pf')
+    G = (std * std) * (Wf @ Wf.T)
+    LtL = Lt.double().T @ Lt.double()                      # (L^T)^T (L^T) = L L^T
+    close(LtL, G.cpu().numpy(), 2e-5, 1e-7, 'L L^T')
+    assert float(torch.tril(Lt, -1).abs().max()) == 0.0     # Lt is upper triangular (L lower)
+    N = 6144
+    X = torch.tensor([[7, 11]], dtype=torch.int64, device=dev()).repeat(N, 1)
+    full = L.dccf_predict(ctx, m, L.rand_struct(seed=3, step=1), X, 0.0).double().cpu().numpy()
+    proj = L.dccf_predict_projected(ctx, m, L.rand_struct(seed=3, step=1), X, 0.0, Pf, Lt).double().cpu().numpy()
+    se = np.sqrt(full.var() / N + proj.var() / N)
+    assert abs(full.mean() - proj.mean()) <= 5 * se, (full.mean(), proj.mean(), se)
+    assert abs(full.std() - proj.std()) <= 5 * full.std() / np.sqrt(2 * N) * 1.5, (full.std(), proj.std())
+    qf, qp = np.quantile(full, [0.25, 0.5, 0.75]), np.quantile(proj, [0.25, 0.5, 0.75])
+    assert np.all(np.abs(qf - qp) <= 0.08 * full.std()), (qf, qp)
+    # a different row: different distribution (the test has power)
+    other = L.dccf_predict(ctx, m, L.rand_struct(seed=3, step=1),
+                           torch.tensor([[8, 12]], dtype=torch.int64, device=dev()).repeat(N, 1), 0.0).double().cpu().numpy()
+    assert abs(other.mean() - full.mean()) > 5 * se
+    # with dropout the projected path still runs and stays finite
+    pd_ = L.dccf_predict_projected(ctx, m, L.rand_struct(seed=3, step=2), X[:257], 0.2, Pf, Lt)
+    assert bool(torch.isfinite(pd_).all())
