@@ -170,3 +170,32 @@ def test_metrics():
            O.ndcg_at_k([1], 2, 0)]
     assert np.allclose(got, g['doc/ndcg'], rtol=1e-12)
     assert np.allclose(got, [1.0, 0.9203032077642922, 0.96519546960144276, 0.0, 1.0], rtol=1e-12)
+
+
+def test_eval_negatives_oracle_properties():
+    """oracle/philox.py::eval_negatives (the sequential definition the device sampler is checked against): neg_n distinct
+    admissible items per user in draw order, reproducible, split-dependent, -1 rows where too few items remain."""
+    from oracle import philox as PH
+    rng = np.random.RandomState(1)
+    U_, I_, neg_n = 40, 97, 15
+    hist = [np.sort(rng.choice(I_, rng.randint(0, 30), replace=False)) for _ in range(U_)]
+    hist[3] = np.sort(rng.choice(I_, 85, replace=False))          # 12 items left < neg_n -> -1
+    hist[4] = np.sort(rng.choice(np.arange(1, I_), 80, replace=False))          # low regime: 17 left incl. item 0
+    indptr = np.r_[0, np.cumsum([len(h) for h in hist])].astype(np.int64)
+    items = np.concatenate(hist).astype(np.int64)
+    users = np.arange(U_, dtype=np.int64)
+    a = PH.eval_negatives(5, 1, users, I_, indptr, items, neg_n)
+    assert np.array_equal(a, PH.eval_negatives(5, 1, users, I_, indptr, items, neg_n))
+    assert not np.array_equal(a, PH.eval_negatives(5, 2, users, I_, indptr, items, neg_n))
+    assert (a[3] == -1).all()
+    for u in range(U_):
+        if u == 3:
+            continue
+        assert len(set(a[u].tolist())) == neg_n and not set(a[u].tolist()) & set(hist[u].tolist())
+    assert 0 not in a[4]                                           # item 0 is never drawn once < 20 % of the items remain
+    # draw order: the first accepted draw of user 0 is its first admissible Philox candidate
+    k0, k1 = PH._key(5, PH.STREAM_EVALNEG)
+    xs = PH.philox4x32(0, np.arange(8), 1, 0, k0, k1)
+    cand = np.stack([PH.mulhi(x, I_) for x in xs], axis=1).reshape(-1)
+    first = next(int(c) for c in cand if int(c) not in set(hist[0].tolist()))
+    assert a[0][0] == first
