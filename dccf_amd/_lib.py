@@ -16,7 +16,8 @@ EXPORTS = ['dccf_ctx_create', 'dccf_ctx_destroy', 'dccf_ctx_reserve', 'dccf_last
            'dccf_debug_keep', 'dccf_debug_workspace', 'dccf_profile', 'dccf_profile_read',
            'shard_pack_rows', 'shard_unpack_rows', 'shard_scatter_add', 'dccf_dense_opt_step_rows', 'dccf_dense_opt_step_dev', 'dccf_advance', 'rank_eval_topk', 'dccf_train_step', 'dp_buffer_words',
            'dp_export_touched', 'dp_import_touched', 'dp_mark_global', 'dccf_dense_opt_phase', 'dccf_ctx_side_stream', 'dp_import_apply',
-           'dccf_sample_eval_negatives', 'dccf_eval_prepare', 'dccf_predict_projected']
+           'dccf_sample_eval_negatives', 'dccf_eval_prepare', 'dccf_predict_projected', 'dccf_dp_local', 'dccf_dp_overlap',
+           'dccf_dp_finish']
 
 OPT_KIND = {'gd': 0, 'adagrad': 1, 'adam': 2}
 MF_KIND = {'RecModel': 0, 'BiasedMF': 1, 'IPSBiasedMF': 2}
@@ -46,6 +47,13 @@ class OptT(C.Structure):
                 ('lr', C.c_float), ('wd', C.c_float), ('l2', C.c_float), ('clip', C.c_float), ('step', C.c_int64),
                 ('nseg', C.c_int32), ('reserved', C.c_int32), ('seg_begin', _f), ('seg_rows', _f), ('seg_width', _f),
                 ('seg_flags', _f)]
+
+
+class DpT(C.Structure):
+    _fields_ = [('G', C.c_int32), ('rank', C.c_int32), ('D', C.c_int32), ('S', C.c_int32), ('cap', C.c_int64),
+                ('dense_begin', C.c_int64), ('item_num', C.c_int64), ('seed', C.c_uint64), ('buf', _f), ('bufs', _f),
+                ('loss', _f), ('loss_sum', _f), ('gflagsU', _f), ('gflagsV', _f), ('segU', C.c_int32), ('segV', C.c_int32),
+                ('glist', _f), ('gcnt', _f), ('mask', _f), ('where', _f)]
 
 
 class MFModelT(C.Structure):
@@ -87,6 +95,10 @@ def load():
         'dccf_dense_opt_step_dev': [i32, vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, vp, i32, C.POINTER(i64), C.POINTER(i64),
                                     C.POINTER(i32), C.POINTER(vp), vp],
         'dccf_advance': [vp, vp],
+        'dccf_dp_local': [vp, C.POINTER(ModelT), C.POINTER(RandT), vp, vp, i64, f32, C.POINTER(GradsT), C.POINTER(OptT),
+                          C.POINTER(DpT), vp, vp],
+        'dccf_dp_overlap': [C.POINTER(OptT), C.POINTER(DpT), vp, i64, u64, i32, vp],
+        'dccf_dp_finish': [C.POINTER(OptT), C.POINTER(DpT), i32, vp],
         'dccf_eval_prepare': [vp, C.POINTER(ModelT), vp, vp, vp],
         'dccf_predict_projected': [vp, C.POINTER(ModelT), C.POINTER(RandT), vp, i64, f32, vp, vp, vp, vp],
         'dccf_sample_eval_negatives': [vp, i64, vp, vp, i64, i32, u64, u64, vp, vp],

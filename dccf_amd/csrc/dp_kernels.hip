@@ -411,3 +411,51 @@ extern "C" int dp_mark_global(const int64_t* X_all, int32_t G, int64_t N, int32_
   HIP_TRY(hipGetLastError());
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------- one step in three calls
+extern "C" int dccf_dp_local(dccf_ctx* ctx, const dccf_model_t* model, const dccf_rand_t* rnd, const int64_t* X, const float* Y,
+                             int64_t N, float dropout, const dccf_grads_t* grads, const dccf_opt_t* opt, const dccf_dp_t* dp,
+                             float* prediction, void* stream) {
+  ARG_CHECK(opt && dp && dp->loss && dp->buf, "NULL opt / dp");
+  if (int e = dccf_train_fwdbwd(ctx, model, rnd, X, Y, N, 1, dropout, grads, prediction, dp->loss, stream)) return e;
+  return dp_export_touched(opt->g, opt->n, opt->nseg, opt->seg_begin, opt->seg_rows, opt->seg_width, opt->seg_flags,
+                           dp->dense_begin, dp->loss, dp->buf, dp->cap, dp->D, 0, stream);
+}
+
+static int dp_global_flags(const dccf_opt_t* opt, const dccf_dp_t* dp, uint8_t** out) {
+  ARG_CHECK(opt->nseg >= 2 && opt->nseg <= 4 && dp->segU >= 0 && dp->segU < opt->nseg && dp->segV >= 0 && dp->segV < opt->nseg &&
+                dp->segU != dp->segV && dp->gflagsU && dp->gflagsV,
+            "bad global-flag segments");
+  for (int q = 0; q < opt->nseg; ++q) out[q] = opt->seg_flags[q];
+  out[dp->segU] = dp->gflagsU;
+  out[dp->segV] = dp->gflagsV;
+  return 0;
+}
+
+extern "C" int dccf_dp_overlap(const dccf_opt_t* opt, const dccf_dp_t* dp, const int64_t* X_all, int64_t N, uint64_t step0,
+                               int32_t parity, void* stream) {
+  ARG_CHECK(opt && dp && dp->gcnt && dp->glist && (parity == 0 || parity == 1), "NULL opt / dp or bad parity");
+  uint8_t* gf[4];
+  if (int e = dp_global_flags(opt, dp, gf)) return e;
+  if (int e = dp_mark_global(X_all, dp->G, N, dp->S, dp->item_num, dp->seed, step0, dp->gflagsU, dp->gflagsV, dp->segU, dp->segV,
+                             dp->glist, dp->gcnt + parity, dp->gcnt + (1 - parity), stream))
+    return e;
+  return dccf_dense_opt_phase(opt->kind, opt->p, opt->g, opt->s1, opt->s2, opt->n, opt->lr, opt->wd, opt->l2, opt->clip, opt->step,
+                              opt->nseg, opt->seg_begin, opt->seg_rows, opt->seg_width, gf, 1, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int dccf_dp_finish(const dccf_opt_t* opt, const dccf_dp_t* dp, int32_t overlap, void* stream) {
+  ARG_CHECK(opt && dp && dp->bufs && dp->mask && dp->where, "NULL opt / dp");
+  if (overlap) {
+    uint8_t* gf[4];
+    if (int e = dp_global_flags(opt, dp, gf)) return e;
+    return dp_import_apply(dp->bufs, dp->G, opt->kind, opt->p, opt->s1, opt->s2, opt->n, opt->lr, opt->wd, opt->l2, opt->clip,
+                           opt->step, opt->nseg, opt->seg_begin, opt->seg_rows, opt->seg_width, gf, dp->dense_begin, dp->loss_sum,
+                           dp->cap, dp->D, dp->mask, dp->where, dp->buf, stream);
+  }
+  if (int e = dp_import_touched(dp->bufs, dp->G, opt->g, opt->n, opt->nseg, opt->seg_begin, opt->seg_rows, opt->seg_width,
+                                opt->seg_flags, dp->dense_begin, dp->loss_sum, dp->cap, dp->D, dp->mask, dp->where, dp->buf, stream))
+    return e;
+  return dccf_dense_opt_step_rows(opt->kind, opt->p, opt->g, opt->s1, opt->s2, opt->n, opt->lr, opt->wd, opt->l2, opt->clip,
+                                  opt->step, opt->nseg, opt->seg_begin, opt->seg_rows, opt->seg_width, opt->seg_flags, stream);
+}

@@ -26,13 +26,19 @@ One optimizer step therefore sees the sum of the G ranks' BPR terms: exactly the
 (loss = -sum log sigmoid, src/models/DCCF.py:116-120).  The row-sharded alternative (dccf_amd/sharded.py) is for tables
 that do not fit one GPU; it needs 4 collectives per step instead of 1.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
+# rehearsal on one GPU: issue the all-gather even at world size 1 (measures the host cost of the collective call)
+_FORCE_COLLECTIVE = os.environ.get('DCCF_FORCE_COLLECTIVE', '0') == '1'
+
 
 class HipBackend(object):
-    """The product backend: libdccf_hip.so through dccf_amd._lib.  The argument blocks of the four library calls of a step
-    are built once (`prepare`): a step at batch 128 is ~150 us of GPU work, the host must stay well below that."""
+    """The product backend: libdccf_hip.so through dccf_amd._lib.  One step = three library calls (dccf_dp_local,
+    dccf_dp_overlap, dccf_dp_finish) whose argument blocks are built once (`prepare`): a step at batch 128 is ~150 us of
+    GPU work and the host must stay below that (measured: 7 separate calls + the collective cost 143 us of host time)."""
 
     def __init__(self, device):
         from dccf_amd import _lib
@@ -45,76 +51,48 @@ class HipBackend(object):
         import ctypes as C
         L = self.L
         lib = L.load()
-        f32, u8 = torch.float32, torch.uint8
+        f32, u8, i32, i64 = torch.float32, torch.uint8, torch.int32, torch.int64
         self.m = L.model_struct(tr.U, tr.V, tr.W, tr.b, tr.feat, tr.expo, tr.S, tr.A, tr.std, ips=tr.ips)
         self.r = L.rand_struct(seed=tr.seed, step=0)
         self.g = L.GradsT(L.ptr(tr.gU), L.ptr(tr.gV), L.ptr(tr.gW), L.ptr(tr.gb), L.ptr(tr.tU, u8), L.ptr(tr.tV, u8))
-        self.seg = L._seg_arrays(tr.segments)
-        self.mp, self.rp, self.gp = C.byref(self.m), C.byref(self.r), C.byref(self.g)
-        self.a_export = (L.ptr(tr.flat_g, f32), tr.flat_g.numel()) + self.seg + (
-            int(tr.dense_begin), L.ptr(tr.loss, f32), L.ptr(tr.buf, f32), int(tr.cap), int(tr.D), 0)
+        self.opt = L.opt_struct('adam', tr.flat_p, tr.flat_g, tr.s1, tr.s2, tr.lr, tr.l2, tr.l2, 50.0, tr.segments, 0)
         self.scratch = L.DpScratch(tr.user_num + tr.item_num, tr.G, tr.flat_g.device)
-        sc = (L.ptr(self.scratch.mask, torch.int32), L.ptr(self.scratch.where, torch.int32))
-        self.a_import = (L.ptr(tr.bufs, f32), int(tr.G), L.ptr(tr.flat_g, f32), tr.flat_g.numel()) + self.seg + (
-            int(tr.dense_begin), L.ptr(tr.loss_sum, f32), int(tr.cap), int(tr.D)) + sc
-        self.a_opt = (L.OPT_KIND['adam'], L.ptr(tr.flat_p, f32), L.ptr(tr.flat_g, f32), L.ptr(tr.s1, f32), L.ptr(tr.s2, f32),
-                      tr.flat_p.numel(), float(tr.lr), float(tr.l2), float(tr.l2), 50.0)
-        self.f_fwbw, self.f_export, self.f_import, self.f_opt = (lib.dccf_train_fwdbwd, lib.dp_export_touched,
-                                                                 lib.dp_import_touched, lib.dccf_dense_opt_step_rows)
-        # overlap mode: global marks, optimizer in two phases, the untouched-row phase while the all-gather is in flight
-        self.gseg = L._seg_arrays(tr.gsegments)
-        self.a_import_g = (L.ptr(tr.bufs, f32), int(tr.G), L.ptr(tr.flat_g, f32), tr.flat_g.numel()) + self.gseg + (
-            int(tr.dense_begin), L.ptr(tr.loss_sum, f32), int(tr.cap), int(tr.D)) + sc
-        self.p_buf = L.ptr(tr.buf, f32)
-        self.a_mark = (int(tr.S), int(tr.item_num), int(tr.seed) & 0xFFFFFFFFFFFFFFFF)
-        self.p_flags = (L.ptr(tr.gfU, u8), L.ptr(tr.gfV, u8), 0, 1, L.ptr(tr.glist, torch.int64))
-        self.p_cnt = L.ptr(tr.gcnt, torch.int32)
-        self.f_mark, self.f_phase, self.f_apply = lib.dp_mark_global, lib.dccf_dense_opt_phase, lib.dp_import_apply
-        self.a_apply_head = (L.ptr(tr.bufs, f32), int(tr.G), L.OPT_KIND['adam'], L.ptr(tr.flat_p, f32), L.ptr(tr.s1, f32),
-                             L.ptr(tr.s2, f32), tr.flat_p.numel(), float(tr.lr), float(tr.l2), float(tr.l2), 50.0)
-        self.a_apply_tail = self.gseg + (int(tr.dense_begin), L.ptr(tr.loss_sum, f32), int(tr.cap), int(tr.D)) + sc + (
-            L.ptr(tr.buf, f32),)
+        d = L.DpT()
+        d.G, d.rank, d.D, d.S = int(tr.G), int(tr.rank), int(tr.D), int(tr.S)
+        d.cap, d.dense_begin, d.item_num = int(tr.cap), int(tr.dense_begin), int(tr.item_num)
+        d.seed = int(tr.seed) & 0xFFFFFFFFFFFFFFFF
+        d.buf, d.bufs, d.loss, d.loss_sum = L.ptr(tr.buf, f32), L.ptr(tr.bufs, f32), L.ptr(tr.loss, f32), L.ptr(tr.loss_sum, f32)
+        d.gflagsU, d.gflagsV, d.segU, d.segV = L.ptr(tr.gfU, u8), L.ptr(tr.gfV, u8), 0, 1
+        d.glist, d.gcnt = L.ptr(tr.glist, i64), L.ptr(tr.gcnt, i32)
+        d.mask, d.where = L.ptr(self.scratch.mask, i32), L.ptr(self.scratch.where, i32)
+        self.dp = d
+        self.mp, self.rp, self.gp, self.op, self.dpp = (C.byref(self.m), C.byref(self.r), C.byref(self.g), C.byref(self.opt),
+                                                        C.byref(self.dp))
+        self.f_local, self.f_overlap, self.f_finish = lib.dccf_dp_local, lib.dccf_dp_overlap, lib.dccf_dp_finish
         self.ready = tr
 
-    def local_step(self, tr, X, Y, step, pred):
+    def local(self, tr, X, Y, step, pred):
+        """forward/backward on this rank's batch + export of the touched gradient rows into tr.buf."""
         if self.ready is not tr:
             self.prepare(tr)
         if pred is None:
             pred = torch.empty(X.shape[0], dtype=torch.float32, device=X.device)
         self.r.step = step
-        self.L.check(self.f_fwbw(self.ctx.h, self.mp, self.rp, self.L.ptr(X, torch.int64), self.L.ptr(Y, torch.float32),
-                                 X.shape[0], 1, tr.dropout, self.gp, self.L.ptr(pred, torch.float32), tr.loss.data_ptr(),
-                                 self.L.stream()))
-        return pred, tr.loss
-
-    def export(self, tr):
-        self.L.check(self.f_export(*self.a_export, self.L.stream()))
-
-    def import_(self, tr, global_flags=False):
-        self.L.check(self.f_import(*(self.a_import_g if global_flags else self.a_import), self.p_buf, self.L.stream()))
-
-    def mark_global(self, tr, X_all, step0):
-        if self.ready is not tr:
-            self.prepare(tr)
-        c = self.p_cnt
-        self.L.check(self.f_mark(self.L.ptr(X_all, torch.int64), X_all.shape[0], X_all.shape[1], *self.a_mark, int(step0),
-                                 *self.p_flags, c + 4 * tr.parity, c + 4 * (1 - tr.parity), self.L.stream()))
-
-    def opt_untouched(self, tr, t):
-        """Phase 1 on the current stream: enqueued right after the all-gather was handed to RCCL's stream, so the
-        collective's kernel is already resident when this pass starts to fill the GPU."""
-        self.L.check(self.f_phase(*self.a_opt, t, *self.gseg, 1, None, None, 0, self.L.stream()))
-
-    def import_apply(self, tr, t):
-        """Import and phase 2 in one pass: rank-ordered sums go straight into the optimizer (dp_import_apply)."""
-        self.L.check(self.f_apply(*self.a_apply_head, t, *self.a_apply_tail, self.L.stream()))
-
-    def opt_touched(self, tr, t):
-        self.L.check(self.f_phase(*self.a_opt, t, *self.gseg, 2, self.p_flags[4], self.p_cnt + 4 * tr.parity, tr.glist.numel(),
+        self.L.check(self.f_local(self.ctx.h, self.mp, self.rp, self.L.ptr(X, torch.int64), self.L.ptr(Y, torch.float32),
+                                  X.shape[0], tr.dropout, self.gp, self.op, self.dpp, self.L.ptr(pred, torch.float32),
                                   self.L.stream()))
+        return pred
 
-    def opt_step(self, tr):
-        self.L.check(self.f_opt(*self.a_opt, tr.t, *self.seg, self.L.stream()))
+    def overlap(self, tr, X_all, step0, t):
+        """While RCCL moves the buffers: mark the rows ANY rank touches, then the optimizer pass over all the others."""
+        self.opt.step = t
+        self.L.check(self.f_overlap(self.op, self.dpp, self.L.ptr(X_all, torch.int64), X_all.shape[1], int(step0), tr.parity,
+                                    self.L.stream()))
+
+    def finish(self, tr, t, ov):
+        """After the gathered buffers arrived: rank-ordered sums -> optimizer (ov: only the marked rows + W, b are left)."""
+        self.opt.step = t
+        self.L.check(self.f_finish(self.op, self.dpp, 1 if ov else 0, self.L.stream()))
 
 
 class ReplicatedDCCF(object):
@@ -185,25 +163,20 @@ class ReplicatedDCCF(object):
         be = self.be
         ov = self.overlap and X_all is not None
         step0, t = self.t * self.G, self.t + 1
-        pred, _ = be.local_step(self, X, Y, step0 + self.rank, pred)
-        be.export(self)
+        pred = be.local(self, X, Y, step0 + self.rank, pred)
         work = None
-        if self.G > 1:                                             # the step's only collective
+        if self.G > 1 or _FORCE_COLLECTIVE:                        # the step's only collective
             work = dist.all_gather_into_tensor(self.bufs, self.buf, group=self.group, async_op=ov)
         else:
             self.bufs.copy_(self.buf)
         self.t = t
         if ov:
-            # while RCCL moves the buffers: mark the rows ANY rank touches, then the optimizer pass over all the others
-            be.mark_global(self, X_all, step0)
-            be.opt_untouched(self, t)
+            be.overlap(self, X_all, step0, t)
             if work is not None:
                 work.wait()
-            be.import_apply(self, t)           # rank-ordered sums -> optimizer for the marked rows + W, b
+        be.finish(self, t, ov)
+        if ov:
             self.parity ^= 1
-        else:
-            be.import_(self)
-            be.opt_step(self)
         return pred, self.loss_sum
 
 
@@ -274,7 +247,7 @@ def bench_main(args, rank, world, dev):
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_prof)]
     for k in range(n_prof):
         ev[k][0].record()
-        be.f_phase(*be.a_opt, tr.t + 1, *be.gseg, 1, None, None, 0, be.L.stream())       # no row is marked: the whole pass
+        be.L.dense_opt_phase('adam', tr.flat_p, tr.flat_g, tr.s1, tr.s2, tr.lr, tr.l2, tr.l2, 50.0, tr.t + 1, tr.gsegments, 1)   # no row is marked: the whole pass
         ev[k][1].record()
     torch.cuda.synchronize()
     adam_ms = sum(a.elapsed_time(b) for a, b in ev) / n_prof

@@ -270,6 +270,36 @@ int dp_import_touched(const float* bufs, int32_t G, float* g, int64_t n, int32_t
                       const int64_t* seg_rows, const int32_t* seg_width, uint8_t* const* seg_flags, int64_t dense_begin,
                       float* loss_sum, int64_t cap, int32_t D, uint32_t* mask, int32_t* where, float* reset_buf, void* stream);
 
+/* The three calls of one replicated data-parallel step, for a host loop that has to stay below ~100 us per step
+ * (dccf_amd/replicated.py): state of the exchange in one struct, the optimizer in a dccf_opt_t whose segments carry the
+ * LOCAL touched bytes (grads->touchedU/V).
+ *   dccf_dp_local    dccf_train_fwdbwd (loss -> dp->loss) + dp_export_touched into dp->buf          [then: all-gather]
+ *   dccf_dp_overlap  dp_mark_global (X_all int64 [G][N][2], Philox step of rank 0 = step0) + dccf_dense_opt_phase(1) on the
+ *                    global marks — enqueue it right after the all-gather was launched
+ *   dccf_dp_finish   overlap != 0: dp_import_apply;  else dp_import_touched + dccf_dense_opt_step_rows   [after the wait] */
+typedef struct {
+  int32_t G, rank, D, S;
+  int64_t cap, dense_begin, item_num;
+  uint64_t seed;
+  float* buf;                /* this rank's export buffer, dp_buffer_words(cap, D, n - dense_begin) words  */
+  float* bufs;               /* the G gathered buffers                                                      */
+  float* loss;               /* [1] this rank's loss                                                        */
+  float* loss_sum;           /* [1] sum over the ranks                                                      */
+  uint8_t* gflagsU;          /* "touched by ANY rank" bytes of the user / item segment (overlap mode)       */
+  uint8_t* gflagsV;
+  int32_t segU, segV;        /* indices of those segments in opt->seg_*                                      */
+  int64_t* glist;            /* [G * cap] de-duplicated global rows                                          */
+  int32_t* gcnt;             /* [2] alternating counters                                                     */
+  uint32_t* mask;            /* scratch of the import, see dp_import_touched                                 */
+  int32_t* where;
+} dccf_dp_t;
+int dccf_dp_local(dccf_ctx* ctx, const dccf_model_t* model, const dccf_rand_t* rnd, const int64_t* X, const float* Y, int64_t N,
+                  float dropout, const dccf_grads_t* grads, const dccf_opt_t* opt, const dccf_dp_t* dp, float* prediction,
+                  void* stream);
+int dccf_dp_overlap(const dccf_opt_t* opt, const dccf_dp_t* dp, const int64_t* X_all, int64_t N, uint64_t step0, int32_t parity,
+                    void* stream);
+int dccf_dp_finish(const dccf_opt_t* opt, const dccf_dp_t* dp, int32_t overlap, void* stream);
+
 /* ---- row movers of the row-sharded multi-GPU path (dccf_amd/sharded.py; no reference counterpart — the reference is
  * single-GPU, src/main.py:106,153-155).  `tables` / `widths` are HOST arrays of up to 4 device pointers / row widths. */
 /* out[dst[j] (j when dst is NULL), 0:sum(widths)] = [T0[idx[j], :] | T1[idx[j], :] | ...]; payload rows are ld floats

@@ -83,6 +83,23 @@ class OracleBackend(object):
         for _, _, _, flags in tr.gsegments:
             flags.zero_()
 
+    # ---- the three calls of a step (interface of replicated.HipBackend), composed from the pieces below
+    def local(self, tr, X, Y, step, pred):
+        pred, _ = self.local_step(tr, X, Y, step, pred)
+        self.export(tr)
+        return pred
+
+    def overlap(self, tr, X_all, step0, t):
+        self.mark_global(tr, X_all, step0)
+        self.opt_untouched(tr, t)
+
+    def finish(self, tr, t, ov):
+        if ov:
+            self.import_apply(tr, t)
+        else:
+            self.import_(tr)
+            self.opt_step(tr)
+
     def import_apply(self, tr, t):
         self.import_(tr, global_flags=True)
         self.opt_touched(tr, t)
