@@ -96,8 +96,8 @@ def load():
                                     C.POINTER(i32), C.POINTER(vp), vp],
         'dccf_advance': [vp, vp],
         'dccf_dp_local': [vp, C.POINTER(ModelT), C.POINTER(RandT), vp, vp, i64, f32, C.POINTER(GradsT), C.POINTER(OptT),
-                          C.POINTER(DpT), vp, vp],
-        'dccf_dp_overlap': [C.POINTER(OptT), C.POINTER(DpT), vp, i64, u64, i32, vp],
+                          C.POINTER(DpT), vp, u64, i32, vp, vp],
+        'dccf_dp_overlap': [C.POINTER(OptT), C.POINTER(DpT), vp],
         'dccf_dp_finish': [C.POINTER(OptT), C.POINTER(DpT), i32, vp],
         'dccf_eval_prepare': [vp, C.POINTER(ModelT), vp, vp, vp],
         'dccf_predict_projected': [vp, C.POINTER(ModelT), C.POINTER(RandT), vp, i64, f32, vp, vp, vp, vp],

@@ -34,19 +34,83 @@ static DpLay dp_layout(int64_t cap, int D, int64_t nd) {
 
 extern "C" int64_t dp_buffer_words(int64_t cap, int32_t D, int64_t nd) { return dp_layout(cap, D, nd).words; }
 
+// ---------------------------------------------------------------------------------------------- global marking
+// Which rows will ANY rank's batch touch this step?  Known without communication: the schedule X_all [G][N][2] is
+// replicated and rank r's candidates are the Philox stream of (seed, step0 + r) — the same draws k_prep makes on rank r
+// (models/DCCF.py:72-74).  Rows outside this set see only the l2 term, so their optimizer pass does not have to wait for
+// the exchange.  Runs as its own launch (dp_mark_global) or as extra workgroups of the export kernel (dccf_dp_local).
+struct MarkGlobal {
+  const int64_t* X_all;
+  int G, S;
+  int64_t N, item_num;
+  rng_key key0;
+  MarkPlan mp;
+};
+
+__device__ __forceinline__ void dp_mark_rows(const MarkGlobal& mg, int64_t tid, int64_t nthreads) {
+  const int S1 = mg.S + 1;
+  const int64_t per = mg.N * S1, total = (int64_t)mg.G * per;
+  for (int64_t i = tid; i < total; i += nthreads) {
+    const int r = (int)(i / per);
+    const int64_t j = i % per, n = j / S1;
+    const int s = (int)(j % S1);
+    const int64_t* X = mg.X_all + (int64_t)r * mg.N * 2;
+    int64_t it;
+    if (s == 0) {
+      it = X[2 * n + 1];
+    } else {
+      const rng_key key = key_plus(mg.key0, r);
+      const u32x4 rr = philox4x32_10((uint32_t)n, (uint32_t)((s - 1) >> 2), key.s0, key.s1, key.k0, key.k1);
+      it = (int64_t)(((uint64_t)pick4(rr, (s - 1) & 3) * (uint64_t)mg.item_num) >> 32);
+    }
+    mark_row(mg.mp.flagV, it, mg.mp.tagV, mg.mp);
+    if (s == 0) mark_row(mg.mp.flagU, X[2 * n], mg.mp.tagU, mg.mp);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_dp_mark(MarkGlobal mg) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *mg.mp.cnt_next = 0;
+  dp_mark_rows(mg, blockIdx.x * (int64_t)blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
+}
+
+static int make_mark_global(const int64_t* X_all, int32_t G, int64_t N, int32_t S, int64_t item_num, uint64_t seed, uint64_t step0,
+                            uint8_t* flagsU, uint8_t* flagsV, int32_t segU, int32_t segV, int64_t* list, int32_t* cnt,
+                            int32_t* cnt_next, MarkGlobal* mg) {
+  ARG_CHECK(X_all && flagsU && flagsV && list && cnt && cnt_next, "NULL argument");
+  ARG_CHECK(G >= 1 && N >= 1 && S >= 0 && item_num > 0, "bad sizes");
+  ARG_CHECK((uintptr_t)flagsU % 4 == 0 && (uintptr_t)flagsV % 4 == 0, "flags must be 4-byte aligned (padded to whole words)");
+  mg->X_all = X_all; mg->G = G; mg->S = S; mg->N = N; mg->item_num = item_num;
+  mg->key0 = make_key(seed, STREAM_CAND, step0);
+  mg->mp.flagU = (uint32_t*)flagsU;
+  mg->mp.flagV = (uint32_t*)flagsV;
+  mg->mp.tagU = (int64_t)segU << 40;
+  mg->mp.tagV = (int64_t)segV << 40;
+  mg->mp.list = list;
+  mg->mp.cnt = cnt;
+  mg->mp.cnt_next = cnt_next;
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------- export
 // A wave looks at 256 consecutive flag bytes of one segment (one 32-bit word per lane): a wave-wide prefix sum places its
 // set bytes behind ONE atomicAdd on the buffer's counter, then 16-lane groups ship four rows at a time (float4 columns).
 __global__ __launch_bounds__(256) void k_dp_export(float* __restrict__ g, RowSegs sg, int64_t dense_begin, const float* loss,
-                                                   float* __restrict__ buf, DpLay y, int scan_blocks) {
+                                                   float* __restrict__ buf, DpLay y, int scan_blocks, int work_blocks,
+                                                   MarkGlobal mg) {
   __shared__ int wl[4][256];                  // per wave: the rows found in the current chunk
+  if ((int)blockIdx.x >= work_blocks) {       // global marking role (independent of the export: different flag arrays)
+    const int mb = blockIdx.x - work_blocks;
+    if (mb == 0 && threadIdx.x == 0) *mg.mp.cnt_next = 0;
+    dp_mark_rows(mg, mb * (int64_t)blockDim.x + threadIdx.x, (int64_t)(gridDim.x - work_blocks) * blockDim.x);
+    return;
+  }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int* count = reinterpret_cast<int*>(buf);
   int64_t* ids = reinterpret_cast<int64_t*>(buf + y.ids_off);
   float* rows = buf + y.rows_off;
   if ((int)blockIdx.x >= scan_blocks) {       // dense tail + loss
     const int64_t tid = (int64_t)(blockIdx.x - scan_blocks) * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)(gridDim.x - scan_blocks) * blockDim.x;
+    const int64_t stride = (int64_t)(work_blocks - scan_blocks) * blockDim.x;
     for (int64_t i = tid; i < y.nd; i += stride) {
       buf[y.dense_off + i] = g[dense_begin + i];
       g[dense_begin + i] = 0.f;
@@ -105,9 +169,9 @@ __global__ __launch_bounds__(256) void k_dp_export(float* __restrict__ g, RowSeg
   }
 }
 
-extern "C" int dp_export_touched(float* g, int64_t n, int32_t nseg, const int64_t* seg_begin, const int64_t* seg_rows,
-                                 const int32_t* seg_width, uint8_t* const* seg_flags, int64_t dense_begin, const float* loss,
-                                 float* buf, int64_t cap, int32_t D, int32_t reset, void* stream) {
+static int dp_export_impl(float* g, int64_t n, int32_t nseg, const int64_t* seg_begin, const int64_t* seg_rows,
+                          const int32_t* seg_width, uint8_t* const* seg_flags, int64_t dense_begin, const float* loss,
+                          float* buf, int64_t cap, int32_t D, int32_t reset, const MarkGlobal* mgp, void* stream) {
   ARG_CHECK(g && buf && nseg >= 1 && nseg <= 4 && seg_begin && seg_rows && seg_width && seg_flags, "NULL / bad segments");
   ARG_CHECK(cap >= 1 && dense_begin >= 0 && dense_begin <= n, "bad cap / dense_begin");
   RowSegs sg;
@@ -130,10 +194,24 @@ extern "C" int dp_export_touched(float* g, int64_t n, int32_t nseg, const int64_
   if (reset) HIP_TRY(hipMemsetAsync(buf, 0, DP_HDR * sizeof(float), st));     // else: dp_import_touched(reset_buf) did it
   const int scan_blocks = (int)max((int64_t)1, min((int64_t)1024, (max_rows / 4 + 255) / 256));
   const int dense_blocks = (int)max((int64_t)1, min((int64_t)256, (y.nd + 255) / 256));
-  hipLaunchKernelGGL(k_dp_export, dim3(scan_blocks + dense_blocks), dim3(256), 0, st, g, sg, dense_begin, loss, buf, y,
-                     scan_blocks);
+  MarkGlobal mg;
+  memset(&mg, 0, sizeof(mg));
+  int mark_blocks = 0;
+  if (mgp) {
+    mg = *mgp;
+    mark_blocks = (int)min((int64_t)256, ((int64_t)mg.G * mg.N * (mg.S + 1) + 255) / 256);
+  }
+  hipLaunchKernelGGL(k_dp_export, dim3(scan_blocks + dense_blocks + mark_blocks), dim3(256), 0, st, g, sg, dense_begin, loss, buf,
+                     y, scan_blocks, scan_blocks + dense_blocks, mg);
   HIP_TRY(hipGetLastError());
   return 0;
+}
+
+extern "C" int dp_export_touched(float* g, int64_t n, int32_t nseg, const int64_t* seg_begin, const int64_t* seg_rows,
+                                 const int32_t* seg_width, uint8_t* const* seg_flags, int64_t dense_begin, const float* loss,
+                                 float* buf, int64_t cap, int32_t D, int32_t reset, void* stream) {
+  return dp_export_impl(g, n, nseg, seg_begin, seg_rows, seg_width, seg_flags, dense_begin, loss, buf, cap, D, reset, nullptr,
+                        stream);
 }
 
 // ---------------------------------------------------------------------------------------------- import
@@ -362,52 +440,14 @@ extern "C" int dp_import_apply(const float* bufs, int32_t G, int32_t kind, float
                         where, reset_buf, &job, (hipStream_t)stream);
 }
 
-// ---------------------------------------------------------------------------------------------- global marking
-// Which rows will ANY rank's batch touch this step?  Known before the step starts: the schedule X_all [G][N][2] is
-// replicated and rank r's candidates are the Philox stream of (seed, step0 + r) — the same draws k_prep makes on rank r
-// (models/DCCF.py:72-74).  Rows outside this set see only the l2 term, so their optimizer pass does not have to wait for
-// the exchange: it runs on a side stream while export / all-gather / import are in flight.
-__global__ __launch_bounds__(256) void k_dp_mark(const int64_t* __restrict__ X_all, int G, int64_t N, int S, int64_t item_num,
-                                                 rng_key key0, MarkPlan mp) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) *mp.cnt_next = 0;
-  const int S1 = S + 1;
-  const int64_t per = N * S1, total = (int64_t)G * per;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int r = (int)(i / per);
-    const int64_t j = i % per, n = j / S1;
-    const int s = (int)(j % S1);
-    const int64_t* X = X_all + (int64_t)r * N * 2;
-    int64_t it;
-    if (s == 0) {
-      it = X[2 * n + 1];
-    } else {
-      const rng_key key = key_plus(key0, r);
-      const u32x4 rr = philox4x32_10((uint32_t)n, (uint32_t)((s - 1) >> 2), key.s0, key.s1, key.k0, key.k1);
-      it = (int64_t)(((uint64_t)pick4(rr, (s - 1) & 3) * (uint64_t)item_num) >> 32);
-    }
-    mark_row(mp.flagV, it, mp.tagV, mp);
-    if (s == 0) mark_row(mp.flagU, X[2 * n], mp.tagU, mp);
-  }
-}
-
 extern "C" int dp_mark_global(const int64_t* X_all, int32_t G, int64_t N, int32_t S, int64_t item_num, uint64_t seed,
                               uint64_t step0, uint8_t* flagsU, uint8_t* flagsV, int32_t segU, int32_t segV, int64_t* list,
                               int32_t* cnt, int32_t* cnt_next, void* stream) {
-  ARG_CHECK(X_all && flagsU && flagsV && list && cnt && cnt_next, "NULL argument");
-  ARG_CHECK(G >= 1 && N >= 1 && S >= 0 && item_num > 0, "bad sizes");
-  ARG_CHECK((uintptr_t)flagsU % 4 == 0 && (uintptr_t)flagsV % 4 == 0, "flags must be 4-byte aligned (padded to whole words)");
-  MarkPlan mp;
-  mp.flagU = (uint32_t*)flagsU;
-  mp.flagV = (uint32_t*)flagsV;
-  mp.tagU = (int64_t)segU << 40;
-  mp.tagV = (int64_t)segV << 40;
-  mp.list = list;
-  mp.cnt = cnt;
-  mp.cnt_next = cnt_next;
+  MarkGlobal mg;
+  if (int e = make_mark_global(X_all, G, N, S, item_num, seed, step0, flagsU, flagsV, segU, segV, list, cnt, cnt_next, &mg)) return e;
   const int64_t total = (int64_t)G * N * (S + 1);
   const int grid = (int)min((int64_t)1024, (total + 255) / 256);
-  hipLaunchKernelGGL(k_dp_mark, dim3(grid), dim3(256), 0, (hipStream_t)stream, X_all, G, N, S, item_num,
-                     make_key(seed, STREAM_CAND, step0), mp);
+  hipLaunchKernelGGL(k_dp_mark, dim3(grid), dim3(256), 0, (hipStream_t)stream, mg);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -415,11 +455,18 @@ extern "C" int dp_mark_global(const int64_t* X_all, int32_t G, int64_t N, int32_
 // ---------------------------------------------------------------------------------------------- one step in three calls
 extern "C" int dccf_dp_local(dccf_ctx* ctx, const dccf_model_t* model, const dccf_rand_t* rnd, const int64_t* X, const float* Y,
                              int64_t N, float dropout, const dccf_grads_t* grads, const dccf_opt_t* opt, const dccf_dp_t* dp,
-                             float* prediction, void* stream) {
+                             const int64_t* X_all, uint64_t step0, int32_t parity, float* prediction, void* stream) {
   ARG_CHECK(opt && dp && dp->loss && dp->buf, "NULL opt / dp");
   if (int e = dccf_train_fwdbwd(ctx, model, rnd, X, Y, N, 1, dropout, grads, prediction, dp->loss, stream)) return e;
-  return dp_export_touched(opt->g, opt->n, opt->nseg, opt->seg_begin, opt->seg_rows, opt->seg_width, opt->seg_flags,
-                           dp->dense_begin, dp->loss, dp->buf, dp->cap, dp->D, 0, stream);
+  MarkGlobal mg;
+  if (X_all) {     // overlap mode: the global marking rides in the export launch
+    ARG_CHECK(dp->gcnt && dp->glist && (parity == 0 || parity == 1), "NULL global list / bad parity");
+    if (int e = make_mark_global(X_all, dp->G, N, dp->S, dp->item_num, dp->seed, step0, dp->gflagsU, dp->gflagsV, dp->segU,
+                                 dp->segV, dp->glist, dp->gcnt + parity, dp->gcnt + (1 - parity), &mg))
+      return e;
+  }
+  return dp_export_impl(opt->g, opt->n, opt->nseg, opt->seg_begin, opt->seg_rows, opt->seg_width, opt->seg_flags,
+                        dp->dense_begin, dp->loss, dp->buf, dp->cap, dp->D, 0, X_all ? &mg : nullptr, stream);
 }
 
 static int dp_global_flags(const dccf_opt_t* opt, const dccf_dp_t* dp, uint8_t** out) {
@@ -432,14 +479,10 @@ static int dp_global_flags(const dccf_opt_t* opt, const dccf_dp_t* dp, uint8_t**
   return 0;
 }
 
-extern "C" int dccf_dp_overlap(const dccf_opt_t* opt, const dccf_dp_t* dp, const int64_t* X_all, int64_t N, uint64_t step0,
-                               int32_t parity, void* stream) {
-  ARG_CHECK(opt && dp && dp->gcnt && dp->glist && (parity == 0 || parity == 1), "NULL opt / dp or bad parity");
+extern "C" int dccf_dp_overlap(const dccf_opt_t* opt, const dccf_dp_t* dp, void* stream) {
+  ARG_CHECK(opt && dp, "NULL opt / dp");
   uint8_t* gf[4];
   if (int e = dp_global_flags(opt, dp, gf)) return e;
-  if (int e = dp_mark_global(X_all, dp->G, N, dp->S, dp->item_num, dp->seed, step0, dp->gflagsU, dp->gflagsV, dp->segU, dp->segV,
-                             dp->glist, dp->gcnt + parity, dp->gcnt + (1 - parity), stream))
-    return e;
   return dccf_dense_opt_phase(opt->kind, opt->p, opt->g, opt->s1, opt->s2, opt->n, opt->lr, opt->wd, opt->l2, opt->clip, opt->step,
                               opt->nseg, opt->seg_begin, opt->seg_rows, opt->seg_width, gf, 1, nullptr, nullptr, 0, stream);
 }

@@ -71,23 +71,23 @@ class HipBackend(object):
         self.f_local, self.f_overlap, self.f_finish = lib.dccf_dp_local, lib.dccf_dp_overlap, lib.dccf_dp_finish
         self.ready = tr
 
-    def local(self, tr, X, Y, step, pred):
-        """forward/backward on this rank's batch + export of the touched gradient rows into tr.buf."""
+    def local(self, tr, X, Y, step, pred, X_all=None, step0=0):
+        """forward/backward on this rank's batch + export of the touched gradient rows into tr.buf; with X_all the rows ANY
+        rank touches this step are marked in the same launch (overlap mode)."""
         if self.ready is not tr:
             self.prepare(tr)
         if pred is None:
             pred = torch.empty(X.shape[0], dtype=torch.float32, device=X.device)
         self.r.step = step
         self.L.check(self.f_local(self.ctx.h, self.mp, self.rp, self.L.ptr(X, torch.int64), self.L.ptr(Y, torch.float32),
-                                  X.shape[0], tr.dropout, self.gp, self.op, self.dpp, self.L.ptr(pred, torch.float32),
-                                  self.L.stream()))
+                                  X.shape[0], tr.dropout, self.gp, self.op, self.dpp, self.L.ptr(X_all, torch.int64), int(step0),
+                                  tr.parity, self.L.ptr(pred, torch.float32), self.L.stream()))
         return pred
 
-    def overlap(self, tr, X_all, step0, t):
-        """While RCCL moves the buffers: mark the rows ANY rank touches, then the optimizer pass over all the others."""
+    def overlap(self, tr, t):
+        """While RCCL moves the buffers: the optimizer pass over the rows no rank touches."""
         self.opt.step = t
-        self.L.check(self.f_overlap(self.op, self.dpp, self.L.ptr(X_all, torch.int64), X_all.shape[1], int(step0), tr.parity,
-                                    self.L.stream()))
+        self.L.check(self.f_overlap(self.op, self.dpp, self.L.stream()))
 
     def finish(self, tr, t, ov):
         """After the gathered buffers arrived: rank-ordered sums -> optimizer (ov: only the marked rows + W, b are left)."""
@@ -163,7 +163,7 @@ class ReplicatedDCCF(object):
         be = self.be
         ov = self.overlap and X_all is not None
         step0, t = self.t * self.G, self.t + 1
-        pred = be.local(self, X, Y, step0 + self.rank, pred)
+        pred = be.local(self, X, Y, step0 + self.rank, pred, X_all if ov else None, step0)
         work = None
         if self.G > 1 or _FORCE_COLLECTIVE:                        # the step's only collective
             work = dist.all_gather_into_tensor(self.bufs, self.buf, group=self.group, async_op=ov)
@@ -171,7 +171,7 @@ class ReplicatedDCCF(object):
             self.bufs.copy_(self.buf)
         self.t = t
         if ov:
-            be.overlap(self, X_all, step0, t)
+            be.overlap(self, t)
             if work is not None:
                 work.wait()
         be.finish(self, t, ov)

@@ -273,9 +273,10 @@ int dp_import_touched(const float* bufs, int32_t G, float* g, int64_t n, int32_t
 /* The three calls of one replicated data-parallel step, for a host loop that has to stay below ~100 us per step
  * (dccf_amd/replicated.py): state of the exchange in one struct, the optimizer in a dccf_opt_t whose segments carry the
  * LOCAL touched bytes (grads->touchedU/V).
- *   dccf_dp_local    dccf_train_fwdbwd (loss -> dp->loss) + dp_export_touched into dp->buf          [then: all-gather]
- *   dccf_dp_overlap  dp_mark_global (X_all int64 [G][N][2], Philox step of rank 0 = step0) + dccf_dense_opt_phase(1) on the
- *                    global marks — enqueue it right after the all-gather was launched
+ *   dccf_dp_local    dccf_train_fwdbwd (loss -> dp->loss) + dp_export_touched into dp->buf; with X_all != NULL (int64
+ *                    [G][N][2], Philox step of rank 0 = step0) the global marking of dp_mark_global rides in the export
+ *                    launch                                                                            [then: all-gather]
+ *   dccf_dp_overlap  dccf_dense_opt_phase(1) on the global marks — enqueue it right after the all-gather was launched
  *   dccf_dp_finish   overlap != 0: dp_import_apply;  else dp_import_touched + dccf_dense_opt_step_rows   [after the wait] */
 typedef struct {
   int32_t G, rank, D, S;
@@ -294,10 +295,9 @@ typedef struct {
   int32_t* where;
 } dccf_dp_t;
 int dccf_dp_local(dccf_ctx* ctx, const dccf_model_t* model, const dccf_rand_t* rnd, const int64_t* X, const float* Y, int64_t N,
-                  float dropout, const dccf_grads_t* grads, const dccf_opt_t* opt, const dccf_dp_t* dp, float* prediction,
-                  void* stream);
-int dccf_dp_overlap(const dccf_opt_t* opt, const dccf_dp_t* dp, const int64_t* X_all, int64_t N, uint64_t step0, int32_t parity,
-                    void* stream);
+                  float dropout, const dccf_grads_t* grads, const dccf_opt_t* opt, const dccf_dp_t* dp, const int64_t* X_all,
+                  uint64_t step0, int32_t parity, float* prediction, void* stream);
+int dccf_dp_overlap(const dccf_opt_t* opt, const dccf_dp_t* dp, void* stream);
 int dccf_dp_finish(const dccf_opt_t* opt, const dccf_dp_t* dp, int32_t overlap, void* stream);
 
 /* ---- row movers of the row-sharded multi-GPU path (dccf_amd/sharded.py; no reference counterpart — the reference is

@@ -84,13 +84,14 @@ class OracleBackend(object):
             flags.zero_()
 
     # ---- the three calls of a step (interface of replicated.HipBackend), composed from the pieces below
-    def local(self, tr, X, Y, step, pred):
+    def local(self, tr, X, Y, step, pred, X_all=None, step0=0):
         pred, _ = self.local_step(tr, X, Y, step, pred)
         self.export(tr)
+        if X_all is not None:
+            self.mark_global(tr, X_all, step0)
         return pred
 
-    def overlap(self, tr, X_all, step0, t):
-        self.mark_global(tr, X_all, step0)
+    def overlap(self, tr, t):
         self.opt_untouched(tr, t)
 
     def finish(self, tr, t, ov):
