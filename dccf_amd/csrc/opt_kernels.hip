@@ -387,7 +387,9 @@ static int launch_job(const OptJob& j, int phase, const int64_t* list, const int
     return 0;
   }
   const int64_t work = (j.n + 3) / 4;
-  const int grid = (int)min((int64_t)(256 * 16), (work + 255) / 256);
+  // one float4 slot per thread at Electronics size (16384 workgroups): 61.5 -> 59.3 us against 4096 grid-striding workgroups
+  const int64_t gmax = getenv("DCCF_OPT_GRID") ? atoll(getenv("DCCF_OPT_GRID")) : 16384;
+  const int grid = (int)min(gmax, (work + 255) / 256);
   if (j.n >= 100000000LL) {
     if (j.kind == DCCF_OPT_GD) hipLaunchKernelGGL((k_dense_opt_rows<DCCF_OPT_GD, 2>), dim3(grid), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.n, j.a, j.sg, phase);
     else if (j.kind == DCCF_OPT_ADAGRAD) hipLaunchKernelGGL((k_dense_opt_rows<DCCF_OPT_ADAGRAD, 2>), dim3(grid), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.n, j.a, j.sg, phase);
