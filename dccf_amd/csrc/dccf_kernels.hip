@@ -155,7 +155,7 @@ __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT,
                                                    const uint8_t* __restrict__ keep, float* __restrict__ hbuf,
                                                    float* __restrict__ m, int64_t L, int S1,
                                                    int A, int F, rng_key nkey, rng_key dkey, float nscale,
-                                                   uint32_t drop_thr, float kscale, StepRef sr) {
+                                                   uint32_t drop_thr, float kscale, StepRef sr, int store_h) {
   extern __shared__ float zpart[];   // [8][32][DW]
   TRACE(0);
   {
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT,
           for (int w = 1; w < NW; ++w) z += zpart[(w * 32 + row) * DW + lane];
           z += bias_d;
           const float hv = (z > 0.f && ((kbits >> i) & 1u)) ? z * kscale : 0.f;
-          hbuf[lr * DP + dcol] = hv;
+          if (store_h) hbuf[lr * DP + dcol] = hv;          // the backward's input; evaluation does not need it
           part = uval[i] * hv;
         }
         part = wave_sum(part);
@@ -800,7 +800,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
       once = true;                                                                                                   \
     }                                                                                                                \
     hipLaunchKernelGGL((k_noise_fwd<D_, MODE_, NCM_>), grid, block, smem, st, WT, M->b, M->U, M->V, M->feat, X, cand, \
-                       rnd->noise, rnd->keep, hbuf, m, y.L, S1, A, F, nkey, dkey, nscale, thr, kscale, sr);        \
+                       rnd->noise, rnd->keep, hbuf, m, y.L, S1, A, F, nkey, dkey, nscale, thr, kscale, sr, train ? 1 : 0); \
   }
 #define LAUNCH_FWD2(D_, MODE_)                                              \
   if (y.FP == 256) LAUNCH_FWD3(D_, MODE_, 2) else if (y.FP == 768) LAUNCH_FWD3(D_, MODE_, 6) else LAUNCH_FWD3(D_, MODE_, 7)
