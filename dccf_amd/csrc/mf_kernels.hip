@@ -195,6 +195,97 @@ __global__ __launch_bounds__(256) void k_mf_train(mf_model_t M, mf_grads_t G, co
   if (threadIdx.x == 0) atomicAdd(loss, red[0] + red[1] + red[2] + red[3]);
 }
 
+// Small batches (the reference's default 128 pairs): the chunked kernel above runs 4 workgroups through three barriers
+// and takes 37 us; here ONE WAVE owns one unit (a BPR pair, or one MSE row): rows gathered straight into registers
+// (lane = column, up to 4 columns per lane), scores by a wave reduction, gradients leave as one atomic row add per
+// embedding row (duplicates inside a batch are rare at this size and the atomics sum them anyway).
+__global__ __launch_bounds__(256) void k_mf_train_small(mf_model_t M, mf_grads_t G, const int64_t* __restrict__ X,
+                                                        const float* __restrict__ Y, int64_t N, int rank,
+                                                        float* __restrict__ pred, float* __restrict__ loss) {
+  const int D = M.D;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t B = N / 2;
+  const int64_t units = rank == 1 ? B : N;
+  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  float lsum = 0.f, b0sum = 0.f;
+  for (int64_t k = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6); k < units; k += nw) {
+    const int nrow = rank == 1 ? 2 : 1;
+    int64_t u[2], it[2], row[2];
+    float pv[2][4], qv[2][4], sc[2], ip[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      row[r] = r == 0 ? k : B + k;
+      const bool on = r < nrow;
+      u[r] = X[2 * (on ? row[r] : k)];
+      it[r] = X[2 * (on ? row[r] : k) + 1];
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int d = lane + 64 * c;
+        const int dc = d < D ? d : 0;
+        pv[r][c] = M.P[u[r] * D + dc];
+        qv[r][c] = M.Q[it[r] * D + dc];
+        if (d < D) acc = fmaf(pv[r][c], qv[r][c], acc);
+      }
+      acc = wave_sum(acc);
+      sc[r] = mf_score(M, u[r], it[r], acc, ip[r]);
+    }
+    float g[2] = {0.f, 0.f};
+    if (rank == 1) {
+      const float dd = sc[0] - sc[1];
+      const float sg = 1.f / (1.f + expf(-dd));
+      const float gp = -(1.f - sg);
+      g[0] = gp / ip[0];
+      g[1] = -gp / ip[1];
+      if (lane == 0) {
+        pred[k] = sc[0];
+        pred[B + k] = sc[1];
+        lsum += -logf(sg);
+      }
+    } else {
+      const float diff = sc[0] - Y[k];
+      g[0] = (2.f * diff / (float)N) / ip[0];
+      if (lane == 0) {
+        pred[k] = sc[0];
+        lsum += diff * diff / (float)N;
+      }
+    }
+    const bool same_user = rank == 1 && u[0] == u[1];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      if (r >= nrow) break;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int d = lane + 64 * c;
+        if (d >= D) break;
+        // the user row of a BPR pair is shared by its positive and negative row: one atomic row add for both
+        if (same_user) { if (r == 0) atomicAdd(&G.gP[u[0] * D + d], fmaf(g[0], qv[0][c], g[1] * qv[1][c])); }
+        else atomicAdd(&G.gP[u[r] * D + d], g[r] * qv[r][c]);
+        atomicAdd(&G.gQ[it[r] * D + d], g[r] * pv[r][c]);
+      }
+      if (lane == 0) {
+        if (M.kind >= 1) {
+          atomicAdd(&G.gbu[u[r]], g[r]);
+          atomicAdd(&G.gbi[it[r]], g[r]);
+        }
+        if (G.touchedP) G.touchedP[u[r]] = 1;
+        if (G.touchedQ) G.touchedQ[it[r]] = 1;
+      }
+    }
+    b0sum += g[0] + (nrow == 2 ? g[1] : 0.f);
+  }
+  __shared__ float red[8];             // one atomic per workgroup on the two single-address sums
+  if (lane == 0) { red[wv] = lsum; red[4 + wv] = b0sum; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(loss, red[0] + red[1] + red[2] + red[3]);
+    if (M.kind >= 1) atomicAdd(G.gb0, red[4] + red[5] + red[6] + red[7]);
+  }
+}
+
 extern "C" int mf_train_fwdbwd(dccf_ctx* ctx, const mf_model_t* M, const int64_t* X, const float* Y, int64_t N,
                                int32_t rank, const mf_grads_t* G, float* prediction, float* loss, void* stream) {
   (void)ctx;
@@ -211,6 +302,12 @@ extern "C" int mf_train_fwdbwd(dccf_ctx* ctx, const mf_model_t* M, const int64_t
   if (N == 0) return 0;
   const int per = rank == 1 ? MF_CH / 2 : MF_CH;
   const int64_t units = rank == 1 ? N / 2 : N;
+  if (units <= 1024 && M->D <= 256) {        // one wave per pair / row (measured: 11.6 vs 36.8 us at 128 pairs)
+    hipLaunchKernelGGL(k_mf_train_small, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st, *M, *G, X, Y, N, rank, prediction,
+                       loss);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   const int64_t nchunks = (units + per - 1) / per;
   const size_t smem = (size_t)2 * MF_CH * M->D * 4 + MF_CH * (4 + 4 + 8 + 8 + 8 + 4 + 4 + 4 + 4 + 4);
   const int grid = (int)min((int64_t)2048, nchunks);
