@@ -50,6 +50,8 @@ def parse():
                                                              'touches on a side stream while the gradient exchange is in flight')
     p.add_argument('--force_replicated', type=int, default=0, help='run the replicated data-parallel pipeline even at --gpus 1')
     p.add_argument('--force_sharded', type=int, default=0, help='run the row-sharded pipeline even at --gpus 1')
+    p.add_argument('--prep_next', type=int, default=1, help='1: each step hands the library the next batch, whose candidates '
+                   'are then drawn inside this step\'s optimizer launch (as the runner does); 0: k_prep every step')
     p.add_argument('--overlap', type=int, default=0, help='1: dccf_train_step with the untouched-row optimizer pass on a side '
                                                           'stream (see DESIGN.md: +5 %% only with DCCF_SIDE_CUS=128 --stream 1)')
     p.add_argument('--stream', type=int, default=0, help='1: run on a created stream instead of the default (null) stream')
@@ -165,7 +167,7 @@ def main():
         if events is None:      # one library call per step (dccf_train_step)
             for k in range(k0, k1):
                 batch['X'] = full[k]
-                model.train_step(batch, overlap=args.overlap)
+                model.train_step(batch, overlap=args.overlap, X_next=full[k + 1] if args.prep_next and k + 1 < k1 else None)
             return
         for k in range(k0, k1):
             batch['X'] = full[k]

@@ -17,7 +17,7 @@ EXPORTS = ['dccf_ctx_create', 'dccf_ctx_destroy', 'dccf_ctx_reserve', 'dccf_last
            'shard_pack_rows', 'shard_unpack_rows', 'shard_scatter_add', 'dccf_dense_opt_step_rows', 'dccf_dense_opt_step_dev', 'dccf_advance', 'rank_eval_topk', 'dccf_train_step', 'dp_buffer_words',
            'dp_export_touched', 'dp_import_touched', 'dp_mark_global', 'dccf_dense_opt_phase', 'dccf_ctx_side_stream', 'dp_import_apply',
            'dccf_sample_eval_negatives', 'dccf_eval_prepare', 'dccf_predict_projected', 'dccf_dp_local', 'dccf_dp_overlap',
-           'dccf_dp_finish']
+           'dccf_dp_finish', 'dccf_ctx_prepared_steps']
 
 OPT_KIND = {'gd': 0, 'adagrad': 1, 'adam': 2}
 MF_KIND = {'RecModel': 0, 'BiasedMF': 1, 'IPSBiasedMF': 2}
@@ -111,13 +111,14 @@ def load():
         'dp_export_touched': [vp, i64, i32, vp, vp, vp, vp, i64, vp, vp, i64, i32, i32, vp],
         'dp_import_touched': [vp, i32, vp, i64, i32, vp, vp, vp, vp, i64, vp, i64, i32, vp, vp, vp, vp],
         'dccf_train_step': [vp, C.POINTER(ModelT), C.POINTER(RandT), vp, vp, i64, i32, f32, C.POINTER(GradsT),
-                            C.POINTER(OptT), vp, vp, vp],
+                            C.POINTER(OptT), vp, vp, vp, u64, vp],
         'rank_eval_topk': [vp, vp, vp, vp, i64, C.POINTER(i32), vp, i32, vp, vp],
         'dccf_sumsq': [vp, i64, vp, vp],
         'mf_predict': [C.POINTER(MFModelT), vp, i64, vp, vp],
         'mf_train_fwdbwd': [vp, C.POINTER(MFModelT), vp, vp, i64, i32, C.POINTER(MFGradsT), vp, vp, vp],
         'mf_predict_full': [C.POINTER(MFModelT), vp, vp],
         'dccf_sample_train_negatives': [vp, vp, vp, vp, i64, i64, u64, u64, vp, vp],
+        'dccf_ctx_prepared_steps': [vp, C.POINTER(C.c_int64)],
         'dccf_debug_candidates': [i64, i32, i64, u64, u64, vp, vp],
         'dccf_debug_noise': [i64, i32, f32, u64, u64, vp, vp],
         'dccf_debug_keep': [i64, i32, f32, u64, u64, vp, vp],
@@ -165,6 +166,12 @@ class Context(object):
 
     def reserve(self, max_rows, D, F, S, A):
         check(load().dccf_ctx_reserve(self.h, int(max_rows), int(D), int(F), int(S), int(A)))
+
+    def prepared_steps(self):
+        """How many train steps started from a step the previous call prepared (dccf_ctx_prepared_steps)."""
+        n = C.c_int64()
+        check(load().dccf_ctx_prepared_steps(self.h, C.byref(n)))
+        return n.value
 
     def side_stream(self):
         """The context's low-priority (or CU-masked, DCCF_SIDE_CUS) stream as a torch stream."""
@@ -268,9 +275,13 @@ def opt_struct(kind, p, g, s1, s2, lr, wd, l2, clip, segments, overlap):
 
 
 def dccf_train_step(ctx, m, r, X, Y, rank, dropout, gU, gV, gW, gb, opt, step, pred=None, loss=None, touchedU=None,
-                    touchedV=None):
-    """forward + loss + backward + regularised optimizer step (dccf_train_step): BaseRunner.py:172-188 in one call."""
+                    touchedV=None, X_next=None, step_next=0):
+    """forward + loss + backward + regularised optimizer step (dccf_train_step): BaseRunner.py:172-188 in one call.
+    X_next (same shape as X) = the next call's batch, whose Philox step will be step_next: prepared inside this call's
+    optimizer launch."""
     N = X.shape[0]
+    if X_next is not None and tuple(X_next.shape) != tuple(X.shape):
+        X_next = None
     if pred is None:
         pred = torch.empty(N, dtype=torch.float32, device=X.device)
     if loss is None:
@@ -278,7 +289,8 @@ def dccf_train_step(ctx, m, r, X, Y, rank, dropout, gU, gV, gW, gb, opt, step, p
     g = GradsT(ptr(gU), ptr(gV), ptr(gW), ptr(gb), ptr(touchedU, torch.uint8), ptr(touchedV, torch.uint8))
     opt.step = int(step)
     check(load().dccf_train_step(ctx.h, C.byref(m), C.byref(r), ptr(X, torch.int64), ptr(Y), N, int(rank), float(dropout),
-                                 C.byref(g), C.byref(opt), ptr(pred), ptr(loss), stream()))
+                                 C.byref(g), C.byref(opt), ptr(pred), ptr(loss), ptr(X_next, torch.int64), int(step_next),
+                                 stream()))
     return pred, loss
 
 

@@ -45,6 +45,14 @@ struct dccf_ctx {
   // events, and the de-duplicated list of the rows this step touches (built by k_prep, consumed by k_opt_touched)
   hipStream_t side;
   hipEvent_t ev_fork, ev_join;
+  // what the last dccf_train_step prepared for the next one (candidates, exposures, W^T, zeroed accumulators)
+  int prep_valid;
+  int64_t prep_hits;
+  const void* prep_X;
+  const void* prep_U;
+  const void* prep_W;
+  int64_t prep_N;
+  uint64_t prep_step, prep_seed;
   int64_t* tl_list;
   int64_t tl_cap;
   int* tl_cnt;      // [2]: counters of the current / next step (double-buffered so no launch is spent on the reset)
@@ -80,6 +88,8 @@ struct dccf_opt_args;      // == dccf_opt_t of include/dccf_hip.h
 #define OPT_PHASE_TOUCHED 2
 // opt_kernels.hip: one phase of the dense regularised optimizer step described by `o` (dccf_opt_t)
 int dccf_opt_phase(const void* o, int phase, const int64_t* list, const int* cnt, int64_t max_rows, hipStream_t st);
+struct PrepNext;
+int dccf_opt_all_prep(const void* o, const PrepNext* pn, hipStream_t st);
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -199,3 +209,65 @@ __device__ __forceinline__ void mark_row(uint32_t* flags, int64_t row, int64_t t
   if (first) mp.list[base + __popcll(b & ((1ull << lane) - 1))] = tag | row;
 }
 
+// ---------------------------------------------------------------------------------------------- per-step preparation
+// Expo[u, i] (models/DCCF.py:98), dense or recomputed from the IPSBiasedMF factors that produced it (IPSBiasedMF.py:32-40)
+__device__ __forceinline__ float expo_at(const dccf_model_t& M, int64_t u, int64_t i) {
+  if (M.expo) return M.expo[u * M.item_num + i];
+  float acc = 0.f;
+  for (int k = 0; k < M.ipsD; ++k) acc = fmaf(M.ipsP[u * M.ipsD + k], M.ipsQ[i * M.ipsD + k], acc);
+  acc = acc + M.ipsBu[u] + M.ipsBi[i] + M.ipsB0;
+  return acc / fmaxf(M.ipsProp[i], M.ipsM);
+}
+
+
+// Slot j = (n, s) of a batch: cand[n][0] = the true item, cand[n][s] = injected or Philox candidate (models/DCCF.py:72-74),
+// eg[n][s] = Expo[u(n), cand[n][s]].  Returns the item.
+__device__ __forceinline__ int64_t prep_cand(const dccf_model_t& M, const int64_t* X, const int64_t* sample_item, int* cand,
+                                             float* eg, int64_t j, int S, int64_t item_num, int fused, const rng_key& key) {
+  const int64_t n = j / (S + 1);
+  const int s = (int)(j % (S + 1));
+  int64_t it;
+  if (s == 0) {
+    it = X[2 * n + 1];
+  } else if (!fused) {
+    it = sample_item[n * S + (s - 1)];
+  } else {
+    const u32x4 r = philox4x32_10((uint32_t)n, (uint32_t)((s - 1) >> 2), key.s0, key.s1, key.k0, key.k1);
+    it = (int64_t)(((uint64_t)pick4(r, (s - 1) & 3) * (uint64_t)item_num) >> 32);
+  }
+  cand[j] = (int)it;
+  eg[j] = expo_at(M, X[2 * n], it);
+  return it;
+}
+
+// What the optimizer launch of step t prepares for step t + 1 (dccf_train_step with X_next): the candidate / exposure
+// slots, the zeroed accumulators, and — while it writes the new W anyway — the transposed copy W^T the forward reads.
+// The next step then starts with its forward kernel; k_prep runs only when nothing (or something else) was prepared.
+struct PrepNext {
+  dccf_model_t M;
+  float* WT;
+  int* cand;
+  float* eg;
+  float* m;
+  const int64_t* X;
+  int64_t N, Lm, w_begin, w_end;     // [w_begin, w_end): elements of W inside the flat parameter buffer
+  int S, DP, blocks;
+  rng_key key;
+};
+
+__device__ __forceinline__ void prep_next_slots(const PrepNext& pn, int64_t tid, int64_t nthreads) {
+  const int64_t NS = pn.N * (pn.S + 1);
+  const int64_t total = NS + pn.Lm;
+  for (int64_t i = tid; i < total; i += nthreads) {
+    if (i < NS) prep_cand(pn.M, pn.X, nullptr, pn.cand, pn.eg, i, pn.S, pn.M.item_num, 1, pn.key);
+    else pn.m[i - NS] = 0.f;
+  }
+}
+
+// element e of the flat parameter buffer lies in W = [D][D+F]: mirror its new value into W^T [k][DP]
+__device__ __forceinline__ void prep_next_wt(const PrepNext& pn, int64_t e, float v) {
+  const int64_t idx = e - pn.w_begin;
+  const int KF = pn.M.D + pn.M.F;
+  const int d = (int)(idx / KF), k = (int)(idx % KF);
+  pn.WT[(int64_t)k * pn.DP + d] = v;
+}

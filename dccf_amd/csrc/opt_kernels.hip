@@ -36,6 +36,8 @@ extern "C" int dccf_ctx_create(dccf_ctx** out, int device) {
   c->tl_cap = 0;
   c->tl_cnt = nullptr;
   c->tl_parity = 0;
+  c->prep_valid = 0;
+  c->prep_hits = 0;
   *out = c;
   return 0;
 }
@@ -118,6 +120,12 @@ int dccf_step_ensure(dccf_ctx* ctx, int64_t max_rows) {
   return 0;
 }
 
+extern "C" int dccf_ctx_prepared_steps(const dccf_ctx* ctx, int64_t* out) {
+  ARG_CHECK(ctx && out, "NULL argument");
+  *out = ctx->prep_hits;
+  return 0;
+}
+
 extern "C" int dccf_ctx_side_stream(dccf_ctx* ctx, void** out) {
   ARG_CHECK(ctx && out, "NULL argument");
   if (int e = dccf_step_ensure(ctx, 0)) return e;
@@ -129,6 +137,7 @@ int dccf_ws_ensure(dccf_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->ws_bytes) return 0;
   // grow-only; growing synchronises the device (earlier launches may still use the old slab)
   HIP_TRY(hipDeviceSynchronize());
+  ctx->prep_valid = 0;                       // the prepared slots lived in the old slab
   if (ctx->ws) HIP_TRY(hipFree(ctx->ws));
   ctx->ws = nullptr;
   ctx->ws_bytes = 0;
@@ -219,10 +228,15 @@ __device__ __forceinline__ void touched_rows(float* __restrict__ p, float* __res
 template <int KIND, int UN>
 __global__ __launch_bounds__(256) void k_dense_opt_rows(float* __restrict__ p, float* __restrict__ g, float* __restrict__ s1,
                                                         float* __restrict__ s2, int64_t n, OptArgs a, RowSegs sg,
-                                                        int phase) {
+                                                        int phase, PrepNext pn) {
   opt_resolve(a);
+  const int nblk = (int)gridDim.x - pn.blocks;
+  if ((int)blockIdx.x >= nblk) {             // next step's candidate / exposure slots (independent of this pass)
+    prep_next_slots(pn, (int64_t)(blockIdx.x - nblk) * blockDim.x + threadIdx.x, (int64_t)pn.blocks * blockDim.x);
+    return;
+  }
   const int64_t n4 = n / 4;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t stride = (int64_t)nblk * blockDim.x;
   // row widths are powers of two (16..128): shifts instead of 64-bit divisions
   int wsh[4];
 #pragma unroll
@@ -267,6 +281,12 @@ __global__ __launch_bounds__(256) void k_dense_opt_rows(float* __restrict__ p, f
       opt_elem<KIND>(pv[u].z, gv[u].z, av[u].z, bv[u].z, a);
       opt_elem<KIND>(pv[u].w, gv[u].w, av[u].w, bv[u].w, a);
       reinterpret_cast<float4*>(p)[i] = pv[u];
+      if (pn.blocks && i * 4 >= pn.w_begin && i * 4 < pn.w_end) {      // the forward's transposed copy of W, for the next step
+        prep_next_wt(pn, i * 4, pv[u].x);
+        prep_next_wt(pn, i * 4 + 1, pv[u].y);
+        prep_next_wt(pn, i * 4 + 2, pv[u].z);
+        prep_next_wt(pn, i * 4 + 3, pv[u].w);
+      }
       if (touched[u]) reinterpret_cast<float4*>(g)[i] = make_float4(0, 0, 0, 0);
       if (KIND != DCCF_OPT_GD) reinterpret_cast<float4*>(s1)[i] = av[u];
       if (KIND == DCCF_OPT_ADAM) reinterpret_cast<float4*>(s2)[i] = bv[u];
@@ -371,7 +391,8 @@ static int dense_complement(const RowSegs& sg, int64_t n, DenseSegs* ds, int64_t
   else if (kind == DCCF_OPT_ADAGRAD) hipLaunchKernelGGL(K<DCCF_OPT_ADAGRAD>, __VA_ARGS__);  \
   else hipLaunchKernelGGL(K<DCCF_OPT_ADAM>, __VA_ARGS__)
 
-static int launch_job(const OptJob& j, int phase, const int64_t* list, const int* cnt, int64_t max_rows, hipStream_t st) {
+static int launch_job(const OptJob& j, int phase, const int64_t* list, const int* cnt, int64_t max_rows, hipStream_t st,
+                      const PrepNext* pnp = nullptr) {
   if (j.n == 0) return 0;
   if (phase == OPT_PHASE_TOUCHED) {
     ARG_CHECK(list && cnt, "touched phase needs the row list");
@@ -389,15 +410,18 @@ static int launch_job(const OptJob& j, int phase, const int64_t* list, const int
   const int64_t work = (j.n + 3) / 4;
   // one float4 slot per thread at Electronics size (16384 workgroups): 61.5 -> 59.3 us against 4096 grid-striding workgroups
   const int64_t gmax = getenv("DCCF_OPT_GRID") ? atoll(getenv("DCCF_OPT_GRID")) : 16384;
-  const int grid = (int)min(gmax, (work + 255) / 256);
+  PrepNext pn;
+  memset(&pn, 0, sizeof(pn));
+  if (pnp) pn = *pnp;
+  const int grid = (int)min(gmax, (work + 255) / 256) + pn.blocks;
   if (j.n >= 100000000LL) {
-    if (j.kind == DCCF_OPT_GD) hipLaunchKernelGGL((k_dense_opt_rows<DCCF_OPT_GD, 2>), dim3(grid), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.n, j.a, j.sg, phase);
-    else if (j.kind == DCCF_OPT_ADAGRAD) hipLaunchKernelGGL((k_dense_opt_rows<DCCF_OPT_ADAGRAD, 2>), dim3(grid), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.n, j.a, j.sg, phase);
-    else hipLaunchKernelGGL((k_dense_opt_rows<DCCF_OPT_ADAM, 2>), dim3(grid), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.n, j.a, j.sg, phase);
+    if (j.kind == DCCF_OPT_GD) hipLaunchKernelGGL((k_dense_opt_rows<DCCF_OPT_GD, 2>), dim3(grid), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.n, j.a, j.sg, phase, pn);
+    else if (j.kind == DCCF_OPT_ADAGRAD) hipLaunchKernelGGL((k_dense_opt_rows<DCCF_OPT_ADAGRAD, 2>), dim3(grid), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.n, j.a, j.sg, phase, pn);
+    else hipLaunchKernelGGL((k_dense_opt_rows<DCCF_OPT_ADAM, 2>), dim3(grid), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.n, j.a, j.sg, phase, pn);
   } else {
-    if (j.kind == DCCF_OPT_GD) hipLaunchKernelGGL((k_dense_opt_rows<DCCF_OPT_GD, 1>), dim3(grid), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.n, j.a, j.sg, phase);
-    else if (j.kind == DCCF_OPT_ADAGRAD) hipLaunchKernelGGL((k_dense_opt_rows<DCCF_OPT_ADAGRAD, 1>), dim3(grid), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.n, j.a, j.sg, phase);
-    else hipLaunchKernelGGL((k_dense_opt_rows<DCCF_OPT_ADAM, 1>), dim3(grid), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.n, j.a, j.sg, phase);
+    if (j.kind == DCCF_OPT_GD) hipLaunchKernelGGL((k_dense_opt_rows<DCCF_OPT_GD, 1>), dim3(grid), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.n, j.a, j.sg, phase, pn);
+    else if (j.kind == DCCF_OPT_ADAGRAD) hipLaunchKernelGGL((k_dense_opt_rows<DCCF_OPT_ADAGRAD, 1>), dim3(grid), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.n, j.a, j.sg, phase, pn);
+    else hipLaunchKernelGGL((k_dense_opt_rows<DCCF_OPT_ADAM, 1>), dim3(grid), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.n, j.a, j.sg, phase, pn);
   }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -423,6 +447,14 @@ int dccf_opt_phase(const void* ov, int phase, const int64_t* list, const int* cn
   OptJob j;
   if (int e = opt_job(ov, &j)) return e;
   return launch_job(j, phase, list, cnt, max_rows, st);
+}
+
+// The whole pass + the next step's preparation in the same launch (dccf_train_step with X_next).
+int dccf_opt_all_prep(const void* ov, const PrepNext* pn, hipStream_t st) {
+  OptJob j;
+  if (int e = opt_job(ov, &j)) return e;
+  ARG_CHECK(pn->w_begin % 4 == 0 && pn->w_end % 4 == 0 && pn->w_end <= j.n, "W must be 16-byte aligned inside the flat buffer");
+  return launch_job(j, OPT_PHASE_ALL, nullptr, nullptr, 0, st, pn);
 }
 
 extern "C" int dccf_dense_opt_step_rows(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t n, float lr,

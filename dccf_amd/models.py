@@ -431,11 +431,12 @@ class DCCF(DMF):
                                             g['mlp.0.bias'], loss=self._loss, touchedU=self.touchedU, touchedV=self.touchedV)
         return {'prediction': pred, 'check': [('prediction', pred)], 'loss': loss[0]}
 
-    def train_step(self, feed_dict, overlap=0):
+    def train_step(self, feed_dict, overlap=0, X_next=None):
         """zero_grad + forward + backward + `+ l2` + clip + optimizer.step() of src/runners/BaseRunner.py:172-188 as ONE
         library call (dccf_train_step).  ``overlap``: 0 = optimizer pass after the backward; 1 = the pass over the
         embedding rows this batch does not touch runs on a side stream beside forward/backward.  Same arithmetic per
-        element either way."""
+        element either way.  ``X_next``: the batch the NEXT train_step will be given (the same tensor, not a copy) — its
+        candidates are then drawn inside this step's optimizer launch; results are identical with or without it."""
         o = self.optimizer
         key = (o.name, o.lr, o.l2, o.clip, int(overlap))
         if getattr(self, '_opt_struct_key', None) != key:
@@ -444,11 +445,14 @@ class DCCF(DMF):
             self._opt_struct_key = key
         g = self.grads
         o.t += 1
-        pred, loss = _lib.dccf_train_step(self.ctx, self._struct(), self._rand(feed_dict), feed_dict['X'].contiguous(),
+        rs = self._rand(feed_dict)
+        if X_next is not None and (overlap or feed_dict.get('inject') is not None or not X_next.is_contiguous()):
+            X_next = None
+        pred, loss = _lib.dccf_train_step(self.ctx, self._struct(), rs, feed_dict['X'].contiguous(),
                                           feed_dict['Y'], feed_dict['rank'], feed_dict['dropout'],
                                           g['uid_embeddings.weight'], g['iid_embeddings.weight'], g['mlp.0.weight'],
                                           g['mlp.0.bias'], self._opt_struct, o.t, loss=self._loss, touchedU=self.touchedU,
-                                          touchedV=self.touchedV)
+                                          touchedV=self.touchedV, X_next=X_next, step_next=self._call + 1)
         return {'prediction': pred, 'check': [('prediction', pred)], 'loss': loss[0]}
 
 

@@ -125,9 +125,11 @@ class BaseRunner(object):
                 return out
             y = torch.cat([torch.ones(B, device=full.device), torch.zeros(B, device=full.device)])
             batch = {'Y': y, 'rank': 1, 'train': True, 'dropout': self.dropout, utils.REAL_BATCH_SIZE: B}
-            for k in range(full.shape[0]):
+            nb = full.shape[0]
+            for k in range(nb):
                 batch['X'] = full[k]
-                out = self._step(model, batch)
+                # the next batch is known: its candidates are drawn inside this step's optimizer launch
+                out = self._step(model, batch, X_next=full[k + 1] if k + 1 < nb else None)
             if tail is not None:
                 r = tail.shape[0] // 2
                 batch = {'X': tail, 'Y': torch.cat([y[:r], y[B:B + r]]), 'rank': 1, 'train': True, 'dropout': self.dropout,
@@ -140,10 +142,10 @@ class BaseRunner(object):
         model.eval()
         return out
 
-    def _step(self, model, batch):
+    def _step(self, model, batch, X_next=None):
         """The body of the reference's batch loop (src/runners/BaseRunner.py:172-188)."""
         if hasattr(model, 'train_step'):
-            return model.train_step(batch, overlap=self.overlap_opt)    # one library call per step
+            return model.train_step(batch, overlap=self.overlap_opt, X_next=X_next)    # one library call per step
         model.optimizer.zero_grad()
         out = model(batch)
         model.optimizer.step()        # + l2 term, clip_grad_value_(50), update: one dense kernel

@@ -149,7 +149,12 @@ int dccf_dense_opt_phase(int32_t kind, float* p, float* g, float* s1, float* s2,
  * thousand of the U/V rows: their gradient is the l2 term alone, independent of the batch) runs on the context's
  * low-priority side stream WHILE forward/backward run on `stream`; the touched rows + W, b follow after the backward.
  * Needs grads->touchedU / touchedV == the flags of the segments that hold model->U / model->V, 4-byte aligned and padded
- * to a multiple of 4 bytes. */
+ * to a multiple of 4 bytes.
+ * X_next (optional, overlap == 0): the NEXT call's batch — same N, fused draws (rnd.mode 1) with Philox step `step_next`.
+ * The optimizer launch then also prepares that step (candidates, gathered exposures, zeroed accumulators, and the
+ * transposed copy of W written while W is updated), so the next call starts with its forward kernel instead of k_prep.
+ * The context remembers (pointer, N, step, seed, tables); a call that does not match runs k_prep as usual, and any other
+ * call on the context (predict, a different batch) discards what was prepared. */
 typedef struct {
   int32_t kind;              /* DCCF_OPT_*                                                          */
   int32_t overlap;
@@ -171,9 +176,12 @@ typedef struct {
  * DCCF_SIDE_CUS=n is set at its creation (the mask interleaves over the 8 XCDs).  For callers that run
  * dccf_dense_opt_phase(1) beside other work themselves (dccf_amd/replicated.py). */
 int dccf_ctx_side_stream(dccf_ctx* ctx, void** out);
+/* Diagnostics: *out = how many dccf_train_step calls on this context started from a step prepared by the previous call
+ * (X_next matched) instead of launching k_prep. */
+int dccf_ctx_prepared_steps(const dccf_ctx* ctx, int64_t* out);
 int dccf_train_step(dccf_ctx* ctx, const dccf_model_t* model, const dccf_rand_t* rnd, const int64_t* X, const float* Y,
                     int64_t N, int32_t rank, float dropout, const dccf_grads_t* grads, const dccf_opt_t* opt,
-                    float* prediction, float* loss, void* stream);
+                    float* prediction, float* loss, const int64_t* X_next, uint64_t step_next, void* stream);
 
 /* Graph-replayable form of the two calls above: the 1-based step is step + *k_dev (bias corrections computed on the
  * device); dccf_advance adds 1 to *k_dev (last node of a captured step). */

@@ -532,8 +532,9 @@ def test_large_batch_forward_equals_small_batches(L, ctx):
     assert torch.equal(big_inj, torch.cat(parts))                     # same kernel, same per-row arithmetic: bit-identical
 
 
-@pytest.mark.parametrize('opt_name,B,l2', [('gd', 128, 0.05), ('gd', 600, 0.05), ('adam', 128, 1e-4), ('adagrad', 37, 1e-4)])
-def test_overlapped_train_step_equals_split_step(L, opt_name, B, l2):
+@pytest.mark.parametrize('opt_name,B,l2,D', [('gd', 128, 0.05, 64), ('gd', 600, 0.05, 64), ('adam', 128, 1e-4, 64),
+                                             ('adagrad', 37, 1e-4, 64), ('gd', 64, 0.05, 128), ('gd', 50, 0.05, 16)])
+def test_overlapped_train_step_equals_split_step(L, opt_name, B, l2, D):
     """dccf_train_step with the untouched-row optimizer pass on the side stream == forward/backward followed by the
     row-aware dense step over several steps (duplicate users/items inside a batch included).  Same arithmetic per
     element; the only run-to-run difference is the order of the float atomics inside the backward.  So: rows no batch
@@ -542,12 +543,15 @@ def test_overlapped_train_step_equals_split_step(L, opt_name, B, l2):
     vanishing exposure weight) flips sign(g) and moves a whole row by a fraction of lr — in ANY two runs of the same
     code path, measured — so there the bulk must agree and at most a few rows may sit within lr * steps."""
     from dccf_amd.models import DCCF, FusedOptimizer
-    U, I, D, F = 3001, 1999, 64, 96        # not multiples of 4: the word-wise marking must respect the array ends
+    U, I, F = 3001, 1999, 96               # not multiples of 4: the word-wise marking must respect the array ends
     g = torch.Generator(device='cuda').manual_seed(5)
     feat = torch.randn(I, F, generator=g, device='cuda') * 0.05
     expo = torch.randn(U, I, generator=g, device='cuda')
     states = []
-    for mode in ('split', 'step', 'overlap'):
+    gen = torch.Generator(device='cuda').manual_seed(9)
+    full = torch.stack([torch.stack([torch.randint(0, U // 2 if k % 2 else 40, (2 * B,), generator=gen, device='cuda'),
+                                     torch.randint(0, I, (2 * B,), generator=gen, device='cuda')], 1) for k in range(6)])
+    for mode in ('split', 'step', 'overlap', 'prep'):
         m = DCCF(path=None, dataset=None, sentence_model=None, sample_num=10, attribute_num=2, std=0.1, label_min=0, label_max=1,
                  feature_num=0, user_num=U, item_num=I, u_vector_size=D, i_vector_size=D, n_layers=1, random_seed=11,
                  model_path='/tmp/x.pt', feature_embedding=feat, expo_prob=expo)
@@ -555,22 +559,23 @@ def test_overlapped_train_step_equals_split_step(L, opt_name, B, l2):
         m.apply(m.init_paras)
         m.optimizer = FusedOptimizer(m, opt_name, 0.01, l2)
         m.train()
-        gen = torch.Generator(device='cuda').manual_seed(9)
         y = torch.cat([torch.ones(B, device='cuda'), torch.zeros(B, device='cuda')])
         preds = []
         seen = torch.zeros(U, dtype=torch.bool, device='cuda')
         for k in range(6):
-            X = torch.stack([torch.randint(0, U // 2 if k % 2 else 40, (2 * B,), generator=gen, device='cuda'),
-                             torch.randint(0, I, (2 * B,), generator=gen, device='cuda')], 1)
+            X = full[k]
             seen[X[:, 0]] = True
             batch = {'X': X, 'Y': y, 'rank': 1, 'train': True, 'dropout': 0.2}
             if mode == 'split':
                 out = m(batch)
                 m.optimizer.step()
+            elif mode == 'prep':      # the optimizer launch of step k draws step k + 1's candidates and writes W^T
+                out = m.train_step(batch, X_next=full[k + 1] if k < 5 else None)
             else:
                 out = m.train_step(batch, overlap={'step': 0, 'overlap': 1}[mode])
             preds.append(out['prediction'].clone())
         torch.cuda.synchronize()
+        assert m.ctx.prepared_steps() == (5 if mode == 'prep' else 0)
         assert int(m.touchedU.sum()) == 0 and int(m.touchedV.sum()) == 0
         assert float(m.flat_g.abs().max()) == 0.0
         states.append([m.flat_p.clone(), m.optimizer.s1, m.optimizer.s2, seen] + preds)
@@ -586,6 +591,50 @@ def test_overlapped_train_step_equals_split_step(L, opt_name, B, l2):
                     d = (a - b).abs()
                     assert int((d > 6 * STEP_FRAC * 0.01).sum()) <= 4 * D + 8 and float(d.max()) <= 6 * 0.01
         close(other[4], states[0][4].cpu().numpy(), 1e-6, 1e-7, 'first prediction')
+        if opt_name == 'gd':      # same candidates, noise and W^T at every later step too
+            for a, b in zip(states[0][5:], other[5:]):
+                close(b, a.cpu().numpy(), 1e-4, 1e-5, 'later predictions')
+
+
+def test_prepared_next_step_state_is_what_k_prep_writes(L, ctx):
+    """dccf_train_step(X_next): after the call the workspace holds exactly what k_prep would write at the start of the
+    next step — cand = [item ; Philox draws of step_next], the gathered exposures, and the transposed copy of
+    the UPDATED W (padding intact) — bit for bit; the next call then skips k_prep and a call with another batch does not."""
+    from dccf_amd.models import DCCF, FusedOptimizer
+    U, I, D, F, S, A, B = 500, 700, 64, 200, 10, 2, 96
+    g = torch.Generator(device='cuda').manual_seed(2)
+    feat = torch.randn(I, F, generator=g, device='cuda') * 0.05
+    expo = torch.randn(U, I, generator=g, device='cuda')
+    m = DCCF(path=None, dataset=None, sentence_model=None, sample_num=S, attribute_num=A, std=0.1, label_min=0, label_max=1,
+             feature_num=0, user_num=U, item_num=I, u_vector_size=D, i_vector_size=D, n_layers=1, random_seed=21,
+             model_path='/tmp/x.pt', feature_embedding=feat, expo_prob=expo)
+    torch.manual_seed(1)
+    m.apply(m.init_paras)
+    m.optimizer = FusedOptimizer(m, 'adam', 0.01, 1e-4)
+    m.train()
+    full = torch.stack([torch.stack([torch.randint(0, U, (2 * B,), generator=g, device='cuda'),
+                                     torch.randint(0, I, (2 * B,), generator=g, device='cuda')], 1) for _ in range(3)])
+    y = torch.cat([torch.ones(B, device='cuda'), torch.zeros(B, device='cuda')])
+    batch = {'X': full[0], 'Y': y, 'rank': 1, 'train': True, 'dropout': 0.2}
+    m.train_step(batch, X_next=full[1])
+    step_next = m._call + 1
+    N = 2 * B
+    cand, _, _ = L.debug_workspace(m.ctx, N, D, F, S, A, 0, 'cuda')
+    WT, DP, FP = L.debug_workspace(m.ctx, N, D, F, S, A, 1, 'cuda')
+    eg, _, _ = L.debug_workspace(m.ctx, N, D, F, S, A, 5, 'cuda')
+    want = torch.cat([full[1][:, 1:2], L.debug_candidates(N, S, I, 21, step_next, 'cuda')], 1)
+    assert torch.equal(cand.view(N, S + 1).long(), want)
+    assert torch.equal(eg.view(N, S + 1), expo[full[1][:, 0:1].expand(N, S + 1), want])
+    W = dict(m.named_parameters())['mlp.0.weight'].detach()
+    ref = torch.zeros(D + FP, DP, device='cuda')
+    ref[:D + F, :D] = W.t()
+    assert torch.equal(WT.view(D + FP, DP), ref)
+    batch['X'] = full[1]
+    m.train_step(batch, X_next=full[2])
+    assert m.ctx.prepared_steps() == 1
+    batch['X'] = full[0]                      # not the batch that was announced: k_prep runs
+    m.train_step(batch)
+    assert m.ctx.prepared_steps() == 1
 
 
 @pytest.mark.parametrize('D', [64, 24])
