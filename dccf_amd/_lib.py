@@ -52,8 +52,14 @@ class OptT(C.Structure):
 class DpT(C.Structure):
     _fields_ = [('G', C.c_int32), ('rank', C.c_int32), ('D', C.c_int32), ('S', C.c_int32), ('cap', C.c_int64),
                 ('dense_begin', C.c_int64), ('item_num', C.c_int64), ('seed', C.c_uint64), ('buf', _f), ('bufs', _f),
-                ('loss', _f), ('loss_sum', _f), ('gflagsU', _f), ('gflagsV', _f), ('segU', C.c_int32), ('segV', C.c_int32),
+                ('loss', _f), ('loss_sum', _f), ('gflagsU', _f), ('gflagsV', _f), ('gflagsU2', _f), ('gflagsV2', _f),
+                ('lflagsU', _f), ('lflagsV', _f), ('llist', _f), ('lcnt', _f), ('segU', C.c_int32), ('segV', C.c_int32),
                 ('glist', _f), ('gcnt', _f), ('mask', _f), ('where', _f)]
+
+
+class DpNextT(C.Structure):
+    _fields_ = [('ctx', _f), ('model', C.POINTER(ModelT)), ('X_next', _f), ('X_all_next', _f), ('N', C.c_int64),
+                ('step0_next', C.c_uint64)]
 
 
 class MFModelT(C.Structure):
@@ -97,8 +103,8 @@ def load():
         'dccf_advance': [vp, vp],
         'dccf_dp_local': [vp, C.POINTER(ModelT), C.POINTER(RandT), vp, vp, i64, f32, C.POINTER(GradsT), C.POINTER(OptT),
                           C.POINTER(DpT), vp, u64, i32, vp, vp],
-        'dccf_dp_overlap': [C.POINTER(OptT), C.POINTER(DpT), vp],
-        'dccf_dp_finish': [C.POINTER(OptT), C.POINTER(DpT), i32, vp],
+        'dccf_dp_overlap': [C.POINTER(OptT), C.POINTER(DpT), i32, C.POINTER(DpNextT), vp],
+        'dccf_dp_finish': [C.POINTER(OptT), C.POINTER(DpT), i32, i32, C.POINTER(DpNextT), vp],
         'dccf_eval_prepare': [vp, C.POINTER(ModelT), vp, vp, vp],
         'dccf_predict_projected': [vp, C.POINTER(ModelT), C.POINTER(RandT), vp, i64, f32, vp, vp, vp, vp],
         'dccf_sample_eval_negatives': [vp, i64, vp, vp, i64, i32, u64, u64, vp, vp],

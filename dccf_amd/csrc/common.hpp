@@ -51,6 +51,9 @@ struct dccf_ctx {
   const void* prep_X;
   const void* prep_U;
   const void* prep_W;
+  // replicated path: the dp part of the prepared step (global marks in set prep_parity, local list) and its schedule
+  int prep_dp, prep_pending, prep_parity;
+  const void* prep_Xall;
   int64_t prep_N;
   uint64_t prep_step, prep_seed;
   int64_t* tl_list;
@@ -90,6 +93,14 @@ struct dccf_opt_args;      // == dccf_opt_t of include/dccf_hip.h
 int dccf_opt_phase(const void* o, int phase, const int64_t* list, const int* cnt, int64_t max_rows, hipStream_t st);
 struct PrepNext;
 int dccf_opt_all_prep(const void* o, const PrepNext* pn, hipStream_t st);
+// phase 1 (rows whose byte in `flags` is 0) + the next step's slots / marks in the same launch (dccf_dp_overlap)
+int dccf_opt_untouched_prep(const void* o, uint8_t* const* flags, const PrepNext* pn, hipStream_t st);
+// dccf_kernels.hip: workspace pointers / key of the step (X_next, N, step_next) into pn (w_begin / w_end / blocks and the
+// dp fields are the caller's); and the record that makes the next matching call skip k_prep
+int dccf_prep_next_fill(dccf_ctx* ctx, const dccf_model_t* M, int64_t N, const int64_t* X_next, uint64_t seed, uint64_t step_next,
+                        PrepNext* pn);
+void dccf_prep_next_commit(dccf_ctx* ctx, const dccf_model_t* M, int64_t N, const void* X_next, uint64_t seed, uint64_t step_next);
+bool dccf_prep_matches(const dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd, const void* X, int64_t N);
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -253,14 +264,46 @@ struct PrepNext {
   int64_t N, Lm, w_begin, w_end;     // [w_begin, w_end): elements of W inside the flat parameter buffer
   int S, DP, blocks;
   rng_key key;
+  // replicated data-parallel path (dp_kernels.hip) only:
+  MarkPlan lm;               // list != NULL: this rank's rows of the next step as a de-duplicated list (-> k_dp_export_list)
+  const int64_t* X_all;      // != NULL: the replicated schedule [G][N][2] of the next step; every rank's rows get a byte
+  uint8_t* gU;               //          in gU / gV ("touched by ANY rank": the rows phase 1 of the next step skips)
+  uint8_t* gV;
+  int G;
+  rng_key gkey0;             // STREAM_CAND key of rank 0's next step; rank r draws with key + r
 };
 
 __device__ __forceinline__ void prep_next_slots(const PrepNext& pn, int64_t tid, int64_t nthreads) {
-  const int64_t NS = pn.N * (pn.S + 1);
+  const int S1 = pn.S + 1;
+  const int64_t NS = pn.N * S1;
   const int64_t total = NS + pn.Lm;
   for (int64_t i = tid; i < total; i += nthreads) {
-    if (i < NS) prep_cand(pn.M, pn.X, nullptr, pn.cand, pn.eg, i, pn.S, pn.M.item_num, 1, pn.key);
-    else pn.m[i - NS] = 0.f;
+    if (i < NS) {
+      const int64_t it = prep_cand(pn.M, pn.X, nullptr, pn.cand, pn.eg, i, pn.S, pn.M.item_num, 1, pn.key);
+      if (pn.lm.list) {
+        mark_row(pn.lm.flagV, it, pn.lm.tagV, pn.lm);
+        if (i % S1 == 0) mark_row(pn.lm.flagU, pn.X[2 * (i / S1)], pn.lm.tagU, pn.lm);
+      }
+    } else {
+      pn.m[i - NS] = 0.f;
+    }
+  }
+  if (pn.X_all) {            // plain byte stores: nobody needs these rows as a list
+    const int64_t all = (int64_t)pn.G * NS;
+    for (int64_t i = tid; i < all; i += nthreads) {
+      const int r = (int)(i / NS);
+      const int64_t j = i % NS, n = j / S1;
+      const int s = (int)(j % S1);
+      const int64_t* X = pn.X_all + (int64_t)r * pn.N * 2;
+      if (s == 0) {
+        pn.gV[X[2 * n + 1]] = 1;
+        pn.gU[X[2 * n]] = 1;
+      } else {
+        const rng_key key = key_plus(pn.gkey0, r);
+        const u32x4 rr = philox4x32_10((uint32_t)n, (uint32_t)((s - 1) >> 2), key.s0, key.s1, key.k0, key.k1);
+        pn.gV[(int64_t)(((uint64_t)pick4(rr, (s - 1) & 3) * (uint64_t)pn.M.item_num) >> 32)] = 1;
+      }
+    }
   }
 }
 

@@ -698,6 +698,44 @@ static int check_model(const dccf_model_t* M) {
 
 // The optimizer half of dccf_train_step, threaded through run_dccf: `overlap` forks the untouched-row pass onto the
 // context's side stream right after k_prep has marked the rows of this batch.
+// ---------------------------------------------------------------------------------------------- prepared next step
+// Did an earlier call prepare exactly this step (same batch pointer, size, Philox step, seed, tables, device-drawn candidates)?
+bool dccf_prep_matches(const dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd, const void* X, int64_t N) {
+  return ctx->prep_valid && rnd->mode == 1 && rnd->k_dev == nullptr && ctx->prep_X == X && ctx->prep_N == N &&
+         ctx->prep_step == rnd->step && ctx->prep_seed == rnd->seed && ctx->prep_U == (const void*)M->U &&
+         ctx->prep_W == (const void*)M->W;
+}
+
+int dccf_prep_next_fill(dccf_ctx* ctx, const dccf_model_t* M, int64_t N, const int64_t* X_next, uint64_t seed, uint64_t step_next,
+                        PrepNext* pn) {
+  const Lay y = make_layout(N, M->D, M->F, M->S, M->A);
+  if (int e = dccf_ws_ensure(ctx, y.total)) return e;
+  memset(pn, 0, sizeof(*pn));
+  char* ws = ctx->ws;
+  pn->M = *M;
+  pn->WT = (float*)(ws + y.WT);
+  pn->cand = (int*)(ws + y.cand);
+  pn->eg = (float*)(ws + y.dmns);
+  pn->m = (float*)(ws + y.m);
+  pn->X = X_next;
+  pn->N = N;
+  pn->Lm = y.GY > 1 ? y.L : 0;
+  pn->S = M->S;
+  pn->DP = y.DP;
+  pn->key = make_key(seed, STREAM_CAND, step_next);
+  return 0;
+}
+
+void dccf_prep_next_commit(dccf_ctx* ctx, const dccf_model_t* M, int64_t N, const void* X_next, uint64_t seed, uint64_t step_next) {
+  ctx->prep_valid = 1;
+  ctx->prep_X = X_next;
+  ctx->prep_N = N;
+  ctx->prep_step = step_next;
+  ctx->prep_seed = seed;
+  ctx->prep_U = M->U;
+  ctx->prep_W = M->W;
+}
+
 struct StepPlan {
   const dccf_opt_t* opt;
   bool overlap;
@@ -754,9 +792,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
   sr.x_steps = rnd->x_steps > 0 ? rnd->x_steps : 1;
 
   // Did the previous dccf_train_step prepare exactly this step (same batch pointer, size, Philox step, seed, tables)?
-  const bool prepared = ctx->prep_valid && train && fused_cand && !(plan && plan->overlap) && ctx->prep_X == (const void*)X &&
-                        ctx->prep_N == N && ctx->prep_step == rnd->step && ctx->prep_seed == rnd->seed &&
-                        ctx->prep_U == (const void*)M->U && ctx->prep_W == (const void*)M->W && rnd->k_dev == nullptr;
+  const bool prepared = train && !(plan && plan->overlap) && dccf_prep_matches(ctx, M, rnd, X, N);
   ctx->prep_valid = 0;       // consumed — or overwritten by the k_prep below
   if (prepared) ++ctx->prep_hits;
   if (!prepared) {
@@ -861,19 +897,12 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
       // the optimizer launch also prepares the next step: candidates + exposures of X_next, zeroed accumulators, and W^T
       // written while W is updated — the next call starts with its forward kernel
       PrepNext pn;
-      memset(&pn, 0, sizeof(pn));
-      pn.M = *M;
-      pn.WT = WT; pn.cand = cand; pn.eg = dmns; pn.m = m;
-      pn.X = plan->X_next; pn.N = N; pn.Lm = y.GY > 1 ? y.L : 0;
+      if (int e = dccf_prep_next_fill(ctx, M, N, plan->X_next, rnd->seed, plan->step_next, &pn)) return e;
       pn.w_begin = M->W - plan->opt->p;
       pn.w_end = pn.w_begin + (int64_t)D * (D + F);
-      pn.S = M->S; pn.DP = y.DP;
-      pn.blocks = (int)min((int64_t)64, (y.NS + pn.Lm + 1 + 255) / 256);
-      pn.key = make_key(rnd->seed, STREAM_CAND, plan->step_next);
+      pn.blocks = (int)min((int64_t)64, (y.NS + pn.Lm + 255) / 256);
       if (int e = dccf_opt_all_prep(plan->opt, &pn, st)) return e;
-      ctx->prep_valid = 1;
-      ctx->prep_X = plan->X_next; ctx->prep_N = N; ctx->prep_step = plan->step_next; ctx->prep_seed = rnd->seed;
-      ctx->prep_U = M->U; ctx->prep_W = M->W;
+      dccf_prep_next_commit(ctx, M, N, plan->X_next, rnd->seed, plan->step_next);
     } else {
       if (int e = dccf_opt_phase(plan->opt, OPT_PHASE_ALL, nullptr, nullptr, 0, st)) return e;
     }

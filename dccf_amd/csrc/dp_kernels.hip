@@ -63,8 +63,13 @@ __device__ __forceinline__ void dp_mark_rows(const MarkGlobal& mg, int64_t tid, 
       const u32x4 rr = philox4x32_10((uint32_t)n, (uint32_t)((s - 1) >> 2), key.s0, key.s1, key.k0, key.k1);
       it = (int64_t)(((uint64_t)pick4(rr, (s - 1) & 3) * (uint64_t)mg.item_num) >> 32);
     }
-    mark_row(mg.mp.flagV, it, mg.mp.tagV, mg.mp);
-    if (s == 0) mark_row(mg.mp.flagU, X[2 * n], mg.mp.tagU, mg.mp);
+    if (mg.mp.list) {
+      mark_row(mg.mp.flagV, it, mg.mp.tagV, mg.mp);
+      if (s == 0) mark_row(mg.mp.flagU, X[2 * n], mg.mp.tagU, mg.mp);
+    } else {             // nobody needs the rows as a list (dccf_dp_local): plain byte stores
+      reinterpret_cast<uint8_t*>(mg.mp.flagV)[it] = 1;
+      if (s == 0) reinterpret_cast<uint8_t*>(mg.mp.flagU)[X[2 * n]] = 1;
+    }
   }
 }
 
@@ -76,7 +81,7 @@ __global__ __launch_bounds__(256) void k_dp_mark(MarkGlobal mg) {
 static int make_mark_global(const int64_t* X_all, int32_t G, int64_t N, int32_t S, int64_t item_num, uint64_t seed, uint64_t step0,
                             uint8_t* flagsU, uint8_t* flagsV, int32_t segU, int32_t segV, int64_t* list, int32_t* cnt,
                             int32_t* cnt_next, MarkGlobal* mg) {
-  ARG_CHECK(X_all && flagsU && flagsV && list && cnt && cnt_next, "NULL argument");
+  ARG_CHECK(X_all && flagsU && flagsV && ((list && cnt && cnt_next) || (!list && !cnt && !cnt_next)), "NULL argument");
   ARG_CHECK(G >= 1 && N >= 1 && S >= 0 && item_num > 0, "bad sizes");
   ARG_CHECK((uintptr_t)flagsU % 4 == 0 && (uintptr_t)flagsV % 4 == 0, "flags must be 4-byte aligned (padded to whole words)");
   mg->X_all = X_all; mg->G = G; mg->S = S; mg->N = N; mg->item_num = item_num;
@@ -100,7 +105,7 @@ __global__ __launch_bounds__(256) void k_dp_export(float* __restrict__ g, RowSeg
   __shared__ int wl[4][256];                  // per wave: the rows found in the current chunk
   if ((int)blockIdx.x >= work_blocks) {       // global marking role (independent of the export: different flag arrays)
     const int mb = blockIdx.x - work_blocks;
-    if (mb == 0 && threadIdx.x == 0) *mg.mp.cnt_next = 0;
+    if (mb == 0 && threadIdx.x == 0 && mg.mp.cnt_next) *mg.mp.cnt_next = 0;
     dp_mark_rows(mg, mb * (int64_t)blockDim.x + threadIdx.x, (int64_t)(gridDim.x - work_blocks) * blockDim.x);
     return;
   }
@@ -166,6 +171,47 @@ __global__ __launch_bounds__(256) void k_dp_export(float* __restrict__ g, RowSeg
       }
       __builtin_amdgcn_wave_barrier();
     }
+  }
+}
+
+// The same export when the step's rows are already known as a de-duplicated list (a prepared step: the previous step's
+// optimizer launch drew this step's candidates and listed its rows, dccf_dp_overlap): one 16-lane group per list entry,
+// no flag scan, no atomics.  The order of the entries is the (arbitrary) order of the list — the import does not care.
+__global__ __launch_bounds__(256) void k_dp_export_list(float* __restrict__ g, RowSegs sg, int64_t dense_begin, const float* loss,
+                                                        float* __restrict__ buf, DpLay y, int row_blocks,
+                                                        const int64_t* __restrict__ list, const int* __restrict__ cnt,
+                                                        uint8_t* lfU, uint8_t* lfV, int segU) {
+  if ((int)blockIdx.x >= row_blocks) {       // dense tail + loss + the entry count
+    const int64_t tid = (int64_t)(blockIdx.x - row_blocks) * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)(gridDim.x - row_blocks) * blockDim.x;
+    for (int64_t i = tid; i < y.nd; i += stride) {
+      buf[y.dense_off + i] = g[dense_begin + i];
+      g[dense_begin + i] = 0.f;
+    }
+    if (tid == 0) {
+      buf[1] = loss ? loss[0] : 0.f;
+      reinterpret_cast<int*>(buf)[0] = min(*cnt, (int)y.cap);
+    }
+    return;
+  }
+  const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
+  const int t = blockIdx.x * 16 + grp;
+  const int n = min(*cnt, (int)y.cap);
+  if (t >= n) return;
+  const int64_t id = list[t];
+  const int q = (int)(id >> 40);
+  const int64_t row = id & ((1LL << 40) - 1);
+  float4* grow = reinterpret_cast<float4*>(g + sg.begin[q] + row * y.D);
+  float4* dst = reinterpret_cast<float4*>(buf + y.rows_off + (int64_t)t * y.D);
+  const int d4 = y.D >> 2;
+  for (int c = sub; c < d4; c += 16) {
+    dst[c] = grow[c];
+    grow[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (sub == 0) {
+    reinterpret_cast<int64_t*>(buf + y.ids_off)[t] = id;
+    (q == segU ? lfU : lfV)[row] = 0;              // the de-duplication mark is consumed
+    if (sg.flags[q]) sg.flags[q][row] = 0;         // and the byte the backward set
   }
 }
 
@@ -279,11 +325,19 @@ __device__ __forceinline__ void dp_apply4(const OptJob& j, int64_t i4, float4 gs
   if (K == DCCF_OPT_ADAM) reinterpret_cast<float4*>(j.s2)[i4] = bv;
 }
 
+// where the applying form mirrors the updated W (inside the dense tail) for the next step's forward (prepared step)
+struct WMirror {
+  float* WT;                 // NULL: nothing to mirror
+  int64_t w_begin, w_end;    // elements of the flat buffer
+  int KF, DP;
+  int* cnt_reset;            // the local-list counter this step consumed (zeroed for the step after the next)
+};
+
 template <int APPLY>
 __global__ __launch_bounds__(256) void k_dp_sum_rows(const float* __restrict__ bufs, int G, float* __restrict__ g, DpRows sg,
                                                      int64_t dense_begin, float* __restrict__ loss_sum, DpLay y, int64_t R,
                                                      uint32_t* __restrict__ mask, const int* __restrict__ where,
-                                                     int row_blocks, float* reset_buf, OptJob job) {
+                                                     int row_blocks, float* reset_buf, OptJob job, WMirror wm) {
   if ((int)blockIdx.x >= row_blocks) {           // dense tail: sum in rank order
     const int64_t tid = (int64_t)(blockIdx.x - row_blocks) * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)(gridDim.x - row_blocks) * blockDim.x;
@@ -299,11 +353,16 @@ __global__ __launch_bounds__(256) void k_dp_sum_rows(const float* __restrict__ b
         if (K == DCCF_OPT_ADAM) bv = job.s2[dense_begin + i];
         opt_elem<K>(pv, s, av, bv, job.a);
         job.p[dense_begin + i] = pv;
+        if (wm.WT && dense_begin + i >= wm.w_begin && dense_begin + i < wm.w_end) {   // W^T for the next step's forward
+          const int64_t idx = dense_begin + i - wm.w_begin;
+          wm.WT[(idx % wm.KF) * wm.DP + idx / wm.KF] = pv;
+        }
         if (K != DCCF_OPT_GD) job.s1[dense_begin + i] = av;
         if (K == DCCF_OPT_ADAM) job.s2[dense_begin + i] = bv;
       }
     }
     if (tid == 0 && reset_buf) reinterpret_cast<int*>(reset_buf)[0] = 0;      // the local export buffer's counter
+    if (tid == 0 && wm.cnt_reset) *wm.cnt_reset = 0;
     if (tid == 0 && loss_sum) {
       float s = bufs[1];
       for (int r = 1; r < G; ++r) s += bufs[(int64_t)r * y.words + 1];
@@ -378,7 +437,7 @@ __global__ __launch_bounds__(256) void k_dp_sum_rows(const float* __restrict__ b
 static int dp_import_impl(const float* bufs, int32_t G, float* g, int64_t n, int32_t nseg, const int64_t* seg_begin,
                           const int64_t* seg_rows, const int32_t* seg_width, uint8_t* const* seg_flags, int64_t dense_begin,
                           float* loss_sum, int64_t cap, int32_t D, uint32_t* mask, int32_t* where, float* reset_buf,
-                          const OptJob* job, hipStream_t st) {
+                          const OptJob* job, hipStream_t st, const WMirror* wmp = nullptr) {
   ARG_CHECK(bufs && (g || job) && G >= 1 && G <= DP_GMAX, "1..16 ranks");
   ARG_CHECK(nseg >= 1 && nseg <= 4 && seg_begin && seg_rows && seg_width && seg_flags, "bad segments");
   ARG_CHECK(D >= 4 && D <= 128 && D % 4 == 0 && cap >= 1 && dense_begin >= 0 && dense_begin <= n, "bad D / cap / dense_begin");
@@ -405,9 +464,12 @@ static int dp_import_impl(const float* bufs, int32_t G, float* g, int64_t n, int
   const dim3 grid(row_blocks + dense_blocks);
   OptJob none;
   memset(&none, 0, sizeof(none));
+  WMirror wm;
+  memset(&wm, 0, sizeof(wm));
+  if (wmp) wm = *wmp;
 #define DP_SUM(APPLY_, JOB_)                                                                                          \
   hipLaunchKernelGGL(k_dp_sum_rows<APPLY_>, grid, dim3(256), 0, st, bufs, G, g, sg, dense_begin, loss_sum, y, R, mask, where, \
-                     row_blocks, reset_buf, JOB_)
+                     row_blocks, reset_buf, JOB_, wm)
   if (!job) DP_SUM(-1, none);
   else if (job->kind == DCCF_OPT_GD) DP_SUM(DCCF_OPT_GD, *job);
   else if (job->kind == DCCF_OPT_ADAGRAD) DP_SUM(DCCF_OPT_ADAGRAD, *job);
@@ -453,48 +515,165 @@ extern "C" int dp_mark_global(const int64_t* X_all, int32_t G, int64_t N, int32_
 }
 
 // ---------------------------------------------------------------------------------------------- one step in three calls
+static uint8_t* dp_gflags(const dccf_dp_t* dp, int parity, int which) {      // double-buffered "touched by ANY rank" bytes
+  uint8_t* a = which == 0 ? dp->gflagsU : dp->gflagsV;
+  uint8_t* b = which == 0 ? dp->gflagsU2 : dp->gflagsV2;
+  return (parity && b) ? b : a;
+}
+static size_t pad4(int64_t n) { return (size_t)((n + 3) / 4 * 4); }
+
+// A prepared step that is not going to run as announced: its marks and list must not leak into later steps.
+static int dp_discard_prepared(dccf_ctx* ctx, const dccf_model_t* M, const dccf_dp_t* dp, hipStream_t st) {
+  if (ctx->prep_dp || ctx->prep_pending) {
+    const int par = ctx->prep_parity;
+    HIP_TRY(hipMemsetAsync(dp_gflags(dp, par, 0), 0, pad4(M->user_num), st));
+    HIP_TRY(hipMemsetAsync(dp_gflags(dp, par, 1), 0, pad4(M->item_num), st));
+    if (dp->lflagsU) HIP_TRY(hipMemsetAsync(dp->lflagsU, 0, pad4(M->user_num), st));
+    if (dp->lflagsV) HIP_TRY(hipMemsetAsync(dp->lflagsV, 0, pad4(M->item_num), st));
+    if (dp->lcnt) HIP_TRY(hipMemsetAsync(dp->lcnt, 0, 2 * sizeof(int32_t), st));
+    ctx->prep_valid = 0;
+  }
+  ctx->prep_dp = ctx->prep_pending = 0;
+  return 0;
+}
+
 extern "C" int dccf_dp_local(dccf_ctx* ctx, const dccf_model_t* model, const dccf_rand_t* rnd, const int64_t* X, const float* Y,
                              int64_t N, float dropout, const dccf_grads_t* grads, const dccf_opt_t* opt, const dccf_dp_t* dp,
                              const int64_t* X_all, uint64_t step0, int32_t parity, float* prediction, void* stream) {
-  ARG_CHECK(opt && dp && dp->loss && dp->buf, "NULL opt / dp");
+  ARG_CHECK(ctx && model && rnd && opt && dp && dp->loss && dp->buf, "NULL ctx / model / rnd / opt / dp");
+  ARG_CHECK(parity == 0 || parity == 1, "parity must be 0 or 1");
+  hipStream_t st = (hipStream_t)stream;
+  // prepared by the previous step's dccf_dp_overlap + dccf_dp_finish: slots and W^T (-> no k_prep), this rank's rows as a
+  // list (-> list export), every rank's rows marked in the flag set of this parity (-> no marking role)
+  const bool prepared = X_all && ctx->prep_dp && !ctx->prep_pending && ctx->prep_parity == parity &&
+                        ctx->prep_Xall == (const void*)X_all && dccf_prep_matches(ctx, model, rnd, X, N);
+  if (!prepared) {
+    if (int e = dp_discard_prepared(ctx, model, dp, st)) return e;
+  }
+  ctx->prep_dp = 0;
   if (int e = dccf_train_fwdbwd(ctx, model, rnd, X, Y, N, 1, dropout, grads, prediction, dp->loss, stream)) return e;
+  if (prepared) {
+    ARG_CHECK(opt->nseg >= 2 && opt->nseg <= 4, "bad segments");
+    RowSegs sg;
+    memset(&sg, 0, sizeof(sg));
+    sg.n = opt->nseg;
+    for (int q = 0; q < opt->nseg; ++q) {
+      ARG_CHECK(opt->seg_width[q] == dp->D, "every row segment must have width D");
+      sg.begin[q] = opt->seg_begin[q];
+      sg.end[q] = opt->seg_begin[q] + opt->seg_rows[q] * dp->D;
+      sg.width[q] = dp->D;
+      sg.flags[q] = opt->seg_flags[q];
+    }
+    const DpLay y = dp_layout(dp->cap, dp->D, opt->n - dp->dense_begin);
+    const int row_blocks = (int)((dp->cap + 15) / 16);
+    const int dense_blocks = (int)max((int64_t)1, min((int64_t)256, (y.nd + 255) / 256));
+    hipLaunchKernelGGL(k_dp_export_list, dim3(row_blocks + dense_blocks), dim3(256), 0, st, opt->g, sg, dp->dense_begin, dp->loss,
+                       dp->buf, y, row_blocks, dp->llist, dp->lcnt + parity, dp->lflagsU, dp->lflagsV, dp->segU);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   MarkGlobal mg;
   if (X_all) {     // overlap mode: the global marking rides in the export launch
-    ARG_CHECK(dp->gcnt && dp->glist && (parity == 0 || parity == 1), "NULL global list / bad parity");
-    if (int e = make_mark_global(X_all, dp->G, N, dp->S, dp->item_num, dp->seed, step0, dp->gflagsU, dp->gflagsV, dp->segU,
-                                 dp->segV, dp->glist, dp->gcnt + parity, dp->gcnt + (1 - parity), &mg))
+    // (bytes only: the merged import needs no list of the marked rows, so dp->glist / dp->gcnt stay untouched)
+    if (int e = make_mark_global(X_all, dp->G, N, dp->S, dp->item_num, dp->seed, step0, dp_gflags(dp, parity, 0),
+                                 dp_gflags(dp, parity, 1), dp->segU, dp->segV, nullptr, nullptr, nullptr, &mg))
       return e;
   }
   return dp_export_impl(opt->g, opt->n, opt->nseg, opt->seg_begin, opt->seg_rows, opt->seg_width, opt->seg_flags,
                         dp->dense_begin, dp->loss, dp->buf, dp->cap, dp->D, 0, X_all ? &mg : nullptr, stream);
 }
 
-static int dp_global_flags(const dccf_opt_t* opt, const dccf_dp_t* dp, uint8_t** out) {
+static int dp_global_flags(const dccf_opt_t* opt, const dccf_dp_t* dp, int parity, uint8_t** out) {
   ARG_CHECK(opt->nseg >= 2 && opt->nseg <= 4 && dp->segU >= 0 && dp->segU < opt->nseg && dp->segV >= 0 && dp->segV < opt->nseg &&
                 dp->segU != dp->segV && dp->gflagsU && dp->gflagsV,
             "bad global-flag segments");
+  ARG_CHECK(parity == 0 || parity == 1, "parity must be 0 or 1");
   for (int q = 0; q < opt->nseg; ++q) out[q] = opt->seg_flags[q];
-  out[dp->segU] = dp->gflagsU;
-  out[dp->segV] = dp->gflagsV;
+  out[dp->segU] = dp_gflags(dp, parity, 0);
+  out[dp->segV] = dp_gflags(dp, parity, 1);
   return 0;
 }
 
-extern "C" int dccf_dp_overlap(const dccf_opt_t* opt, const dccf_dp_t* dp, void* stream) {
-  ARG_CHECK(opt && dp, "NULL opt / dp");
-  uint8_t* gf[4];
-  if (int e = dp_global_flags(opt, dp, gf)) return e;
-  return dccf_dense_opt_phase(opt->kind, opt->p, opt->g, opt->s1, opt->s2, opt->n, opt->lr, opt->wd, opt->l2, opt->clip, opt->step,
-                              opt->nseg, opt->seg_begin, opt->seg_rows, opt->seg_width, gf, 1, nullptr, nullptr, 0, stream);
+static bool dp_next_usable(const dccf_opt_t* opt, const dccf_dp_t* dp, const dccf_dp_next_t* nx) {
+  if (!nx || !nx->ctx || !nx->model || !nx->X_next || !nx->X_all_next || nx->N <= 0) return false;
+  if (!dp->gflagsU2 || !dp->gflagsV2 || !dp->lflagsU || !dp->lflagsV || !dp->llist || !dp->lcnt) return false;
+  const dccf_model_t* M = nx->model;
+  return opt->p <= M->W && M->W + (int64_t)M->D * (M->D + M->F) <= opt->p + opt->n && (M->W - opt->p) >= dp->dense_begin &&
+         nx->N * (M->S + 2) <= dp->cap;
 }
 
-extern "C" int dccf_dp_finish(const dccf_opt_t* opt, const dccf_dp_t* dp, int32_t overlap, void* stream) {
+extern "C" int dccf_dp_overlap(const dccf_opt_t* opt, const dccf_dp_t* dp, int32_t parity, const dccf_dp_next_t* next,
+                               void* stream) {
+  ARG_CHECK(opt && dp, "NULL opt / dp");
+  uint8_t* gf[4];
+  if (int e = dp_global_flags(opt, dp, parity, gf)) return e;
+  if (!dp_next_usable(opt, dp, next))
+    return dccf_dense_opt_phase(opt->kind, opt->p, opt->g, opt->s1, opt->s2, opt->n, opt->lr, opt->wd, opt->l2, opt->clip, opt->step,
+                                opt->nseg, opt->seg_begin, opt->seg_rows, opt->seg_width, gf, 1, nullptr, nullptr, 0, stream);
+  // the pass over the rows no rank touches + the next step's preparation, in one launch
+  dccf_ctx* ctx = next->ctx;
+  const dccf_model_t* M = next->model;
+  PrepNext pn;
+  if (int e = dccf_prep_next_fill(ctx, M, next->N, next->X_next, dp->seed, next->step0_next + (uint64_t)dp->rank, &pn)) return e;
+  const int64_t NS = next->N * (M->S + 1);
+  pn.blocks = (int)min((int64_t)256, ((int64_t)dp->G * NS + 255) / 256);
+  pn.lm.flagU = (uint32_t*)dp->lflagsU;
+  pn.lm.flagV = (uint32_t*)dp->lflagsV;
+  pn.lm.tagU = (int64_t)dp->segU << 40;
+  pn.lm.tagV = (int64_t)dp->segV << 40;
+  pn.lm.list = dp->llist;
+  pn.lm.cnt = dp->lcnt + (1 - parity);
+  pn.lm.cnt_next = nullptr;
+  pn.X_all = next->X_all_next;
+  pn.gU = dp_gflags(dp, 1 - parity, 0);
+  pn.gV = dp_gflags(dp, 1 - parity, 1);
+  pn.G = dp->G;
+  pn.gkey0 = make_key(dp->seed, STREAM_CAND, next->step0_next);
+  ctx->prep_valid = 0;
+  ctx->prep_dp = 0;
+  ctx->prep_pending = 1;             // committed by dccf_dp_finish (W^T is written there)
+  ctx->prep_parity = 1 - parity;
+  return dccf_opt_untouched_prep(opt, gf, &pn, (hipStream_t)stream);
+}
+
+extern "C" int dccf_dp_finish(const dccf_opt_t* opt, const dccf_dp_t* dp, int32_t overlap, int32_t parity,
+                              const dccf_dp_next_t* next, void* stream) {
   ARG_CHECK(opt && dp && dp->bufs && dp->mask && dp->where, "NULL opt / dp");
   if (overlap) {
     uint8_t* gf[4];
-    if (int e = dp_global_flags(opt, dp, gf)) return e;
-    return dp_import_apply(dp->bufs, dp->G, opt->kind, opt->p, opt->s1, opt->s2, opt->n, opt->lr, opt->wd, opt->l2, opt->clip,
-                           opt->step, opt->nseg, opt->seg_begin, opt->seg_rows, opt->seg_width, gf, dp->dense_begin, dp->loss_sum,
-                           dp->cap, dp->D, dp->mask, dp->where, dp->buf, stream);
+    if (int e = dp_global_flags(opt, dp, parity, gf)) return e;
+    OptJob job;
+    if (int e = opt_make_job(opt->kind, opt->p, opt->p, opt->s1, opt->s2, opt->n, opt->lr, opt->wd, opt->l2, opt->clip, opt->step,
+                             nullptr, opt->nseg, opt->seg_begin, opt->seg_rows, opt->seg_width, gf, &job))
+      return e;
+    WMirror wm;
+    memset(&wm, 0, sizeof(wm));
+    wm.cnt_reset = dp->lcnt ? dp->lcnt + parity : nullptr;
+    dccf_ctx* ctx = next ? next->ctx : nullptr;
+    const bool commit = ctx && ctx->prep_pending && ctx->prep_parity == 1 - parity && dp_next_usable(opt, dp, next);
+    if (commit) {
+      const dccf_model_t* M = next->model;
+      PrepNext pn;       // (for the workspace address of W^T; the slab cannot move: same N as in dccf_dp_overlap)
+      if (int e = dccf_prep_next_fill(ctx, M, next->N, next->X_next, dp->seed, next->step0_next + (uint64_t)dp->rank, &pn)) return e;
+      wm.WT = pn.WT;
+      wm.w_begin = M->W - opt->p;
+      wm.w_end = wm.w_begin + (int64_t)M->D * (M->D + M->F);
+      wm.KF = M->D + M->F;
+      wm.DP = pn.DP;
+    } else if (ctx && ctx->prep_pending) {
+      if (int e = dp_discard_prepared(ctx, next->model, dp, (hipStream_t)stream)) return e;
+    }
+    if (int e = dp_import_impl(dp->bufs, dp->G, nullptr, opt->n, opt->nseg, opt->seg_begin, opt->seg_rows, opt->seg_width, gf,
+                               dp->dense_begin, dp->loss_sum, dp->cap, dp->D, dp->mask, dp->where, dp->buf, &job,
+                               (hipStream_t)stream, &wm))
+      return e;
+    if (commit) {
+      dccf_prep_next_commit(ctx, next->model, next->N, next->X_next, dp->seed, next->step0_next + (uint64_t)dp->rank);
+      ctx->prep_dp = 1;
+      ctx->prep_pending = 0;
+      ctx->prep_Xall = next->X_all_next;
+    }
+    return 0;
   }
   if (int e = dp_import_touched(dp->bufs, dp->G, opt->g, opt->n, opt->nseg, opt->seg_begin, opt->seg_rows, opt->seg_width,
                                 opt->seg_flags, dp->dense_begin, dp->loss_sum, dp->cap, dp->D, dp->mask, dp->where, dp->buf, stream))

@@ -38,6 +38,8 @@ extern "C" int dccf_ctx_create(dccf_ctx** out, int device) {
   c->tl_parity = 0;
   c->prep_valid = 0;
   c->prep_hits = 0;
+  c->prep_dp = c->prep_pending = c->prep_parity = 0;
+  c->prep_Xall = nullptr;
   *out = c;
   return 0;
 }
@@ -230,11 +232,14 @@ __global__ __launch_bounds__(256) void k_dense_opt_rows(float* __restrict__ p, f
                                                         float* __restrict__ s2, int64_t n, OptArgs a, RowSegs sg,
                                                         int phase, PrepNext pn) {
   opt_resolve(a);
-  const int nblk = (int)gridDim.x - pn.blocks;
-  if ((int)blockIdx.x >= nblk) {             // next step's candidate / exposure slots (independent of this pass)
-    prep_next_slots(pn, (int64_t)(blockIdx.x - nblk) * blockDim.x + threadIdx.x, (int64_t)pn.blocks * blockDim.x);
+  // the next step's candidate / exposure slots and marks (independent of this pass) take the FIRST workgroups: their
+  // dependent chains (Philox -> gather -> atomics) then run under the streaming pass instead of after it
+  if ((int)blockIdx.x < pn.blocks) {
+    prep_next_slots(pn, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)pn.blocks * blockDim.x);
     return;
   }
+  const int nblk = (int)gridDim.x - pn.blocks;
+  const int bid = (int)blockIdx.x - pn.blocks;
   const int64_t n4 = n / 4;
   const int64_t stride = (int64_t)nblk * blockDim.x;
   // row widths are powers of two (16..128): shifts instead of 64-bit divisions
@@ -243,7 +248,7 @@ __global__ __launch_bounds__(256) void k_dense_opt_rows(float* __restrict__ p, f
   for (int q = 0; q < 4; ++q) wsh[q] = q < sg.n ? 31 - __clz(sg.width[q]) : 0;
   // UN float4 slots in flight per thread: 2 pays once the tables exceed the Infinity Cache (5.0 -> 5.5 TB/s at 1.4 G
   // parameters), 1 is better at Electronics size (fewer registers, 8 waves per SIMD)
-  for (int64_t i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i0 < n4; i0 += stride * UN) {
+  for (int64_t i0 = bid * (int64_t)blockDim.x + threadIdx.x; i0 < n4; i0 += stride * UN) {
     float4 pv[UN], av[UN], bv[UN], gv[UN];
     uint8_t* fl[UN];
     bool live[UN], first[UN], touched[UN];
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(256) void k_dense_opt_rows(float* __restrict__ p, f
     }
   }
   if (phase == OPT_PHASE_UNTOUCHED) return;
-  for (int64_t i = n4 * 4 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) {   // dense tail
+  for (int64_t i = n4 * 4 + bid * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) {   // dense tail
     float pv = p[i], gv = g[i], av = 0.f, bv = 0.f;
     if (KIND != DCCF_OPT_GD) av = s1[i];
     if (KIND == DCCF_OPT_ADAM) bv = s2[i];
@@ -455,6 +460,16 @@ int dccf_opt_all_prep(const void* ov, const PrepNext* pn, hipStream_t st) {
   if (int e = opt_job(ov, &j)) return e;
   ARG_CHECK(pn->w_begin % 4 == 0 && pn->w_end % 4 == 0 && pn->w_end <= j.n, "W must be 16-byte aligned inside the flat buffer");
   return launch_job(j, OPT_PHASE_ALL, nullptr, nullptr, 0, st, pn);
+}
+
+int dccf_opt_untouched_prep(const void* ov, uint8_t* const* flags, const PrepNext* pn, hipStream_t st) {
+  const dccf_opt_t* o = (const dccf_opt_t*)ov;
+  ARG_CHECK(o != nullptr && flags != nullptr, "opt / flags is NULL");
+  OptJob j;
+  if (int e = opt_make_job(o->kind, o->p, o->g, o->s1, o->s2, o->n, o->lr, o->wd, o->l2, o->clip, o->step, nullptr, o->nseg,
+                           o->seg_begin, o->seg_rows, o->seg_width, flags, &j))
+    return e;
+  return launch_job(j, OPT_PHASE_UNTOUCHED, nullptr, nullptr, 0, st, pn);
 }
 
 extern "C" int dccf_dense_opt_step_rows(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t n, float lr,

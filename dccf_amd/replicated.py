@@ -63,9 +63,14 @@ class HipBackend(object):
         d.seed = int(tr.seed) & 0xFFFFFFFFFFFFFFFF
         d.buf, d.bufs, d.loss, d.loss_sum = L.ptr(tr.buf, f32), L.ptr(tr.bufs, f32), L.ptr(tr.loss, f32), L.ptr(tr.loss_sum, f32)
         d.gflagsU, d.gflagsV, d.segU, d.segV = L.ptr(tr.gfU, u8), L.ptr(tr.gfV, u8), 0, 1
+        d.gflagsU2, d.gflagsV2 = L.ptr(tr.gfU2, u8), L.ptr(tr.gfV2, u8)
+        d.lflagsU, d.lflagsV, d.llist, d.lcnt = L.ptr(tr.lfU, u8), L.ptr(tr.lfV, u8), L.ptr(tr.llist, i64), L.ptr(tr.lcnt, i32)
         d.glist, d.gcnt = L.ptr(tr.glist, i64), L.ptr(tr.gcnt, i32)
         d.mask, d.where = L.ptr(self.scratch.mask, i32), L.ptr(self.scratch.where, i32)
         self.dp = d
+        self.nx = L.DpNextT()
+        self.nx.ctx, self.nx.model = self.ctx.h, C.pointer(self.m)
+        self.nxp = C.byref(self.nx)
         self.mp, self.rp, self.gp, self.op, self.dpp = (C.byref(self.m), C.byref(self.r), C.byref(self.g), C.byref(self.opt),
                                                         C.byref(self.dp))
         self.f_local, self.f_overlap, self.f_finish = lib.dccf_dp_local, lib.dccf_dp_overlap, lib.dccf_dp_finish
@@ -84,15 +89,27 @@ class HipBackend(object):
                                   tr.parity, self.L.ptr(pred, torch.float32), self.L.stream()))
         return pred
 
+    def _next(self, tr):
+        """tr.next = (X_next, X_all_next) of the step after this one, or None: what the optimizer launches may prepare."""
+        nxt = getattr(tr, 'next', None)
+        if nxt is None:
+            return None
+        X_next, X_all_next = nxt
+        nx = self.nx
+        nx.X_next, nx.X_all_next = self.L.ptr(X_next, torch.int64), self.L.ptr(X_all_next, torch.int64)
+        nx.N, nx.step0_next = X_next.shape[0], tr.t * tr.G          # tr.t was already advanced: rank 0's next Philox step
+        return self.nxp
+
     def overlap(self, tr, t):
-        """While RCCL moves the buffers: the optimizer pass over the rows no rank touches."""
+        """While RCCL moves the buffers: the optimizer pass over the rows no rank touches (+ the next step's preparation)."""
         self.opt.step = t
-        self.L.check(self.f_overlap(self.op, self.dpp, self.L.stream()))
+        self.L.check(self.f_overlap(self.op, self.dpp, tr.parity, self._next(tr), self.L.stream()))
 
     def finish(self, tr, t, ov):
         """After the gathered buffers arrived: rank-ordered sums -> optimizer (ov: only the marked rows + W, b are left)."""
         self.opt.step = t
-        self.L.check(self.f_finish(self.op, self.dpp, 1 if ov else 0, self.L.stream()))
+        self.L.check(self.f_finish(self.op, self.dpp, 1 if ov else 0, tr.parity, self._next(tr) if ov else None,
+                                   self.L.stream()))
 
 
 class ReplicatedDCCF(object):
@@ -137,6 +154,12 @@ class ReplicatedDCCF(object):
         self.gfU = torch.zeros((user_num + 3) // 4 * 4, dtype=u8, device=device)[:user_num]
         self.gfV = torch.zeros((item_num + 3) // 4 * 4, dtype=u8, device=device)[:item_num]
         self.gsegments = [(offs[0], user_num, D, self.gfU), (offs[1], item_num, D, self.gfV)]
+        # prepared next step (HipBackend): second set of global bytes, this rank's de-duplication marks + row list
+        self.gfU2, self.gfV2 = torch.zeros_like(self.gfU), torch.zeros_like(self.gfV)
+        self.lfU, self.lfV = torch.zeros_like(self.gfU), torch.zeros_like(self.gfV)
+        self.llist = torch.zeros(self.cap + 64, dtype=torch.int64, device=device)
+        self.lcnt = torch.zeros(2, dtype=torch.int32, device=device)
+        self.next = None
         self.glist = torch.zeros(world * self.cap + 1024, dtype=torch.int64, device=device)
         self.gcnt = torch.zeros(2, dtype=torch.int32, device=device)
         self.parity = 0
@@ -155,13 +178,17 @@ class ReplicatedDCCF(object):
         for dst, src in ((self.U, U), (self.V, V), (self.W, W), (self.b, b)):
             dst.copy_(src)
 
-    def train_step(self, X, Y, pred=None, X_all=None):
+    def train_step(self, X, Y, pred=None, X_all=None, X_all_next=None):
         """X int64 [2B, 2] = this rank's [positives ; negatives]; one optimizer step over the G ranks' batches.
         X_all int64 [G, 2B, 2] (every rank's batch of this step, X_all[rank] == X) enables the overlap of the optimizer
-        pass over the rows NO rank touches with the all-gather.
+        pass over the rows NO rank touches with the all-gather.  X_all_next: the tensor the NEXT call will get as X_all
+        (and X_all_next[rank] as X) — the optimizer launches then also prepare that step (same results, fewer launches).
         Returns (prediction of this rank's rows, loss summed over the ranks)."""
         be = self.be
         ov = self.overlap and X_all is not None
+        self.next = None
+        if ov and X_all_next is not None and tuple(X_all_next.shape) == tuple(X_all.shape):
+            self.next = (X_all_next[self.rank], X_all_next)
         step0, t = self.t * self.G, self.t + 1
         pred = be.local(self, X, Y, step0 + self.rank, pred, X_all if ov else None, step0)
         work = None
@@ -220,16 +247,21 @@ def bench_main(args, rank, world, dev):
         full, _ = ds.epoch_batches(e, B)                       # same permutation / negatives on every rank
         return full[:n * world].view(n, world, 2 * B, 2)       # step k: rank r trains full[k*world + r]
 
+    pn = bool(getattr(args, 'prep_next', 1))
+
+    def nxt(sched, k, n):                                      # the next step's schedule entry, when there is one
+        return sched[k + 1] if pn and k + 1 < n else None
+
     sched = schedule(0, args.warmup)
     for k in range(args.warmup):
-        tr.train_step(sched[k, rank], y, pred, X_all=sched[k])
+        tr.train_step(sched[k, rank], y, pred, X_all=sched[k], X_all_next=nxt(sched, k, args.warmup))
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     sched = schedule(1, args.steps)                            # the epoch's negative sampling is timed
     for k in range(args.steps):
-        tr.train_step(sched[k, rank], y, pred, X_all=sched[k])
+        tr.train_step(sched[k, rank], y, pred, X_all=sched[k], X_all_next=nxt(sched, k, args.steps))
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()

@@ -284,8 +284,10 @@ int dp_import_touched(const float* bufs, int32_t G, float* g, int64_t n, int32_t
  *   dccf_dp_local    dccf_train_fwdbwd (loss -> dp->loss) + dp_export_touched into dp->buf; with X_all != NULL (int64
  *                    [G][N][2], Philox step of rank 0 = step0) the global marking of dp_mark_global rides in the export
  *                    launch                                                                            [then: all-gather]
- *   dccf_dp_overlap  dccf_dense_opt_phase(1) on the global marks — enqueue it right after the all-gather was launched
- *   dccf_dp_finish   overlap != 0: dp_import_apply;  else dp_import_touched + dccf_dense_opt_step_rows   [after the wait] */
+ *   dccf_dp_overlap  dccf_dense_opt_phase(1) on the global marks (of this parity) — enqueue it right after the all-gather
+ *                    was launched
+ *   dccf_dp_finish   overlap != 0: dp_import_apply;  else dp_import_touched + dccf_dense_opt_step_rows   [after the wait]
+ * parity alternates 0, 1, 0, ... over the steps (the same value in the three calls of a step). */
 typedef struct {
   int32_t G, rank, D, S;
   int64_t cap, dense_begin, item_num;
@@ -296,17 +298,37 @@ typedef struct {
   float* loss_sum;           /* [1] sum over the ranks                                                      */
   uint8_t* gflagsU;          /* "touched by ANY rank" bytes of the user / item segment (overlap mode)       */
   uint8_t* gflagsV;
+  uint8_t* gflagsU2;         /* the second set (steps of parity 1) — needed only for dccf_dp_next_t, else NULL */
+  uint8_t* gflagsV2;
+  uint8_t* lflagsU;          /* de-duplication marks of THIS rank's rows (zero between steps), padded to words; */
+  uint8_t* lflagsV;          /* with llist [cap + 64] and lcnt [2] (by parity): dccf_dp_next_t only, else NULL   */
+  int64_t* llist;
+  int32_t* lcnt;
   int32_t segU, segV;        /* indices of those segments in opt->seg_*                                      */
-  int64_t* glist;            /* [G * cap] de-duplicated global rows                                          */
-  int32_t* gcnt;             /* [2] alternating counters                                                     */
+  int64_t* glist;            /* unused by dccf_dp_* (the marks are bytes only); may be NULL                   */
+  int32_t* gcnt;
   uint32_t* mask;            /* scratch of the import, see dp_import_touched                                 */
   int32_t* where;
 } dccf_dp_t;
 int dccf_dp_local(dccf_ctx* ctx, const dccf_model_t* model, const dccf_rand_t* rnd, const int64_t* X, const float* Y, int64_t N,
                   float dropout, const dccf_grads_t* grads, const dccf_opt_t* opt, const dccf_dp_t* dp, const int64_t* X_all,
                   uint64_t step0, int32_t parity, float* prediction, void* stream);
-int dccf_dp_overlap(const dccf_opt_t* opt, const dccf_dp_t* dp, void* stream);
-int dccf_dp_finish(const dccf_opt_t* opt, const dccf_dp_t* dp, int32_t overlap, void* stream);
+/* What the host knows about the NEXT step (same N, overlap mode), handed to dccf_dp_overlap AND dccf_dp_finish of this step:
+ * the optimizer launches then also prepare it — this rank's candidates / exposures / W^T (no k_prep), this rank's rows as a
+ * list (the export becomes a gather of ~3 k listed rows instead of a scan of every flag), and every rank's rows marked in
+ * the flag set of the other parity (no marking role).  dccf_dp_local recognises the prepared step by (X, X_all, N, Philox
+ * step, parity); anything else discards the preparation.  Results are identical with or without it. */
+typedef struct {
+  dccf_ctx* ctx;
+  const dccf_model_t* model;
+  const int64_t* X_next;       /* this rank's batch of the next step [N][2]: the pointer dccf_dp_local will get as X */
+  const int64_t* X_all_next;   /* [G][N][2]: the pointer dccf_dp_local will get as X_all                            */
+  int64_t N;
+  uint64_t step0_next;         /* Philox step word of rank 0 in the next step                                        */
+} dccf_dp_next_t;
+int dccf_dp_overlap(const dccf_opt_t* opt, const dccf_dp_t* dp, int32_t parity, const dccf_dp_next_t* next, void* stream);
+int dccf_dp_finish(const dccf_opt_t* opt, const dccf_dp_t* dp, int32_t overlap, int32_t parity, const dccf_dp_next_t* next,
+                   void* stream);
 
 /* ---- row movers of the row-sharded multi-GPU path (dccf_amd/sharded.py; no reference counterpart — the reference is
  * single-GPU, src/main.py:106,153-155).  `tables` / `widths` are HOST arrays of up to 4 device pointers / row widths. */

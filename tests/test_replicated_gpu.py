@@ -103,10 +103,12 @@ def test_mark_global_matches_oracle_streams():
     assert sorted(got) == sorted(list(users) + [(1 << 40) | i for i in items])
 
 
-@pytest.mark.parametrize('overlap', [False, True])
+@pytest.mark.parametrize('overlap', [False, True, 'prep'])
 def test_replicated_trainer_world1_equals_single_gpu_step(overlap):
     """At G = 1 the replicated step (fwd/bwd -> export -> [all_gather] -> import -> Adam), with and without the optimizer
-    pass over the untouched rows on the side stream, must equal the plain step."""
+    pass over the untouched rows beside the collective, and with every step prepared by the one before ('prep': no k_prep,
+    list export, marks one step ahead), must equal the plain step."""
+    prep, overlap = overlap == 'prep', bool(overlap)
     import torch.distributed as dist
     from dccf_amd import replicated, _lib as L
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -134,11 +136,14 @@ def test_replicated_trainer_world1_equals_single_gpu_step(overlap):
     y = torch.cat([torch.ones(B, device='cuda'), torch.zeros(B, device='cuda')])
     gen = torch.Generator(device='cuda').manual_seed(2)
     seen = []
-    for t in range(4):
-        X = torch.stack([torch.randint(0, U // 2, (2 * B,), generator=gen, device='cuda'),
-                         torch.randint(0, I, (2 * B,), generator=gen, device='cuda')], 1)
+    T = 5
+    sched = torch.stack([torch.stack([torch.randint(0, U // 2, (2 * B,), generator=gen, device='cuda'),
+                                      torch.randint(0, I, (2 * B,), generator=gen, device='cuda')], 1) for _ in range(T)])[:, None]
+    for t in range(T):
+        X = sched[t, 0]
         seen.append(X[:, 0])
-        pred, loss = tr.train_step(X, y, X_all=X[None].contiguous() if overlap else None)
+        pred, loss = tr.train_step(X, y, X_all=sched[t] if overlap else None,
+                                   X_all_next=sched[t + 1] if prep and t + 1 < T and t != 2 else None)   # (one gap)
         m = L.model_struct(views[0], views[1], W, b, feat, expo, S, A, 0.1)
         pred2, loss2 = L.dccf_train_fwdbwd(ctx, m, L.rand_struct(seed=5, step=t), X, y, 1, 0.2, gviews[0], gviews[1], gW, gb)
         L.dense_opt_step('adam', p0, gg, s1, s2, 1e-3, 1e-4, 1e-4, 50.0, t + 1)
@@ -150,6 +155,8 @@ def test_replicated_trainer_world1_equals_single_gpu_step(overlap):
     assert float(d.max()) <= 4 * 1e-3 and int((d > 4 * 5e-3 * 1e-3).sum()) <= 4 * D + 8
     assert int(tr.tU.sum()) == 0 and int(tr.tV.sum()) == 0 and float(tr.flat_g.abs().max()) == 0.0
     assert int(tr.gfU.sum()) == 0 and int(tr.gfV.sum()) == 0
+    assert sum(int(a.sum()) for a in (tr.gfU2, tr.gfV2, tr.lfU, tr.lfV)) == 0
+    assert tr.be.ctx.prepared_steps() == (3 if prep else 0)
     # rows no batch touched are bit-identical (their update never sees a float atomic)
     never = torch.ones(U, dtype=torch.bool, device='cuda')
     never[torch.cat(seen)] = False
@@ -159,6 +166,8 @@ def test_replicated_trainer_world1_equals_single_gpu_step(overlap):
 
 def _rank_main(rank, world, port, out, overlap):
     import torch.distributed as dist
+    tag = str(overlap)
+    prep, overlap = overlap == 'prep', bool(overlap)
     from dccf_amd import replicated
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -175,32 +184,34 @@ def _rank_main(rank, world, port, out, overlap):
     y = torch.cat([torch.ones(c['B'], device='cuda'), torch.zeros(c['B'], device='cuda')])
     gen = torch.Generator(device='cuda').manual_seed(2)
     losses = []
+    sched = torch.stack([torch.stack([torch.stack([torch.randint(0, c['U'], (2 * c['B'],), generator=gen, device='cuda'),
+                                                   torch.randint(0, c['I'], (2 * c['B'],), generator=gen, device='cuda')], 1)
+                                      for _ in range(world)]) for _ in range(c['steps'])])
     for t in range(c['steps']):
-        X_all = torch.stack([torch.stack([torch.randint(0, c['U'], (2 * c['B'],), generator=gen, device='cuda'),
-                                          torch.randint(0, c['I'], (2 * c['B'],), generator=gen, device='cuda')], 1)
-                             for _ in range(world)])
-        _, loss = tr.train_step(X_all[rank].contiguous(), y, X_all=X_all if overlap else None)
+        _, loss = tr.train_step(sched[t, rank], y, X_all=sched[t] if overlap else None,
+                                X_all_next=sched[t + 1] if prep and t + 1 < c['steps'] else None)
         losses.append(float(loss))
     torch.cuda.synchronize()
-    np.savez(os.path.join(out, 'r%d_%d.npz' % (rank, int(overlap))), p=tr.flat_p.cpu().numpy(), losses=np.array(losses),
-             flags=np.array([int(tr.tU.sum()), int(tr.tV.sum()), int(tr.gfU.sum()), int(tr.gfV.sum())]),
+    assert tr.be.ctx.prepared_steps() == (c['steps'] - 1 if prep else 0)
+    np.savez(os.path.join(out, 'r%d_%s.npz' % (rank, tag)), p=tr.flat_p.cpu().numpy(), losses=np.array(losses),
+             flags=np.array([int(a.sum()) for a in (tr.tU, tr.tV, tr.gfU, tr.gfV, tr.gfU2, tr.gfV2, tr.lfU, tr.lfV)]),
              gmax=float(tr.flat_g.abs().max()))
     dist.destroy_process_group()
 
 
-W2 = dict(U=700, I=450, D=64, F=96, S=10, A=2, B=40, steps=4)
+W2 = dict(U=700, I=450, D=64, F=96, S=10, A=2, B=40, steps=5)
 
 
-@pytest.mark.parametrize('overlap', [False, True])
+@pytest.mark.parametrize('overlap', [False, True, 'prep'])
 def test_two_ranks_hip_backend_replicas_bit_identical(tmp_path, overlap):
     """World size 2 with the HIP backend (both ranks on this box's one GPU, gloo as the transport): the replicas end
     bit-identical, nothing is left in the gradient buffer or the flags, and the result equals the same two batches
     accumulated into one gradient on one GPU, to the float-atomic tolerance."""
     import torch.multiprocessing as mp
     from dccf_amd import _lib as L
-    port = 33000 + os.getpid() % 2000 + (11 if overlap else 0)
+    port = 33000 + os.getpid() % 2000 + {False: 0, True: 11, 'prep': 23}[overlap]
     mp.spawn(_rank_main, args=(2, port, str(tmp_path), overlap), nprocs=2, join=True)
-    r0, r1 = [dict(np.load(os.path.join(str(tmp_path), 'r%d_%d.npz' % (r, int(overlap))))) for r in range(2)]
+    r0, r1 = [dict(np.load(os.path.join(str(tmp_path), 'r%d_%s.npz' % (r, str(overlap))))) for r in range(2)]
     assert np.array_equal(r0['p'], r1['p'])
     assert np.array_equal(r0['losses'], r1['losses'])
     assert r0['flags'].sum() == 0 and r1['flags'].sum() == 0 and r0['gmax'] == 0 and r1['gmax'] == 0
