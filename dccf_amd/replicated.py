@@ -276,13 +276,14 @@ def bench_main(args, rank, world, dev):
     # roofline of the dominant kernel (the dense regularised Adam pass, HBM-bound): HIP events around its launches in a
     # short extra pass on rank 0's stream, outside the timed region
     n_prof = 50
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_prof)]
+    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(n_prof)]
     for k in range(n_prof):
         ev[k][0].record()
         be.L.dense_opt_phase('adam', tr.flat_p, tr.flat_g, tr.s1, tr.s2, tr.lr, tr.l2, tr.l2, 50.0, tr.t + 1, tr.gsegments, 1)   # no row is marked: the whole pass
         ev[k][1].record()
+        ev[k][2].record()          # empty bracket = the cost of an event boundary, contained once in the first bracket
     torch.cuda.synchronize()
-    adam_ms = sum(a.elapsed_time(b) for a, b in ev) / n_prof
+    adam_ms = max(sum(a.elapsed_time(b) - b.elapsed_time(c) for a, b, c in ev) / n_prof, 1e-6)
     n_params = tr.flat_p.numel()
     roofline = {'kernel': 'dense_adam', 'bound': 'hbm', 'achieved': round(24.0 * n_params / 1e9 / (adam_ms / 1e3), 2),
                 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(24.0 * n_params / 1e9 / (adam_ms / 1e3) / 8000.0, 4),
