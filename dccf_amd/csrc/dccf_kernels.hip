@@ -381,6 +381,11 @@ __global__ __launch_bounds__(256) void k_pair_epilogue(int S1, int A, const floa
 // roles 19 -> 18 us at B=128 (kernel 28.7 -> 27.7 us), but B=4096 loses 4 % (0.411 -> 0.428 ms) — the k-loop is bound by the
 // shared VALU / fp32-MFMA pipe (Philox + Box-Muller ~600 cycles + 8 MFMAs = 512 cycles per k-step), not by latency.
 #define BWD_NW 4
+#ifdef DCCF_BWD_NO_WPE
+#define BWD_WPE
+#else
+#define BWD_WPE __attribute__((amdgpu_waves_per_eu(2)))
+#endif
 // ================================================================================================ K3: backward
 // dz[l][d] = dm[l] * U[u(l)][d] * [h[l][d] > 0] * kscale is never stored: every role rebuilds the operand it needs from
 // h, dm and the user row.  grid = (row splits, roles x column halves); a workgroup has ONE role and 4 waves that split
@@ -408,10 +413,49 @@ struct BwdArgs {
   float kscale, nscale;
   rng_key nkey;
   StepRef sr;
+  // FOLD (S1 <= 16): the pair epilogue runs inside this kernel — dmns holds Expo[u, cand] and stays read-only
+  const float *m, *Y;
+  float *pred, *loss;
+  int rank;
 };
 
+// FOLD: what k_pair_epilogue would have stored for batch row n, recomputed by the wave that walks n (every role needs it;
+// 66 loads and a few shuffles per n instead of a kernel between forward and backward).  16-lane groups: even groups take
+// row n, odd groups its BPR partner (n +- N/2), so one xor-16 shuffle gives every lane both predictions.  Returns
+// d loss / d (mean_a m[n][s]) for s = lane & 15, valid in lanes 0 .. S1-1; `emit` (one role) writes prediction and loss.
+__device__ __forceinline__ float wave_dm(const BwdArgs& p, int64_t n, float& lsum, bool emit) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15;
+  const int64_t B = p.N / 2;
+  const int64_t other = p.rank == 1 ? (n < B ? n + B : n - B) : n;
+  const int64_t row = (g & 1) ? other : n;
+  float w;
+  const float pm = row_predict<16>(p.dmns, p.m, row, s, p.S1, p.A, w);
+  float dm;
+  if (p.rank == 1) {
+    const float po = __shfl_xor(pm, 16, 64);
+    const bool pos = row < B;
+    const float pp = pos ? pm : po, pn = pos ? po : pm;
+    const float d = pp - pn;
+    const float sg = 1.f / (1.f + expf(-d));
+    const float gp = -(1.f - sg);                 // d loss / d pos = -sigmoid(neg - pos)
+    dm = pos ? w * gp : w * (-gp);
+    if (emit && lane == 0) {
+      p.pred[n] = pm;
+      if (n < B) lsum += -logf(sg);
+    }
+  } else {
+    const float diff = pm - p.Y[row];
+    dm = w * (2.f * diff / (float)p.N);
+    if (emit && lane == 0) {
+      p.pred[n] = pm;
+      lsum += diff * diff / (float)p.N;
+    }
+  }
+  return dm;
+}
+
 // roles "feature chunk" (CHUNK) and "item": A = dz^T for the rows of n, B = eps (regenerated / injected) or V[cand]
-template <int D, int MODE, bool CHUNK>
+template <int D, int MODE, bool CHUNK, bool FOLD>
 __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int role, int dbase) {
   constexpr int DP = D <= 32 ? 32 : (D + 63) / 64 * 64;
   constexpr int ND = D <= 32 ? 1 : 2;
@@ -438,9 +482,11 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
     gb_acc[mt] = 0.f;
     dok[mt] = dbase + mt * 32 + c31 < D;
   }
+  float lsum = 0.f;
   for (int64_t n = n0; n < p.N; n += nstride) {
     const int64_t u = p.X[2 * n];
     const float* frow = p.feat + p.X[2 * n + 1] * F;
+    float dmn = 0.f;
     float uv[ND], asum[ND], due[ND], fb[NB];
 #pragma unroll
     for (int mt = 0; mt < ND; ++mt) {
@@ -468,7 +514,7 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
         const int rc = lv ? r : rpn - 1;
         lrow[jj] = n * rpn + rc;
         const int64_t ns = n * S1 + rc / A;
-        dmv[jj] = p.dmns[ns];
+        if (!FOLD) dmv[jj] = p.dmns[ns];
         lvv[jj] = lv;
 #pragma unroll
         for (int mt = 0; mt < ND; ++mt) hv[jj][mt] = p.hbuf[lrow[jj] * DP + dbase + mt * 32 + c31];
@@ -480,6 +526,12 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
 #pragma unroll
           for (int o = 0; o < NB; ++o) bq[jj][o] = p.noise[lrow[jj] * F + min(role * 128 + 32 * o + c31, F - 1)];
         }
+      }
+      if (FOLD) {
+        // the row's epilogue, computed while the first batch of loads is in flight (its own loads join that round trip)
+        if (j0 == 0) dmn = wave_dm(p, n, lsum, CHUNK && role == 0 && dbase == 0);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) dmv[jj] = __shfl(dmn, min(2 * (j0 + jj) + h, rpn - 1) / A, 64);
       }
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {              // pin the batch (one wait), then mask
@@ -565,11 +617,12 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
     for (int mt = 0; mt < ND; ++mt)
       if (dok[mt]) atomicAdd(&p.gb[dbase + mt * 32 + c31], gb_acc[mt]);
   }
+  if (FOLD && CHUNK && role == 0 && dbase == 0 && lane == 0 && lsum != 0.f) atomicAdd(p.loss, lsum);
   TRACEB(role, 2);
 }
 
 // role "dx": gV[cand] += dz W_i   (MFMA: M = rows of n, N = d', K = d)
-template <int D>
+template <int D, bool FOLD>
 __device__ __forceinline__ void bwd_dx_role(const BwdArgs& p, int dbase) {
   constexpr int DP = D <= 32 ? 32 : (D + 63) / 64 * 64;
   constexpr int ND = D <= 32 ? 1 : 2;
@@ -592,12 +645,16 @@ __device__ __forceinline__ void bwd_dx_role(const BwdArgs& p, int dbase) {
   const int RT = (rpn + 31) / 32;
   for (int64_t n = n0; n < p.N; n += nstride) {
     const float* urow = p.U + p.X[2 * n] * D;
+    float dmn = 0.f, lnone = 0.f;
+    if (FOLD) dmn = wave_dm(p, n, lnone, false);
     for (int t = 0; t < RT; ++t) {
       const int rr = t * 32 + c31;
       const bool lv = rr < rpn;
       const int rc = lv ? rr : rpn - 1;             // clamped: loads are unconditional, dm zeroes the row
       const int64_t l = n * rpn + rc;
-      const float dm0 = p.dmns[n * S1 + rc / A];
+      float dm0;
+      if (FOLD) dm0 = __shfl(dmn, rc / A, 64);
+      else dm0 = p.dmns[n * S1 + rc / A];
       KEEP(dm0);
       const float dmv = lv ? dm0 : 0.f;
       const float* hrow = p.hbuf + l * DP;
@@ -657,8 +714,8 @@ __device__ __forceinline__ void bwd_dx_role(const BwdArgs& p, int dbase) {
   }
 }
 
-template <int D_, int MODE>
-__global__ __launch_bounds__(64 * BWD_NW) void k_bwd(BwdArgs p) {
+template <int D_, int MODE, bool FOLD>
+__global__ __launch_bounds__(64 * BWD_NW) BWD_WPE void k_bwd(BwdArgs p) {
   extern __shared__ float red[];          // [BWD_NW waves][128 / BWD_NW regs][64 lanes]
   {
     const int64_t k = step_k(p.sr);
@@ -669,9 +726,9 @@ __global__ __launch_bounds__(64 * BWD_NW) void k_bwd(BwdArgs p) {
   constexpr int GY = D_ <= 64 ? 1 : D_ / 64;
   const int role = blockIdx.y / GY;
   const int dbase = (blockIdx.y % GY) * DW;
-  if (role < p.NC) bwd_col_role<D_, MODE, true>(p, red, role, dbase);
-  else if (role == p.NC) bwd_col_role<D_, MODE, false>(p, red, role, dbase);
-  else bwd_dx_role<D_>(p, dbase);
+  if (role < p.NC) bwd_col_role<D_, MODE, true, FOLD>(p, red, role, dbase);
+  else if (role == p.NC) bwd_col_role<D_, MODE, false, FOLD>(p, red, role, dbase);
+  else bwd_dx_role<D_, FOLD>(p, dbase);
   if (role > p.NC) TRACEB(7, 2);
 }
 
@@ -840,7 +897,9 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
 #undef LAUNCH_FWD3
     prof_end(ctx, 2, st);
   }
-  {
+  // training with at most 16 candidates per row: the pair epilogue is folded into the backward (wave_dm)
+  const bool fold = train && S1 <= 16 && N <= (getenv("DCCF_FOLD_MAX_N") ? atoll(getenv("DCCF_FOLD_MAX_N")) : 1024);
+  if (!fold) {
     const int64_t units = (train && rank == 1) ? N / 2 : N;
     const int GS = S1 <= 16 ? 16 : (S1 <= 32 ? 32 : 64);
     const int grid = (int)min((int64_t)2048, (units * GS + 255) / 256);
@@ -861,29 +920,27 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     const dim3 grid((unsigned)gx, (unsigned)roles);
     const size_t smem = (size_t)4 * 32 * 64 * 4;
     prof_begin(ctx, st);
-#define LAUNCH_BWD(D_)                                                                                              \
-  if (fused) {                                                                                                      \
-    static bool once0 = false;                                                                                      \
-    if (!once0) {                                                                                                   \
-      HIP_TRY(hipFuncSetAttribute((const void*)k_bwd<D_, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-      once0 = true;                                                                                                 \
-    }                                                                                                               \
-    hipLaunchKernelGGL((k_bwd<D_, 0>), grid, dim3(64 * BWD_NW), smem, st, ba);                                              \
-  } else {                                                                                                          \
-    static bool once1 = false;                                                                                      \
-    if (!once1) {                                                                                                   \
-      HIP_TRY(hipFuncSetAttribute((const void*)k_bwd<D_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-      once1 = true;                                                                                                 \
-    }                                                                                                               \
-    hipLaunchKernelGGL((k_bwd<D_, 1>), grid, dim3(64 * BWD_NW), smem, st, ba);                                              \
+#define LAUNCH_BWD3(D_, MODE_, FOLD_)                                                                                \
+  {                                                                                                                  \
+    static bool once = false;                                                                                        \
+    if (!once) {                                                                                                     \
+      HIP_TRY(hipFuncSetAttribute((const void*)k_bwd<D_, MODE_, FOLD_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+      once = true;                                                                                                   \
+    }                                                                                                                \
+    hipLaunchKernelGGL((k_bwd<D_, MODE_, FOLD_>), grid, dim3(64 * BWD_NW), smem, st, ba);                            \
   }
+#define LAUNCH_BWD2(D_, MODE_) if (fold) LAUNCH_BWD3(D_, MODE_, true) else LAUNCH_BWD3(D_, MODE_, false)
+#define LAUNCH_BWD(D_) if (fused) LAUNCH_BWD2(D_, 0) else LAUNCH_BWD2(D_, 1)
     BwdArgs ba;
     ba.W = M->W; ba.U = M->U; ba.V = M->V; ba.feat = M->feat; ba.X = X; ba.cand = cand; ba.dmns = dmns; ba.hbuf = hbuf;
     ba.noise = rnd->noise; ba.gU = G->gU; ba.gV = G->gV; ba.gW = G->gW; ba.gb = G->gb;
     ba.touchedU = G->touchedU; ba.touchedV = G->touchedV; ba.N = N; ba.S1 = S1; ba.A = A;
     ba.F = F; ba.NC = y.NC; ba.kscale = kscale; ba.nscale = nscale; ba.nkey = nkey; ba.sr = sr;
+    ba.m = m; ba.Y = Y; ba.pred = pred; ba.loss = loss; ba.rank = rank;
     BY_D(D, LAUNCH_BWD)
 #undef LAUNCH_BWD
+#undef LAUNCH_BWD2
+#undef LAUNCH_BWD3
     prof_end(ctx, 5, st);
   }
   HIP_TRY(hipGetLastError());
