@@ -53,7 +53,7 @@ class DpT(C.Structure):
     _fields_ = [('G', C.c_int32), ('rank', C.c_int32), ('D', C.c_int32), ('S', C.c_int32), ('cap', C.c_int64),
                 ('dense_begin', C.c_int64), ('item_num', C.c_int64), ('seed', C.c_uint64), ('buf', _f), ('bufs', _f),
                 ('loss', _f), ('loss_sum', _f), ('gflagsU', _f), ('gflagsV', _f), ('gflagsU2', _f), ('gflagsV2', _f),
-                ('lflagsU', _f), ('lflagsV', _f), ('llist', _f), ('lcnt', _f), ('segU', C.c_int32), ('segV', C.c_int32),
+                ('lflagsU', _f), ('lflagsV', _f), ('llist', _f), ('lcnt', _f), ('ctx', _f), ('pmask', _f), ('pwhere', _f), ('segU', C.c_int32), ('segV', C.c_int32),
                 ('glist', _f), ('gcnt', _f), ('mask', _f), ('where', _f)]
 
 

@@ -53,6 +53,7 @@ struct dccf_ctx {
   const void* prep_W;
   // replicated path: the dp part of the prepared step (global marks in set prep_parity, local list) and its schedule
   int prep_dp, prep_pending, prep_parity;
+  int prep_tables, cur_tables;     // the import tables of the prepared / of the running step were built ahead
   const void* prep_Xall;
   int64_t prep_N;
   uint64_t prep_step, prep_seed;
@@ -271,6 +272,12 @@ struct PrepNext {
   uint8_t* gV;
   int G;
   rng_key gkey0;             // STREAM_CAND key of rank 0's next step; rank r draws with key + r
+  // != NULL: the import tables of the next step, built here instead of by k_dp_scatter_ids after the all-gather:
+  // nmask[gid] bit r = rank r touches the row; nwhere[r * R + gid] = the slot of rank r's buffer that will hold it = the
+  // row's FIRST position in rank r's canonical (n, s) order (atomicMin: the same on every rank)
+  uint32_t* nmask;
+  int* nwhere;
+  int64_t R, offU, offV;     // rows of all segments; first global row index of the user / item segment
 };
 
 __device__ __forceinline__ void prep_next_slots(const PrepNext& pn, int64_t tid, int64_t nthreads) {
@@ -295,13 +302,24 @@ __device__ __forceinline__ void prep_next_slots(const PrepNext& pn, int64_t tid,
       const int64_t j = i % NS, n = j / S1;
       const int s = (int)(j % S1);
       const int64_t* X = pn.X_all + (int64_t)r * pn.N * 2;
+      int64_t it;
       if (s == 0) {
-        pn.gV[X[2 * n + 1]] = 1;
-        pn.gU[X[2 * n]] = 1;
+        it = X[2 * n + 1];
+        const int64_t u = X[2 * n];
+        pn.gU[u] = 1;
+        if (pn.nmask) {
+          atomicMin(&pn.nwhere[(int64_t)r * pn.R + pn.offU + u], (int)(NS + n));
+          atomicOr(&pn.nmask[pn.offU + u], 1u << r);
+        }
       } else {
         const rng_key key = key_plus(pn.gkey0, r);
         const u32x4 rr = philox4x32_10((uint32_t)n, (uint32_t)((s - 1) >> 2), key.s0, key.s1, key.k0, key.k1);
-        pn.gV[(int64_t)(((uint64_t)pick4(rr, (s - 1) & 3) * (uint64_t)pn.M.item_num) >> 32)] = 1;
+        it = (int64_t)(((uint64_t)pick4(rr, (s - 1) & 3) * (uint64_t)pn.M.item_num) >> 32);
+      }
+      pn.gV[it] = 1;
+      if (pn.nmask) {
+        atomicMin(&pn.nwhere[(int64_t)r * pn.R + pn.offV + it], (int)j);
+        atomicOr(&pn.nmask[pn.offV + it], 1u << r);
       }
     }
   }

@@ -180,7 +180,8 @@ __global__ __launch_bounds__(256) void k_dp_export(float* __restrict__ g, RowSeg
 __global__ __launch_bounds__(256) void k_dp_export_list(float* __restrict__ g, RowSegs sg, int64_t dense_begin, const float* loss,
                                                         float* __restrict__ buf, DpLay y, int row_blocks,
                                                         const int64_t* __restrict__ list, const int* __restrict__ cnt,
-                                                        uint8_t* lfU, uint8_t* lfV, int segU) {
+                                                        uint8_t* lfU, uint8_t* lfV, int segU, const int* __restrict__ where_r,
+                                                        int64_t offU, int64_t offV) {
   if ((int)blockIdx.x >= row_blocks) {       // dense tail + loss + the entry count
     const int64_t tid = (int64_t)(blockIdx.x - row_blocks) * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)(gridDim.x - row_blocks) * blockDim.x;
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(256) void k_dp_export_list(float* __restrict__ g, R
     }
     if (tid == 0) {
       buf[1] = loss ? loss[0] : 0.f;
-      reinterpret_cast<int*>(buf)[0] = min(*cnt, (int)y.cap);
+      reinterpret_cast<int*>(buf)[0] = where_r ? (int)y.cap : min(*cnt, (int)y.cap);   // table slots are sparse
     }
     return;
   }
@@ -201,15 +202,18 @@ __global__ __launch_bounds__(256) void k_dp_export_list(float* __restrict__ g, R
   const int64_t id = list[t];
   const int q = (int)(id >> 40);
   const int64_t row = id & ((1LL << 40) - 1);
+  // slot: the list position, or — when the import tables were built ahead — the slot every rank expects the row in
+  const int slot = where_r ? where_r[(q == segU ? offU : offV) + row] : t;
+  if (slot < 0 || slot >= (int)y.cap) return;      // (cannot happen: the table was built from the same draws as the list)
   float4* grow = reinterpret_cast<float4*>(g + sg.begin[q] + row * y.D);
-  float4* dst = reinterpret_cast<float4*>(buf + y.rows_off + (int64_t)t * y.D);
+  float4* dst = reinterpret_cast<float4*>(buf + y.rows_off + (int64_t)slot * y.D);
   const int d4 = y.D >> 2;
   for (int c = sub; c < d4; c += 16) {
     dst[c] = grow[c];
     grow[c] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   if (sub == 0) {
-    reinterpret_cast<int64_t*>(buf + y.ids_off)[t] = id;
+    reinterpret_cast<int64_t*>(buf + y.ids_off)[slot] = id;
     (q == segU ? lfU : lfV)[row] = 0;              // the de-duplication mark is consumed
     if (sg.flags[q]) sg.flags[q][row] = 0;         // and the byte the backward set
   }
@@ -331,12 +335,13 @@ struct WMirror {
   int64_t w_begin, w_end;    // elements of the flat buffer
   int KF, DP;
   int* cnt_reset;            // the local-list counter this step consumed (zeroed for the step after the next)
+  int reset_where;           // tables built ahead (atomicMin): the owner puts the consumed where entries back to INT_MAX
 };
 
 template <int APPLY>
 __global__ __launch_bounds__(256) void k_dp_sum_rows(const float* __restrict__ bufs, int G, float* __restrict__ g, DpRows sg,
                                                      int64_t dense_begin, float* __restrict__ loss_sum, DpLay y, int64_t R,
-                                                     uint32_t* __restrict__ mask, const int* __restrict__ where,
+                                                     uint32_t* __restrict__ mask, int* where,
                                                      int row_blocks, float* reset_buf, OptJob job, WMirror wm) {
   if ((int)blockIdx.x >= row_blocks) {           // dense tail: sum in rank order
     const int64_t tid = (int64_t)(blockIdx.x - row_blocks) * blockDim.x + threadIdx.x;
@@ -402,12 +407,14 @@ __global__ __launch_bounds__(256) void k_dp_sum_rows(const float* __restrict__ b
       a0 = src[sub];
       if (two) a1 = src[sub + 16];
     }
+    if (wm.reset_where && sub == 0) where[(int64_t)r * R + gid] = 0x7fffffff;
     m &= m - 1;
     while (m) {
       const int r2 = __ffs(m) - 1;
       m &= m - 1;
-      const float4* src = reinterpret_cast<const float4*>(bufs + (int64_t)r2 * y.words + y.rows_off +
-                                                           (int64_t)where[(int64_t)r2 * R + gid] * y.D);
+      const int e2 = where[(int64_t)r2 * R + gid];
+      if (wm.reset_where && sub == 0) where[(int64_t)r2 * R + gid] = 0x7fffffff;
+      const float4* src = reinterpret_cast<const float4*>(bufs + (int64_t)r2 * y.words + y.rows_off + (int64_t)e2 * y.D);
       const float4 v0 = src[sub];
       a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
       if (two) {
@@ -437,7 +444,7 @@ __global__ __launch_bounds__(256) void k_dp_sum_rows(const float* __restrict__ b
 static int dp_import_impl(const float* bufs, int32_t G, float* g, int64_t n, int32_t nseg, const int64_t* seg_begin,
                           const int64_t* seg_rows, const int32_t* seg_width, uint8_t* const* seg_flags, int64_t dense_begin,
                           float* loss_sum, int64_t cap, int32_t D, uint32_t* mask, int32_t* where, float* reset_buf,
-                          const OptJob* job, hipStream_t st, const WMirror* wmp = nullptr) {
+                          const OptJob* job, hipStream_t st, const WMirror* wmp = nullptr, bool scatter = true) {
   ARG_CHECK(bufs && (g || job) && G >= 1 && G <= DP_GMAX, "1..16 ranks");
   ARG_CHECK(nseg >= 1 && nseg <= 4 && seg_begin && seg_rows && seg_width && seg_flags, "bad segments");
   ARG_CHECK(D >= 4 && D <= 128 && D % 4 == 0 && cap >= 1 && dense_begin >= 0 && dense_begin <= n, "bad D / cap / dense_begin");
@@ -457,8 +464,9 @@ static int dp_import_impl(const float* bufs, int32_t G, float* g, int64_t n, int
   }
   const DpLay y = dp_layout(cap, D, n - dense_begin);
   const int64_t total = (int64_t)G * cap;
-  hipLaunchKernelGGL(k_dp_scatter_ids, dim3((unsigned)min((int64_t)1024, (total + 255) / 256)), dim3(256), 0, st, bufs, G, y, sg,
-                     R, mask, where);
+  if (scatter)       // (a prepared step's tables were built one step ahead, inside the optimizer launch)
+    hipLaunchKernelGGL(k_dp_scatter_ids, dim3((unsigned)min((int64_t)1024, (total + 255) / 256)), dim3(256), 0, st, bufs, G, y,
+                       sg, R, mask, where);
   const int row_blocks = (int)((total + 15) / 16);          // one 16-lane group per entry
   const int dense_blocks = (int)max((int64_t)1, min((int64_t)256, (y.nd + 255) / 256));
   const dim3 grid(row_blocks + dense_blocks);
@@ -531,10 +539,26 @@ static int dp_discard_prepared(dccf_ctx* ctx, const dccf_model_t* M, const dccf_
     if (dp->lflagsU) HIP_TRY(hipMemsetAsync(dp->lflagsU, 0, pad4(M->user_num), st));
     if (dp->lflagsV) HIP_TRY(hipMemsetAsync(dp->lflagsV, 0, pad4(M->item_num), st));
     if (dp->lcnt) HIP_TRY(hipMemsetAsync(dp->lcnt, 0, 2 * sizeof(int32_t), st));
+    if (ctx->prep_tables && dp->pmask && dp->pwhere) {
+      const int64_t R = M->user_num + M->item_num;
+      HIP_TRY(hipMemsetAsync(dp->pmask + (int64_t)par * R, 0, (size_t)R * 4, st));
+      HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(dp->pwhere + (int64_t)par * dp->G * R), 0x7fffffff, (size_t)dp->G * R, st));
+    }
     ctx->prep_valid = 0;
   }
-  ctx->prep_dp = ctx->prep_pending = 0;
+  ctx->prep_dp = ctx->prep_pending = ctx->prep_tables = 0;
   return 0;
+}
+
+// the import tables built ahead need the two-segment layout [users | items] that R = user_num + item_num assumes
+static bool dp_tables_usable(const dccf_opt_t* opt, const dccf_dp_t* dp, const dccf_model_t* M) {
+  return dp->ctx && dp->pmask && dp->pwhere && opt->nseg == 2 && opt->seg_rows[dp->segU] == M->user_num &&
+         opt->seg_rows[dp->segV] == M->item_num;
+}
+static int64_t dp_rowoff(const dccf_opt_t* opt, int seg) {
+  int64_t o = 0;
+  for (int q = 0; q < seg; ++q) o += opt->seg_rows[q];
+  return o;
 }
 
 extern "C" int dccf_dp_local(dccf_ctx* ctx, const dccf_model_t* model, const dccf_rand_t* rnd, const int64_t* X, const float* Y,
@@ -551,6 +575,8 @@ extern "C" int dccf_dp_local(dccf_ctx* ctx, const dccf_model_t* model, const dcc
     if (int e = dp_discard_prepared(ctx, model, dp, st)) return e;
   }
   ctx->prep_dp = 0;
+  ctx->cur_tables = prepared && ctx->prep_tables && dp->ctx == ctx && dp_tables_usable(opt, dp, model);
+  ctx->prep_tables = 0;
   if (int e = dccf_train_fwdbwd(ctx, model, rnd, X, Y, N, 1, dropout, grads, prediction, dp->loss, stream)) return e;
   if (prepared) {
     ARG_CHECK(opt->nseg >= 2 && opt->nseg <= 4, "bad segments");
@@ -567,8 +593,11 @@ extern "C" int dccf_dp_local(dccf_ctx* ctx, const dccf_model_t* model, const dcc
     const DpLay y = dp_layout(dp->cap, dp->D, opt->n - dp->dense_begin);
     const int row_blocks = (int)((dp->cap + 15) / 16);
     const int dense_blocks = (int)max((int64_t)1, min((int64_t)256, (y.nd + 255) / 256));
+    const int64_t R = model->user_num + model->item_num;
+    const int* where_r = ctx->cur_tables ? dp->pwhere + ((int64_t)parity * dp->G + dp->rank) * R : nullptr;
     hipLaunchKernelGGL(k_dp_export_list, dim3(row_blocks + dense_blocks), dim3(256), 0, st, opt->g, sg, dp->dense_begin, dp->loss,
-                       dp->buf, y, row_blocks, dp->llist, dp->lcnt + parity, dp->lflagsU, dp->lflagsV, dp->segU);
+                       dp->buf, y, row_blocks, dp->llist, dp->lcnt + parity, dp->lflagsU, dp->lflagsV, dp->segU, where_r,
+                       dp_rowoff(opt, dp->segU), dp_rowoff(opt, dp->segV));
     HIP_TRY(hipGetLastError());
     return 0;
   }
@@ -629,6 +658,15 @@ extern "C" int dccf_dp_overlap(const dccf_opt_t* opt, const dccf_dp_t* dp, int32
   pn.gV = dp_gflags(dp, 1 - parity, 1);
   pn.G = dp->G;
   pn.gkey0 = make_key(dp->seed, STREAM_CAND, next->step0_next);
+  ctx->prep_tables = 0;
+  if (dp->ctx == ctx && dp_tables_usable(opt, dp, M)) {
+    pn.R = M->user_num + M->item_num;
+    pn.nmask = dp->pmask + (int64_t)(1 - parity) * pn.R;
+    pn.nwhere = dp->pwhere + (int64_t)(1 - parity) * dp->G * pn.R;
+    pn.offU = dp_rowoff(opt, dp->segU);
+    pn.offV = dp_rowoff(opt, dp->segV);
+    ctx->prep_tables = 1;
+  }
   ctx->prep_valid = 0;
   ctx->prep_dp = 0;
   ctx->prep_pending = 1;             // committed by dccf_dp_finish (W^T is written there)
@@ -663,9 +701,22 @@ extern "C" int dccf_dp_finish(const dccf_opt_t* opt, const dccf_dp_t* dp, int32_
     } else if (ctx && ctx->prep_pending) {
       if (int e = dp_discard_prepared(ctx, next->model, dp, (hipStream_t)stream)) return e;
     }
+    // this step's import tables: built one step ahead (no scatter pass) or by k_dp_scatter_ids from the received ids
+    uint32_t* mask = dp->mask;
+    int32_t* where = dp->where;
+    bool scatter = true;
+    if (dp->ctx && dp->ctx->cur_tables) {
+      dccf_ctx* ctx = dp->ctx;
+      const int64_t R = opt->seg_rows[0] + opt->seg_rows[1];
+      mask = dp->pmask + (int64_t)parity * R;
+      where = dp->pwhere + (int64_t)parity * dp->G * R;
+      wm.reset_where = 1;
+      scatter = false;
+      ctx->cur_tables = 0;
+    }
     if (int e = dp_import_impl(dp->bufs, dp->G, nullptr, opt->n, opt->nseg, opt->seg_begin, opt->seg_rows, opt->seg_width, gf,
-                               dp->dense_begin, dp->loss_sum, dp->cap, dp->D, dp->mask, dp->where, dp->buf, &job,
-                               (hipStream_t)stream, &wm))
+                               dp->dense_begin, dp->loss_sum, dp->cap, dp->D, mask, where, dp->buf, &job,
+                               (hipStream_t)stream, &wm, scatter))
       return e;
     if (commit) {
       dccf_prep_next_commit(ctx, next->model, next->N, next->X_next, dp->seed, next->step0_next + (uint64_t)dp->rank);

@@ -65,6 +65,7 @@ class HipBackend(object):
         d.gflagsU, d.gflagsV, d.segU, d.segV = L.ptr(tr.gfU, u8), L.ptr(tr.gfV, u8), 0, 1
         d.gflagsU2, d.gflagsV2 = L.ptr(tr.gfU2, u8), L.ptr(tr.gfV2, u8)
         d.lflagsU, d.lflagsV, d.llist, d.lcnt = L.ptr(tr.lfU, u8), L.ptr(tr.lfV, u8), L.ptr(tr.llist, i64), L.ptr(tr.lcnt, i32)
+        d.ctx, d.pmask, d.pwhere = self.ctx.h, L.ptr(tr.pmask, i32), L.ptr(tr.pwhere, i32)
         d.glist, d.gcnt = L.ptr(tr.glist, i64), L.ptr(tr.gcnt, i32)
         d.mask, d.where = L.ptr(self.scratch.mask, i32), L.ptr(self.scratch.where, i32)
         self.dp = d
@@ -159,6 +160,9 @@ class ReplicatedDCCF(object):
         self.lfU, self.lfV = torch.zeros_like(self.gfU), torch.zeros_like(self.gfV)
         self.llist = torch.zeros(self.cap + 64, dtype=torch.int64, device=device)
         self.lcnt = torch.zeros(2, dtype=torch.int32, device=device)
+        R = user_num + item_num                              # import tables of prepared steps, built one step ahead
+        self.pmask = torch.zeros(2 * R, dtype=torch.int32, device=device)
+        self.pwhere = torch.full((2 * world * R,), 0x7fffffff, dtype=torch.int32, device=device)
         self.next = None
         self.glist = torch.zeros(world * self.cap + 1024, dtype=torch.int64, device=device)
         self.gcnt = torch.zeros(2, dtype=torch.int32, device=device)

@@ -304,6 +304,9 @@ typedef struct {
   uint8_t* lflagsV;          /* with llist [cap + 64] and lcnt [2] (by parity): dccf_dp_next_t only, else NULL   */
   int64_t* llist;
   int32_t* lcnt;
+  dccf_ctx* ctx;             /* the context dccf_dp_local runs on (needed when pmask / pwhere are given)              */
+  uint32_t* pmask;           /* optional [2][R] zeros and [2][G * R] 0x7fffffff (R = rows of all segments): the import */
+  int32_t* pwhere;           /* tables of a prepared step are then built one step ahead too (no k_dp_scatter_ids)    */
   int32_t segU, segV;        /* indices of those segments in opt->seg_*                                      */
   int64_t* glist;            /* unused by dccf_dp_* (the marks are bytes only); may be NULL                   */
   int32_t* gcnt;

@@ -156,6 +156,7 @@ def test_replicated_trainer_world1_equals_single_gpu_step(overlap):
     assert int(tr.tU.sum()) == 0 and int(tr.tV.sum()) == 0 and float(tr.flat_g.abs().max()) == 0.0
     assert int(tr.gfU.sum()) == 0 and int(tr.gfV.sum()) == 0
     assert sum(int(a.sum()) for a in (tr.gfU2, tr.gfV2, tr.lfU, tr.lfV)) == 0
+    assert int(tr.pmask.abs().sum()) == 0 and int((tr.pwhere != 0x7fffffff).sum()) == 0      # import tables consumed
     assert tr.be.ctx.prepared_steps() == (3 if prep else 0)
     # rows no batch touched are bit-identical (their update never sees a float atomic)
     never = torch.ones(U, dtype=torch.bool, device='cuda')
@@ -194,7 +195,8 @@ def _rank_main(rank, world, port, out, overlap):
     torch.cuda.synchronize()
     assert tr.be.ctx.prepared_steps() == (c['steps'] - 1 if prep else 0)
     np.savez(os.path.join(out, 'r%d_%s.npz' % (rank, tag)), p=tr.flat_p.cpu().numpy(), losses=np.array(losses),
-             flags=np.array([int(a.sum()) for a in (tr.tU, tr.tV, tr.gfU, tr.gfV, tr.gfU2, tr.gfV2, tr.lfU, tr.lfV)]),
+             flags=np.array([int(a.sum()) for a in (tr.tU, tr.tV, tr.gfU, tr.gfV, tr.gfU2, tr.gfV2, tr.lfU, tr.lfV)]
+                            + [int(tr.pmask.abs().sum()), int((tr.pwhere != 0x7fffffff).sum())]),
              gmax=float(tr.flat_g.abs().max()))
     dist.destroy_process_group()
 
