@@ -54,6 +54,15 @@ struct dccf_ctx {
   // replicated path: the dp part of the prepared step (global marks in set prep_parity, local list) and its schedule
   int prep_dp, prep_pending, prep_parity;
   int prep_tables, cur_tables;     // the import tables of the prepared / of the running step were built ahead
+  // slot mode of the backward (dccf_dp_local with tables): embedding gradient rows go straight into the slots of the
+  // all-gather buffer (row -> slot via slot_where), there is no export pass; and what the import needs to recompute the
+  // row of a slot (the replicated schedule of the running step)
+  const int* slot_where;
+  float* slot_rows;
+  int64_t slot_offU, slot_offV;
+  const void* cur_Xall;
+  uint64_t cur_step0;
+  int64_t cur_N;
   const void* prep_Xall;
   int64_t prep_N;
   uint64_t prep_step, prep_seed;

@@ -417,6 +417,10 @@ struct BwdArgs {
   const float *m, *Y;
   float *pred, *loss;
   int rank;
+  // slot mode (replicated path): row x of table U / V accumulates in slot_rows[slot_where[off + x]] instead of gU / gV
+  const int* slot_where;
+  float* slot_rows;
+  int64_t slot_offU, slot_offV;
 };
 
 // FOLD: what k_pair_epilogue would have stored for batch row n, recomputed by the wave that walks n (every role needs it;
@@ -487,6 +491,8 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
     const int64_t u = p.X[2 * n];
     const float* frow = p.feat + p.X[2 * n + 1] * F;
     float dmn = 0.f;
+    int64_t urow_g = u;            // where gU[u] accumulates: the row itself, or its slot of the all-gather buffer
+    if (CHUNK && role == 0 && p.slot_where) urow_g = p.slot_where[p.slot_offU + u];
     float uv[ND], asum[ND], due[ND], fb[NB];
 #pragma unroll
     for (int mt = 0; mt < ND; ++mt) {
@@ -578,7 +584,8 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
       for (int mt = 0; mt < ND; ++mt) {
         const float dt = due[mt] + __shfl_xor(due[mt], 32, 64);
         if (h == 0 && dok[mt]) {
-          atomicAdd(&p.gU[u * D + dbase + mt * 32 + c31], dt);
+          float* gu = (p.slot_where ? p.slot_rows : p.gU) + urow_g * D;
+          atomicAdd(&gu[dbase + mt * 32 + c31], dt);
           gb_acc[mt] += tot[mt];
         }
       }
@@ -658,6 +665,18 @@ __device__ __forceinline__ void bwd_dx_role(const BwdArgs& p, int dbase) {
       KEEP(dm0);
       const float dmv = lv ? dm0 : 0.f;
       const float* hrow = p.hbuf + l * DP;
+      // where the 8 candidate rows this lane will emit go (A == 2): candidate id, or in slot mode its slot of the all-gather
+      // buffer — fetched now, so the dependent lookups are over when the accumulators are ready
+      int sl8[8];
+      if (A == 2) {
+#pragma unroll
+        for (int r2 = 0; r2 < 8; ++r2) {
+          const int r = 2 * r2;
+          const int ro = min(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, rpn - 1);
+          const int ci = p.cand[n * S1 + (ro >> 1)];
+          sl8[r2] = p.slot_where ? p.slot_where[p.slot_offV + ci] : ci;
+        }
+      }
       f32x16 acc[ND];
 #pragma unroll
       for (int nt = 0; nt < ND; ++nt)
@@ -693,8 +712,9 @@ __device__ __forceinline__ void bwd_dx_role(const BwdArgs& p, int dbase) {
           for (int r = 0; r < 16; r += 2) {
             const int ro = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (ro < rpn && dd < D) {
-              const int64_t ci = p.cand[n * S1 + (ro >> 1)];
-              atomicAdd(&p.gV[ci * D + dd], acc[nt][r] + acc[nt][r + 1]);
+              const int64_t ci = sl8[r >> 1];
+              float* gv = (p.slot_where ? p.slot_rows : p.gV) + ci * D;
+              atomicAdd(&gv[dd], acc[nt][r] + acc[nt][r + 1]);
               if (p.touchedV && c31 == 0 && nt == 0) p.touchedV[ci] = 1;
             }
           }
@@ -704,7 +724,8 @@ __device__ __forceinline__ void bwd_dx_role(const BwdArgs& p, int dbase) {
             const int ro = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (ro < rpn && dd < D) {
               const int64_t ci = p.cand[n * S1 + ro / A];
-              atomicAdd(&p.gV[ci * D + dd], acc[nt][r]);
+              float* gv = p.slot_where ? p.slot_rows + (int64_t)p.slot_where[p.slot_offV + ci] * D : p.gV + ci * D;
+              atomicAdd(&gv[dd], acc[nt][r]);
               if (p.touchedV && c31 == 0 && nt == 0) p.touchedV[ci] = 1;
             }
           }
@@ -937,6 +958,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     ba.touchedU = G->touchedU; ba.touchedV = G->touchedV; ba.N = N; ba.S1 = S1; ba.A = A;
     ba.F = F; ba.NC = y.NC; ba.kscale = kscale; ba.nscale = nscale; ba.nkey = nkey; ba.sr = sr;
     ba.m = m; ba.Y = Y; ba.pred = pred; ba.loss = loss; ba.rank = rank;
+    ba.slot_where = ctx->slot_where; ba.slot_rows = ctx->slot_rows; ba.slot_offU = ctx->slot_offU; ba.slot_offV = ctx->slot_offV;
     BY_D(D, LAUNCH_BWD)
 #undef LAUNCH_BWD
 #undef LAUNCH_BWD2

@@ -336,6 +336,16 @@ struct WMirror {
   int KF, DP;
   int* cnt_reset;            // the local-list counter this step consumed (zeroed for the step after the next)
   int reset_where;           // tables built ahead (atomicMin): the owner puts the consumed where entries back to INT_MAX
+  // slot mode (the backward wrote straight into the buffer slots, no ids travelled): slot e of rank r holds the row at
+  // position e of rank r's canonical order — recomputed from the replicated schedule and the candidate stream
+  const int64_t* X_all;      // NULL: read the ids from the buffers
+  rng_key key0;
+  int64_t N, NS, item_num;
+  int S1;
+  int segU, segV;
+  // the local send buffer: its rows / dense tail are zeroed once summed (the next backward adds into them)
+  float* local_buf;
+  int self;
 };
 
 template <int APPLY>
@@ -349,6 +359,7 @@ __global__ __launch_bounds__(256) void k_dp_sum_rows(const float* __restrict__ b
     for (int64_t i = tid; i < y.nd; i += stride) {
       float s = bufs[y.dense_off + i];
       for (int r = 1; r < G; ++r) s += bufs[(int64_t)r * y.words + y.dense_off + i];
+      if (wm.local_buf) wm.local_buf[y.dense_off + i] = 0.f;
       if (APPLY < 0) {
         g[dense_begin + i] = s;
       } else {
@@ -389,10 +400,38 @@ __global__ __launch_bounds__(256) void k_dp_sum_rows(const float* __restrict__ b
     // No entry count is read here (a header word read by every group of the grid is a hot spot): an entry is live iff
     // this step's scatter pass registered exactly it — bit r of the row's mask set and where[r][row] == e.  Slots past a
     // rank's count hold ids of earlier steps (or zeros) and fail that test.
-    const int64_t id = reinterpret_cast<const int64_t*>(b + y.ids_off)[e];
+    if (wm.local_buf && r == wm.self && sub < d4) {         // (the sums below read the gathered copy, not this buffer)
+      float4* z = reinterpret_cast<float4*>(wm.local_buf + y.rows_off + (int64_t)e * y.D);
+      z[sub] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (sub + 16 < d4) z[sub + 16] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    int q;
+    int64_t row;
+    if (wm.X_all) {
+      const int64_t* X = wm.X_all + (int64_t)r * wm.N * 2;
+      if (e < wm.NS) {
+        const int64_t n = e / wm.S1;
+        const int s1 = (int)(e - n * wm.S1);
+        q = wm.segV;
+        if (s1 == 0) {
+          row = X[2 * n + 1];
+        } else {
+          const rng_key key = key_plus(wm.key0, r);
+          const u32x4 rr = philox4x32_10((uint32_t)n, (uint32_t)((s1 - 1) >> 2), key.s0, key.s1, key.k0, key.k1);
+          row = (int64_t)(((uint64_t)pick4(rr, (s1 - 1) & 3) * (uint64_t)wm.item_num) >> 32);
+        }
+      } else if (e < wm.NS + wm.N) {
+        q = wm.segU;
+        row = X[2 * (e - wm.NS)];
+      } else {
+        return;
+      }
+    } else {
+      const int64_t id = reinterpret_cast<const int64_t*>(b + y.ids_off)[e];
+      q = (int)(id >> 40);
+      row = id & ((1LL << 40) - 1);
+    }
     DPT(2);
-    const int q = (int)(id >> 40);
-    const int64_t row = id & ((1LL << 40) - 1);
     if (q >= sg.n) return;
     const int64_t gid = sg.rowoff[q] + row;
     uint32_t m = mask[gid];
@@ -577,6 +616,29 @@ extern "C" int dccf_dp_local(dccf_ctx* ctx, const dccf_model_t* model, const dcc
   ctx->prep_dp = 0;
   ctx->cur_tables = prepared && ctx->prep_tables && dp->ctx == ctx && dp_tables_usable(opt, dp, model);
   ctx->prep_tables = 0;
+  ctx->cur_Xall = X_all;
+  ctx->cur_step0 = step0;
+  ctx->cur_N = N;
+  if (ctx->cur_tables) {
+    // slot mode: the backward adds the embedding gradient rows, [dW | db] and the loss straight into this rank's all-gather
+    // buffer (slot of a row = what the tables built one step ahead say) — no export pass, g is not touched
+    const DpLay y = dp_layout(dp->cap, dp->D, opt->n - dp->dense_begin);
+    const int64_t R = model->user_num + model->item_num;
+    const int64_t oW = grads->gW - opt->g, ob = grads->gb - opt->g;
+    ARG_CHECK(oW >= dp->dense_begin && ob >= dp->dense_begin && oW < opt->n && ob < opt->n, "gW / gb must lie in the dense tail of g");
+    dccf_grads_t gs = *grads;
+    gs.gW = dp->buf + y.dense_off + (oW - dp->dense_begin);
+    gs.gb = dp->buf + y.dense_off + (ob - dp->dense_begin);
+    gs.touchedU = gs.touchedV = nullptr;
+    ctx->slot_where = dp->pwhere + ((int64_t)parity * dp->G + dp->rank) * R;
+    ctx->slot_rows = dp->buf + y.rows_off;
+    ctx->slot_offU = dp_rowoff(opt, dp->segU);
+    ctx->slot_offV = dp_rowoff(opt, dp->segV);
+    const int e = dccf_train_fwdbwd(ctx, model, rnd, X, Y, N, 1, dropout, &gs, prediction, dp->buf + 1, stream);
+    ctx->slot_where = nullptr;
+    ctx->slot_rows = nullptr;
+    return e;
+  }
   if (int e = dccf_train_fwdbwd(ctx, model, rnd, X, Y, N, 1, dropout, grads, prediction, dp->loss, stream)) return e;
   if (prepared) {
     ARG_CHECK(opt->nseg >= 2 && opt->nseg <= 4, "bad segments");
@@ -659,7 +721,8 @@ extern "C" int dccf_dp_overlap(const dccf_opt_t* opt, const dccf_dp_t* dp, int32
   pn.G = dp->G;
   pn.gkey0 = make_key(dp->seed, STREAM_CAND, next->step0_next);
   ctx->prep_tables = 0;
-  if (dp->ctx == ctx && dp_tables_usable(opt, dp, M)) {
+  if (dp->ctx == ctx && dp_tables_usable(opt, dp, M) && next->X_next == next->X_all_next + (int64_t)dp->rank * next->N * 2) {
+    pn.lm.list = nullptr;            // slot mode: no export pass, hence no list of this rank's rows
     pn.R = M->user_num + M->item_num;
     pn.nmask = dp->pmask + (int64_t)(1 - parity) * pn.R;
     pn.nwhere = dp->pwhere + (int64_t)(1 - parity) * dp->G * pn.R;
@@ -705,6 +768,8 @@ extern "C" int dccf_dp_finish(const dccf_opt_t* opt, const dccf_dp_t* dp, int32_
     uint32_t* mask = dp->mask;
     int32_t* where = dp->where;
     bool scatter = true;
+    wm.local_buf = dp->buf;          // rows and dense tail of the send buffer are zero again after every step
+    wm.self = dp->rank;
     if (dp->ctx && dp->ctx->cur_tables) {
       dccf_ctx* ctx = dp->ctx;
       const int64_t R = opt->seg_rows[0] + opt->seg_rows[1];
@@ -712,6 +777,14 @@ extern "C" int dccf_dp_finish(const dccf_opt_t* opt, const dccf_dp_t* dp, int32_
       where = dp->pwhere + (int64_t)parity * dp->G * R;
       wm.reset_where = 1;
       scatter = false;
+      wm.X_all = (const int64_t*)ctx->cur_Xall;
+      wm.key0 = make_key(dp->seed, STREAM_CAND, ctx->cur_step0);
+      wm.N = ctx->cur_N;
+      wm.S1 = dp->S + 1;
+      wm.NS = ctx->cur_N * (dp->S + 1);
+      wm.item_num = dp->item_num;
+      wm.segU = dp->segU;
+      wm.segV = dp->segV;
       ctx->cur_tables = 0;
     }
     if (int e = dp_import_impl(dp->bufs, dp->G, nullptr, opt->n, opt->nseg, opt->seg_begin, opt->seg_rows, opt->seg_width, gf,

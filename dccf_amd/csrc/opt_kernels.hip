@@ -39,6 +39,10 @@ extern "C" int dccf_ctx_create(dccf_ctx** out, int device) {
   c->prep_valid = 0;
   c->prep_hits = 0;
   c->prep_dp = c->prep_pending = c->prep_parity = 0;
+  c->prep_tables = c->cur_tables = 0;
+  c->slot_where = nullptr;
+  c->slot_rows = nullptr;
+  c->cur_Xall = nullptr;
   c->prep_Xall = nullptr;
   *out = c;
   return 0;
