@@ -427,13 +427,38 @@ struct BwdArgs {
 // 66 loads and a few shuffles per n instead of a kernel between forward and backward).  16-lane groups: even groups take
 // row n, odd groups its BPR partner (n +- N/2), so one xor-16 shuffle gives every lane both predictions.  Returns
 // d loss / d (mean_a m[n][s]) for s = lane & 15, valid in lanes 0 .. S1-1; `emit` (one role) writes prediction and loss.
-__device__ __forceinline__ float wave_dm(const BwdArgs& p, int64_t n, float& lsum, bool emit) {
+// Split in two so that a wave can fetch the operands of its NEXT batch row while it works on the current one.
+struct DmIn {
+  float e, m[4], y;          // Expo[u, cand[row][s]], m[(row, s, a)] for a < A <= 4, Y[row] (rank 0)
+};
+__device__ __forceinline__ void wave_dm_load(const BwdArgs& p, int64_t n, DmIn& in) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, s = min(lane & 15, p.S1 - 1);      // clamped: unconditional loads
+  const int64_t B = p.N / 2;
+  const int64_t other = p.rank == 1 ? (n < B ? n + B : n - B) : n;
+  const int64_t row = (g & 1) ? other : n;
+  in.e = p.dmns[row * p.S1 + s];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) in.m[a] = p.m[(row * p.S1 + s) * p.A + min(a, p.A - 1)];
+  in.y = 0.f;
+  if (p.rank != 1) in.y = p.Y[row];
+}
+__device__ __forceinline__ float wave_dm_calc(const BwdArgs& p, int64_t n, const DmIn& in, float& lsum, bool emit) {
   const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15;
   const int64_t B = p.N / 2;
   const int64_t other = p.rank == 1 ? (n < B ? n + B : n - B) : n;
   const int64_t row = (g & 1) ? other : n;
-  float w;
-  const float pm = row_predict<16>(p.dmns, p.m, row, s, p.S1, p.A, w);
+  // (row_predict<16>, operand for operand)
+  const bool valid = s < p.S1;
+  const float e = valid ? in.e : -INFINITY;
+  const float mx = group_max<16>(e);
+  const float ex = valid ? expf(e - mx) : 0.f;
+  const float w0 = ex / group_sum<16>(ex);
+  float tot = 0.f;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+    if (a < p.A) tot += group_sum<16>(valid ? w0 * in.m[a] : 0.f);
+  const float w = w0 / (float)p.A;
+  const float pm = tot / (float)p.A;
   float dm;
   if (p.rank == 1) {
     const float po = __shfl_xor(pm, 16, 64);
@@ -448,7 +473,7 @@ __device__ __forceinline__ float wave_dm(const BwdArgs& p, int64_t n, float& lsu
       if (n < B) lsum += -logf(sg);
     }
   } else {
-    const float diff = pm - p.Y[row];
+    const float diff = pm - in.y;
     dm = w * (2.f * diff / (float)p.N);
     if (emit && lane == 0) {
       p.pred[n] = pm;
@@ -487,18 +512,52 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
     dok[mt] = dbase + mt * 32 + c31 < D;
   }
   float lsum = 0.f;
+  // One wave per SIMD walks its batch rows alone, so nothing hides a load round trip but the code itself: the ids of the
+  // NEXT batch row are fetched while this one is worked on, the row's own operands (user row, feature row, first batch of
+  // k-steps, the folded epilogue) go out together, and every batch of four k-steps is fetched while the previous one is in
+  // the MFMA pipe (5 exposed round trips per batch row -> 1; in-kernel timestamps: main loop 17.5 -> see DESIGN.md).
+  // All loads are unconditional from clamped addresses (a load inside `cond ? load : 0` makes hipcc branch around it and
+  // wait vmcnt(0)); rows past the batch row read its last row and are zeroed through dm.
+#define BWD_LOAD_BATCH(J0, HV, DMV, BQ)                                                                          \
+  _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                             \
+    const int r_ = 2 * ((J0) + jj) + h;                                                                          \
+    const int rc_ = min(r_, rpn - 1);                                                                            \
+    const int64_t lr_ = n * rpn + rc_;                                                                           \
+    const int64_t ns_ = n * S1 + rc_ / A;                                                                        \
+    if (!FOLD) DMV[jj] = p.dmns[ns_];                                                                            \
+    _Pragma("unroll") for (int mt = 0; mt < ND; ++mt) HV[jj][mt] = p.hbuf[lr_ * DP + dbase + mt * 32 + c31];     \
+    if (!CHUNK) {                                                                                                \
+      const float* vrow_ = p.V + (int64_t)p.cand[ns_] * D;                                                       \
+      _Pragma("unroll") for (int nt = 0; nt < NB; ++nt) BQ[jj][nt] = vrow_[min(nt * 32 + c31, D - 1)];           \
+    } else if (MODE == 1) {                                                                                      \
+      _Pragma("unroll") for (int o = 0; o < NB; ++o)                                                             \
+        BQ[jj][o] = p.noise[lr_ * F + min(role * 128 + 32 * o + c31, F - 1)];                                    \
+    }                                                                                                            \
+  }
+  int64_t u_nx = 0, i_nx = 0;
+  DmIn din;
+  if (n0 < p.N) {
+    u_nx = p.X[2 * n0];
+    i_nx = p.X[2 * n0 + 1];
+    if (FOLD) wave_dm_load(p, n0, din);
+  }
   for (int64_t n = n0; n < p.N; n += nstride) {
-    const int64_t u = p.X[2 * n];
-    const float* frow = p.feat + p.X[2 * n + 1] * F;
+    const int64_t u = u_nx;
+    const float* frow = p.feat + i_nx * F;
+    DmIn dnx;
+    {                                  // the next batch row's ids and epilogue operands travel while this one is computed
+      const int64_t nn = min(n + nstride, p.N - 1);
+      u_nx = p.X[2 * nn];
+      i_nx = p.X[2 * nn + 1];
+      if (FOLD) wave_dm_load(p, nn, dnx);
+    }
     float dmn = 0.f;
     int64_t urow_g = u;            // where gU[u] accumulates: the row itself, or its slot of the all-gather buffer
     if (CHUNK && role == 0 && p.slot_where) urow_g = p.slot_where[p.slot_offU + u];
     float uv[ND], asum[ND], due[ND], fb[NB];
 #pragma unroll
     for (int mt = 0; mt < ND; ++mt) {
-      const float ux = p.U[u * D + min(dbase + mt * 32 + c31, D - 1)];
-      KEEP(ux);
-      uv[mt] = dok[mt] ? ux : 0.f;
+      uv[mt] = p.U[u * D + min(dbase + mt * 32 + c31, D - 1)];
       asum[mt] = 0.f;
       due[mt] = 0.f;
     }
@@ -506,41 +565,27 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
 #pragma unroll
       for (int o = 0; o < NB; ++o) fb[o] = frow[min(role * 128 + 32 * o + c31, F - 1)];   // columns >= F are never stored
     }
+    float hv[4][ND], dmv[4], bq[4][NB];
+    BWD_LOAD_BATCH(0, hv, dmv, bq)
+    if (FOLD) {
+      dmn = wave_dm_calc(p, n, din, lsum, CHUNK && role == 0 && dbase == 0);
+      din = dnx;
+    }
+#pragma unroll
+    for (int mt = 0; mt < ND; ++mt) {
+      KEEP(uv[mt]);
+      uv[mt] = dok[mt] ? uv[mt] : 0.f;
+    }
+    if (n == n0) TRACEB(role, 3);
     for (int j0 = 0; j0 < KS; j0 += 4) {
-      float hv[4][ND], dmv[4], bq[4][NB];
-      int64_t lrow[4];
-      bool lvv[4];
-      // the loads of four k-steps are issued together; every load is unconditional from a clamped address (rows past
-      // the n read its last row and are zeroed through dm) — a load inside `cond ? load : 0` makes hipcc branch around it
-      // and wait vmcnt(0), which serialises the k-steps
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const int r = 2 * (j0 + jj) + h;
-        const bool lv = r < rpn;
-        const int rc = lv ? r : rpn - 1;
-        lrow[jj] = n * rpn + rc;
-        const int64_t ns = n * S1 + rc / A;
-        if (!FOLD) dmv[jj] = p.dmns[ns];
-        lvv[jj] = lv;
-#pragma unroll
-        for (int mt = 0; mt < ND; ++mt) hv[jj][mt] = p.hbuf[lrow[jj] * DP + dbase + mt * 32 + c31];
-        if (!CHUNK) {
-          const float* vrow = p.V + (int64_t)p.cand[ns] * D;
-#pragma unroll
-          for (int nt = 0; nt < NB; ++nt) bq[jj][nt] = vrow[min(nt * 32 + c31, D - 1)];
-        } else if (MODE == 1) {
-#pragma unroll
-          for (int o = 0; o < NB; ++o) bq[jj][o] = p.noise[lrow[jj] * F + min(role * 128 + 32 * o + c31, F - 1)];
-        }
-      }
+      float hv2[4][ND], dmv2[4], bq2[4][NB];
+      BWD_LOAD_BATCH(j0 + 4, hv2, dmv2, bq2)          // the next batch (past the end: clamped rows, never used)
       if (FOLD) {
-        // the row's epilogue, computed while the first batch of loads is in flight (its own loads join that round trip)
-        if (j0 == 0) dmn = wave_dm(p, n, lsum, CHUNK && role == 0 && dbase == 0);
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) dmv[jj] = __shfl(dmn, min(2 * (j0 + jj) + h, rpn - 1) / A, 64);
       }
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {              // pin the batch (one wait), then mask
+      for (int jj = 0; jj < 4; ++jj) {              // pin the current batch (its loads only), then mask
         KEEP(dmv[jj]);
 #pragma unroll
         for (int mt = 0; mt < ND; ++mt) KEEP(hv[jj][mt]);
@@ -548,13 +593,14 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
 #pragma unroll
           for (int o = 0; o < NB; ++o) KEEP(bq[jj][o]);
         }
-        dmv[jj] = lvv[jj] ? dmv[jj] : 0.f;
+        dmv[jj] = 2 * (j0 + jj) + h < rpn ? dmv[jj] : 0.f;
 #pragma unroll
         for (int mt = 0; mt < ND; ++mt) hv[jj][mt] = dok[mt] ? hv[jj][mt] : 0.f;
       }
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
-        if (CHUNK && MODE == 0) noise4((uint32_t)lrow[jj], (uint32_t)(role * 32 + c31), p.nkey, p.nscale, bq[jj]);
+        if (CHUNK && MODE == 0)
+          noise4((uint32_t)(n * rpn + min(2 * (j0 + jj) + h, rpn - 1)), (uint32_t)(role * 32 + c31), p.nkey, p.nscale, bq[jj]);
         float a[ND];
 #pragma unroll
         for (int mt = 0; mt < ND; ++mt) {
@@ -567,7 +613,18 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
 #pragma unroll
           for (int o = 0; o < NB; ++o) acc[mt][o] = MFMA32(a[mt], bq[jj][o], acc[mt][o]);
       }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {              // next batch becomes current
+        dmv[jj] = dmv2[jj];
+#pragma unroll
+        for (int mt = 0; mt < ND; ++mt) hv[jj][mt] = hv2[jj][mt];
+        if (!CHUNK || MODE == 1) {
+#pragma unroll
+          for (int o = 0; o < NB; ++o) bq[jj][o] = bq2[jj][o];
+        }
+      }
     }
+    if (n == n0) TRACEB(role, 4);
     float tot[ND];
 #pragma unroll
     for (int mt = 0; mt < ND; ++mt) tot[mt] = asum[mt] + __shfl_xor(asum[mt], 32, 64);
@@ -627,6 +684,7 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
   if (FOLD && CHUNK && role == 0 && dbase == 0 && lane == 0 && lsum != 0.f) atomicAdd(p.loss, lsum);
   TRACEB(role, 2);
 }
+#undef BWD_LOAD_BATCH
 
 // role "dx": gV[cand] += dz W_i   (MFMA: M = rows of n, N = d', K = d)
 template <int D, bool FOLD>
@@ -653,7 +711,11 @@ __device__ __forceinline__ void bwd_dx_role(const BwdArgs& p, int dbase) {
   for (int64_t n = n0; n < p.N; n += nstride) {
     const float* urow = p.U + p.X[2 * n] * D;
     float dmn = 0.f, lnone = 0.f;
-    if (FOLD) dmn = wave_dm(p, n, lnone, false);
+    if (FOLD) {
+      DmIn din;
+      wave_dm_load(p, n, din);
+      dmn = wave_dm_calc(p, n, din, lnone, false);
+    }
     for (int t = 0; t < RT; ++t) {
       const int rr = t * 32 + c31;
       const bool lv = rr < rpn;
@@ -919,7 +981,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     prof_end(ctx, 2, st);
   }
   // training with at most 16 candidates per row: the pair epilogue is folded into the backward (wave_dm)
-  const bool fold = train && S1 <= 16 && N <= (getenv("DCCF_FOLD_MAX_N") ? atoll(getenv("DCCF_FOLD_MAX_N")) : 1024);
+  const bool fold = train && S1 <= 16 && A <= 4 && N <= (getenv("DCCF_FOLD_MAX_N") ? atoll(getenv("DCCF_FOLD_MAX_N")) : 1024);
   if (!fold) {
     const int64_t units = (train && rank == 1) ? N / 2 : N;
     const int GS = S1 <= 16 ? 16 : (S1 <= 32 ? 32 : 64);
