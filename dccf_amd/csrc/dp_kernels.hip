@@ -9,6 +9,12 @@
 //                       replica computes bit-identical sums and the replicas never drift apart), sets the "touched" bytes,
 //                       dense tail = sum over ranks in rank order.  No atomics on data: a per-row bit mask of the
 //                       contributing ranks + a where-table make the rank-ordered walk possible.
+//   dccf_dp_local / dccf_dp_overlap / dccf_dp_finish   one step in three calls around the collective.  With a
+//                       dccf_dp_next_t every step prepares the next inside its optimizer launches (candidates, W^T, the
+//                       rows any rank will touch, the mask / where tables of the next import): the backward then writes
+//                       its gradient rows straight into the buffer slots the tables name ("slot mode": no export pass, no
+//                       ids in the payload, no table pass after the wait) and a step is forward, backward | all-gather ||
+//                       untouched-row optimizer pass | rank-ordered sums + optimizer.
 //
 // Buffer of one rank (32-bit words): [count | loss | pad pad | ids int64[cap] | rows fp32[cap][D] | dense fp32[nd]].
 #include "common.hpp"
