@@ -103,6 +103,8 @@ struct dccf_opt_args;      // == dccf_opt_t of include/dccf_hip.h
 int dccf_opt_phase(const void* o, int phase, const int64_t* list, const int* cnt, int64_t max_rows, hipStream_t st);
 struct PrepNext;
 int dccf_opt_all_prep(const void* o, const PrepNext* pn, hipStream_t st);
+struct OptJob;
+int dccf_opt_job(const void* o, OptJob* out);     // the validated job of a dccf_opt_t (for kernels that host a pass)
 // phase 1 (rows whose byte in `flags` is 0) + the next step's slots / marks in the same launch (dccf_dp_overlap)
 int dccf_opt_untouched_prep(const void* o, uint8_t* const* flags, const PrepNext* pn, hipStream_t st);
 // dccf_kernels.hip: workspace pointers / key of the step (X_next, N, step_next) into pn (w_begin / w_end / blocks and the

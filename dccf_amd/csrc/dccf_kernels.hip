@@ -21,6 +21,7 @@
 // rounded to 32/64, FP = F rounded up to 2, 6 or 7 chunks of 128); h [L,DP]; m [L]; dmns [N*S1] (holds the gathered
 // exposures Expo[u, cand] between k_prep and k_pair_epilogue, d loss / d mean_a m afterwards).
 #include "common.hpp"
+#include "opt_device.hpp"
 
 // No implicit FMA contraction in this file: a*b+c written as two operations stays two roundings (explicit fmaf() calls
 // are still FMAs).  It keeps "fused draws == injected draws" bit for bit and the optimizer in torch's op order.
@@ -421,6 +422,11 @@ struct BwdArgs {
   const int* slot_where;
   float* slot_rows;
   int64_t slot_offU, slot_offV;
+  // hosted optimizer pass (dccf_train_step overlap == 2): the grid rows past the roles run the untouched-row pass of
+  // `oj` while the roles compute — a backward workgroup is one wave per SIMD at <= 256 VGPRs, so a second workgroup fits
+  // beside it on every CU, and the pass needs HBM, not the VALU / MFMA pipe
+  OptJob oj;
+  int opt_rows_y;            // grid rows that host it (0: none)
 };
 
 // FOLD: what k_pair_epilogue would have stored for batch row n, recomputed by the wave that walks n (every role needs it;
@@ -809,6 +815,15 @@ __global__ __launch_bounds__(64 * BWD_NW) BWD_WPE void k_bwd(BwdArgs p) {
   constexpr int GY = D_ <= 64 ? 1 : D_ / 64;
   const int role = blockIdx.y / GY;
   const int dbase = (blockIdx.y % GY) * DW;
+  if ((int)blockIdx.y >= (p.NC + 2) * GY) {            // hosted untouched-row optimizer pass
+    opt_resolve(p.oj.a);
+    const int64_t bid = (int64_t)(blockIdx.y - (p.NC + 2) * GY) * gridDim.x + blockIdx.x;
+    const int64_t nblk = (int64_t)p.opt_rows_y * gridDim.x;
+    if (p.oj.kind == DCCF_OPT_GD) opt_untouched_pass<DCCF_OPT_GD, 4>(p.oj, bid, nblk, 64 * BWD_NW);
+    else if (p.oj.kind == DCCF_OPT_ADAGRAD) opt_untouched_pass<DCCF_OPT_ADAGRAD, 4>(p.oj, bid, nblk, 64 * BWD_NW);
+    else opt_untouched_pass<DCCF_OPT_ADAM, 4>(p.oj, bid, nblk, 64 * BWD_NW);
+    return;
+  }
   if (role < p.NC) bwd_col_role<D_, MODE, true, FOLD>(p, red, role, dbase);
   else if (role == p.NC) bwd_col_role<D_, MODE, false, FOLD>(p, red, role, dbase);
   else bwd_dx_role<D_, FOLD>(p, dbase);
@@ -879,6 +894,7 @@ void dccf_prep_next_commit(dccf_ctx* ctx, const dccf_model_t* M, int64_t N, cons
 struct StepPlan {
   const dccf_opt_t* opt;
   bool overlap;
+  bool hosted;               // overlap == 2: the untouched-row pass rides in the backward launch (no side stream)
   MarkPlan mark;
   int64_t max_rows;
   const int64_t* X_next;     // same N, Philox step `step_next`: prepared inside the optimizer launch (NULL = not known)
@@ -947,7 +963,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
                        mark);
     prof_end(ctx, 0, st);
   }
-  if (plan && plan->overlap) {
+  if (plan && plan->overlap && !plan->hosted) {
     // fork: rows NOT on this batch's list see only the l2 term -> their optimizer pass needs nothing from this step
     HIP_TRY(hipEventRecord(ctx->ev_fork, st));
     HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
@@ -1000,7 +1016,9 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     const int roles = (y.NC + 2) * y.GY;
     // small batches: ~1 workgroup per CU; large ones: ~4 per CU (4 waves per SIMD fill the shared VALU / fp32-MFMA pipe)
     const int64_t gx = max((int64_t)1, min((N + BWD_NW - 1) / BWD_NW, (int64_t)max(1, (N >= 2048 ? 1024 : 256) / roles)));
-    const dim3 grid((unsigned)gx, (unsigned)roles);
+    // hosted optimizer pass: as many extra workgroups as CUs (one beside each role workgroup)
+    const int opt_rows_y = (plan && plan->overlap && plan->hosted) ? (int)(((getenv("DCCF_HOSTED_WGS") ? atoll(getenv("DCCF_HOSTED_WGS")) : 256) + gx - 1) / gx) : 0;
+    const dim3 grid((unsigned)gx, (unsigned)(roles + opt_rows_y));
     const size_t smem = (size_t)4 * 32 * 64 * 4;
     prof_begin(ctx, st);
 #define LAUNCH_BWD3(D_, MODE_, FOLD_)                                                                                \
@@ -1021,6 +1039,11 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     ba.F = F; ba.NC = y.NC; ba.kscale = kscale; ba.nscale = nscale; ba.nkey = nkey; ba.sr = sr;
     ba.m = m; ba.Y = Y; ba.pred = pred; ba.loss = loss; ba.rank = rank;
     ba.slot_where = ctx->slot_where; ba.slot_rows = ctx->slot_rows; ba.slot_offU = ctx->slot_offU; ba.slot_offV = ctx->slot_offV;
+    memset(&ba.oj, 0, sizeof(ba.oj));
+    ba.opt_rows_y = opt_rows_y;
+    if (opt_rows_y) {
+      if (int e = dccf_opt_job(plan->opt, &ba.oj)) return e;
+    }
     BY_D(D, LAUNCH_BWD)
 #undef LAUNCH_BWD
 #undef LAUNCH_BWD2
@@ -1031,7 +1054,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
   if (plan) {
     prof_begin(ctx, st);
     if (plan->overlap) {
-      HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));
+      if (!plan->hosted) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));
       if (int e = dccf_opt_phase(plan->opt, OPT_PHASE_TOUCHED, plan->mark.list, plan->mark.cnt, plan->max_rows, st)) return e;
     } else if (plan->X_next && fused_cand && rnd->k_dev == nullptr && plan->opt->p <= M->W &&
                M->W + (int64_t)D * (D + F) <= plan->opt->p + plan->opt->n && (M->W - plan->opt->p) % 4 == 0) {
@@ -1061,6 +1084,7 @@ extern "C" int dccf_train_step(dccf_ctx* ctx, const dccf_model_t* M, const dccf_
   memset(&plan, 0, sizeof(plan));
   plan.opt = opt;
   plan.overlap = opt->overlap != 0 && N > 0;
+  plan.hosted = opt->overlap == 2;
   plan.X_next = (N > 0 && rank == 1) ? X_next : nullptr;
   plan.step_next = step_next;
   if (plan.overlap) {

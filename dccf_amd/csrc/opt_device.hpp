@@ -61,6 +61,63 @@ struct OptJob {
   RowSegs sg;
 };
 
+// The untouched-row pass (phase 1 of the two-phase step) as a device function, for kernels that host it as extra
+// workgroups (k_bwd): float4 slots of the row segments whose row byte is 0 get the gradient-free update; everything else
+// (marked rows, the dense tail) is left to the touched-row pass.  UN slots in flight per thread: the hosting workgroups
+// are few (4 waves per CU), so the memory-level parallelism has to come from the lane.
+template <int KIND, int UN>
+__device__ __forceinline__ void opt_untouched_pass(const OptJob& j, int64_t bid, int64_t nblk, int nthreads) {
+  float* __restrict__ p = j.p;
+  float* __restrict__ s1 = j.s1;
+  float* __restrict__ s2 = j.s2;
+  const RowSegs& sg = j.sg;
+  const int64_t n4 = j.n / 4;
+  const int64_t stride = nblk * nthreads;
+  int wsh[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) wsh[q] = q < sg.n ? 31 - __clz(sg.width[q]) : 0;
+  // software-pipelined: the loads of the next UN slots are in flight while the current ones are computed and stored (the
+  // hosting kernel gives this pass one wave per SIMD, so nothing else overlaps its memory latency)
+  float4 pv[UN], av[UN], bv[UN], pn[UN], an[UN], bn[UN];
+  uint8_t fv[UN], fn[UN];
+#define OPT_UP_LOAD(I0, PV, AV, BV, FV)                                                                    \
+  _Pragma("unroll") for (int u = 0; u < UN; ++u) {                                                         \
+    const int64_t i_ = (I0) + u * stride;                                                                  \
+    const int64_t ic_ = min(i_, n4 - 1);                                                                   \
+    const int64_t e_ = ic_ * 4;                                                                            \
+    const uint8_t* fl_ = nullptr;                                                                          \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                          \
+      if (q < sg.n && e_ >= sg.begin[q] && e_ < sg.end[q]) fl_ = sg.flags[q] + ((e_ - sg.begin[q]) >> wsh[q]); \
+    PV[u] = reinterpret_cast<const float4*>(p)[ic_];                                                       \
+    AV[u] = BV[u] = make_float4(0, 0, 0, 0);                                                               \
+    if (KIND != DCCF_OPT_GD) AV[u] = reinterpret_cast<const float4*>(s1)[ic_];                             \
+    if (KIND == DCCF_OPT_ADAM) BV[u] = reinterpret_cast<const float4*>(s2)[ic_];                           \
+    FV[u] = (i_ < n4 && fl_ != nullptr) ? *fl_ : (uint8_t)1;      /* 1 = not this pass's slot */           \
+  }
+  int64_t i0 = bid * nthreads + threadIdx.x;
+  if (i0 >= n4) return;
+  OPT_UP_LOAD(i0, pv, av, bv, fv)
+  for (; i0 < n4; i0 += stride * UN) {
+    OPT_UP_LOAD(i0 + stride * UN, pn, an, bn, fn)
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (fv[u] == 0) {
+        const int64_t i = i0 + u * stride;
+        float4 gv = make_float4(0, 0, 0, 0);
+        opt_elem<KIND>(pv[u].x, gv.x, av[u].x, bv[u].x, j.a);
+        opt_elem<KIND>(pv[u].y, gv.y, av[u].y, bv[u].y, j.a);
+        opt_elem<KIND>(pv[u].z, gv.z, av[u].z, bv[u].z, j.a);
+        opt_elem<KIND>(pv[u].w, gv.w, av[u].w, bv[u].w, j.a);
+        reinterpret_cast<float4*>(p)[i] = pv[u];
+        if (KIND != DCCF_OPT_GD) reinterpret_cast<float4*>(s1)[i] = av[u];
+        if (KIND == DCCF_OPT_ADAM) reinterpret_cast<float4*>(s2)[i] = bv[u];
+      }
+      pv[u] = pn[u]; av[u] = an[u]; bv[u] = bn[u]; fv[u] = fn[u];
+    }
+  }
+#undef OPT_UP_LOAD
+}
+
 // opt_kernels.hip: validation + bias corrections (host side) of one optimizer step
 int opt_make_job(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t n, float lr, float wd, float l2, float clip,
                  int64_t step, const int64_t* k_dev, int32_t nseg, const int64_t* seg_begin, const int64_t* seg_rows,

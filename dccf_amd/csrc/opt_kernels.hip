@@ -452,6 +452,8 @@ static int opt_job(const void* ov, OptJob* out) {
                   o->seg_begin, o->seg_rows, o->seg_width, o->seg_flags, out);
 }
 
+int dccf_opt_job(const void* ov, OptJob* out) { return opt_job(ov, out); }
+
 int dccf_opt_phase(const void* ov, int phase, const int64_t* list, const int* cnt, int64_t max_rows, hipStream_t st) {
   OptJob j;
   if (int e = opt_job(ov, &j)) return e;

@@ -147,7 +147,9 @@ int dccf_dense_opt_phase(int32_t kind, float* p, float* g, float* s1, float* s2,
  * backward, + l2, clip, optimizer step, zero_grad.  Same results, bit for bit, as dccf_train_fwdbwd followed by
  * dccf_dense_opt_step_rows.  With overlap != 0 the optimizer pass over the rows this batch does NOT touch (all but a few
  * thousand of the U/V rows: their gradient is the l2 term alone, independent of the batch) runs on the context's
- * low-priority side stream WHILE forward/backward run on `stream`; the touched rows + W, b follow after the backward.
+ * low-priority side stream WHILE forward/backward run on `stream` (overlap == 1) or as extra workgroups of the backward
+ * launch (overlap == 2: a backward workgroup is one wave per SIMD, a second workgroup fits beside it on every CU); the
+ * touched rows + W, b follow after the backward.  Both are measured options, not the default.
  * Needs grads->touchedU / touchedV == the flags of the segments that hold model->U / model->V, 4-byte aligned and padded
  * to a multiple of 4 bytes.
  * X_next (optional, overlap == 0): the NEXT call's batch — same N, fused draws (rnd.mode 1) with Philox step `step_next`.

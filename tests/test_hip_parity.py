@@ -535,7 +535,8 @@ def test_large_batch_forward_equals_small_batches(L, ctx):
 @pytest.mark.parametrize('opt_name,B,l2,D', [('gd', 128, 0.05, 64), ('gd', 600, 0.05, 64), ('adam', 128, 1e-4, 64),
                                              ('adagrad', 37, 1e-4, 64), ('gd', 64, 0.05, 128), ('gd', 50, 0.05, 16)])
 def test_overlapped_train_step_equals_split_step(L, opt_name, B, l2, D):
-    """dccf_train_step with the untouched-row optimizer pass on the side stream == forward/backward followed by the
+    """dccf_train_step with the untouched-row optimizer pass on the side stream ('overlap'), hosted as extra workgroups of
+    the backward launch ('hosted'), or with every step prepared by the one before ('prep') == forward/backward followed by the
     row-aware dense step over several steps (duplicate users/items inside a batch included).  Same arithmetic per
     element; the only run-to-run difference is the order of the float atomics inside the backward.  So: rows no batch
     touched are bit-identical; under GD (no amplification; l2 large enough that one missed or doubled row update would
@@ -551,7 +552,7 @@ def test_overlapped_train_step_equals_split_step(L, opt_name, B, l2, D):
     gen = torch.Generator(device='cuda').manual_seed(9)
     full = torch.stack([torch.stack([torch.randint(0, U // 2 if k % 2 else 40, (2 * B,), generator=gen, device='cuda'),
                                      torch.randint(0, I, (2 * B,), generator=gen, device='cuda')], 1) for k in range(6)])
-    for mode in ('split', 'step', 'overlap', 'prep'):
+    for mode in ('split', 'step', 'overlap', 'prep', 'hosted'):
         m = DCCF(path=None, dataset=None, sentence_model=None, sample_num=10, attribute_num=2, std=0.1, label_min=0, label_max=1,
                  feature_num=0, user_num=U, item_num=I, u_vector_size=D, i_vector_size=D, n_layers=1, random_seed=11,
                  model_path='/tmp/x.pt', feature_embedding=feat, expo_prob=expo)
@@ -572,7 +573,7 @@ def test_overlapped_train_step_equals_split_step(L, opt_name, B, l2, D):
             elif mode == 'prep':      # the optimizer launch of step k draws step k + 1's candidates and writes W^T
                 out = m.train_step(batch, X_next=full[k + 1] if k < 5 else None)
             else:
-                out = m.train_step(batch, overlap={'step': 0, 'overlap': 1}[mode])
+                out = m.train_step(batch, overlap={'step': 0, 'overlap': 1, 'hosted': 2}[mode])
             preds.append(out['prediction'].clone())
         torch.cuda.synchronize()
         assert m.ctx.prepared_steps() == (5 if mode == 'prep' else 0)
