@@ -376,6 +376,76 @@ def test_large_batch_properties(L, ctx):
     close(a.mean().reshape(1), c.mean().reshape(1).cpu().numpy(), 5e-2, 1e-3, 'step-to-step mean')
 
 
+def test_tables_beyond_2g_elements_equal_compact_tables(L):
+    """BASELINE config 5 territory: a user table of 17 M x 128 = 2.2e9 elements (flat offsets beyond 2^31, 8.7 GB) cannot be
+    checked by the oracle, so it is checked by a size-independent property: two training steps (forward, BPR, backward,
+    dense l2 + GD step, second step prepared by the first) on the big table must equal the same steps on a COMPACT table
+    that holds only the users the batches touch — the fused draws depend on (seed, step, batch row), not on the table.
+    Touched rows, V, W, b and the predictions agree to the float-atomic tolerance; an untouched row at the far end of the
+    big table moved by exactly the l2 term."""
+    from dccf_amd.models import DCCF, FusedOptimizer
+    if torch.cuda.get_device_properties(0).total_memory < 100e9:
+        pytest.skip('needs ~30 GB of HBM')
+    U, I, D, F, S, A, B = 17_000_000, 5000, 128, 64, 10, 2, 64
+    g = torch.Generator(device='cuda').manual_seed(3)
+    feat = torch.randn(I, F, generator=g, device='cuda') * 0.3
+    ips = dict(P=torch.randn(U, 4, generator=g, device='cuda') * 0.3, Q=torch.randn(I, 4, generator=g, device='cuda') * 0.3,
+               bu=torch.randn(U, generator=g, device='cuda') * 0.1, bi=torch.randn(I, generator=g, device='cuda') * 0.1,
+               prop=torch.rand(I, generator=g, device='cuda'), b0=0.1, M=0.1)
+    # users from the whole range, the last rows of the table included (element offsets up to 2.176e9)
+    us = torch.cat([torch.randint(0, U, (2 * B - 3,), generator=g, device='cuda'),
+                    torch.tensor([U - 1, U - 2, 16_900_000], device='cuda')])
+    full = torch.stack([torch.stack([us[torch.randperm(2 * B, generator=g, device='cuda')],
+                                     torch.randint(0, I, (2 * B,), generator=g, device='cuda')], 1) for _ in range(2)])
+    uniq, inv = torch.unique(full[:, :, 0], return_inverse=True)
+    lr, l2 = 0.05, 0.01
+    res = []
+    for mode in ('big', 'compact'):
+        Um = U if mode == 'big' else uniq.numel()
+        sub = (lambda t: t) if mode == 'big' else (lambda t: t[uniq].contiguous())
+        m = DCCF(path=None, dataset=None, sentence_model=None, sample_num=S, attribute_num=A, std=0.1, label_min=0, label_max=1,
+                 feature_num=0, user_num=Um, item_num=I, u_vector_size=D, i_vector_size=D, n_layers=1, random_seed=31,
+                 model_path='/tmp/x.pt', feature_embedding=feat,
+                 ips_factors=dict(ips, P=sub(ips['P']), bu=sub(ips['bu'])))
+        torch.manual_seed(1)
+        m.apply(m.init_paras)
+        P = dict(m.named_parameters())
+        if mode == 'big':
+            big_rows = P['uid_embeddings.weight'].detach()[uniq].clone()
+            keep = [P[k].detach().clone() for k in ('iid_embeddings.weight', 'mlp.0.weight', 'mlp.0.bias')]
+            far = P['uid_embeddings.weight'].detach()[U - 3].clone()          # never in a batch
+        else:
+            with torch.no_grad():
+                P['uid_embeddings.weight'].copy_(big_rows)
+                for k, v in zip(('iid_embeddings.weight', 'mlp.0.weight', 'mlp.0.bias'), keep):
+                    P[k].copy_(v)
+        m.optimizer = FusedOptimizer(m, 'gd', lr, l2)
+        m.train()
+        y = torch.cat([torch.ones(B, device='cuda'), torch.zeros(B, device='cuda')])
+        Xs = full if mode == 'big' else torch.stack([inv, full[:, :, 1]], 2).contiguous()
+        preds = []
+        for k in range(2):
+            out = m.train_step({'X': Xs[k], 'Y': y, 'rank': 1, 'train': True, 'dropout': 0.2}, X_next=Xs[k + 1] if k == 0 else None)
+            preds.append(out['prediction'].clone())
+        torch.cuda.synchronize()
+        assert m.ctx.prepared_steps() == 1
+        Uw = P['uid_embeddings.weight'].detach()
+        res.append((Uw[uniq].clone() if mode == 'big' else Uw.clone(), P['iid_embeddings.weight'].detach().clone(),
+                    P['mlp.0.weight'].detach().clone(), P['mlp.0.bias'].detach().clone(), preds))
+        if mode == 'big':
+            want = far.clone()
+            for _ in range(2):     # two GD steps of the l2 term alone: p -= lr * (2 l2 p + l2 p)
+                want = want - lr * ((2.0 * l2) * want + l2 * want)
+            np.testing.assert_allclose(Uw[U - 3].cpu().numpy(), want.cpu().numpy(), rtol=1e-6, atol=1e-9)
+            assert int(m.touchedU.sum()) == 0 and float(m.flat_g[-4096:].abs().max()) == 0.0
+        del m, P, Uw
+        torch.cuda.empty_cache()
+    for a, b in zip(res[0][:4], res[1][:4]):
+        close(b, a.cpu().numpy(), 0, 2e-6, 'big table vs compact table')
+    for a, b in zip(res[0][4], res[1][4]):
+        close(b, a.cpu().numpy(), 1e-5, 1e-6, 'predictions')
+
+
 def test_sharded_trainer_with_hip_backend_world1(L):
     """dccf_amd/sharded.py with the real HIP backend over RCCL at world size 1 (the routing at world size 2 is covered
     on CPU by tests/test_sharded_gloo.py): two steps must equal the oracle on the same counter-based draws."""
