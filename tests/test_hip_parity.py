@@ -139,7 +139,8 @@ def test_fused_streams_match_oracle(L):
 
 
 @pytest.mark.parametrize('D,F,S,A,p,rank', [(64, 768, 10, 2, 0.2, 1), (16, 32, 10, 2, 0.2, 1), (128, 768, 10, 2, 0.2, 1),
-                                            (32, 160, 4, 3, 0.5, 0), (64, 768, 10, 2, 0.0, 1)])
+                                            (32, 160, 4, 3, 0.5, 0), (64, 768, 10, 2, 0.0, 1),
+                                            (64, 160, 20, 1, 0.2, 1), (32, 32, 3, 5, 0.1, 1), (16, 96, 40, 2, 0.3, 0)])
 def test_fused_equals_injected_on_device_draws(L, ctx, D, F, S, A, p, rank):
     """Fused mode (Philox in registers) must equal injected mode fed with the very same draws written out by the
     debug entry points — and both must equal the oracle on those draws."""
