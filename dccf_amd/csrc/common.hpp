@@ -63,6 +63,11 @@ struct dccf_ctx {
   const void* cur_Xall;
   uint64_t cur_step0;
   int64_t cur_N;
+  // dccf_train_step, item table hosted: the rows of V a step touches, as bytes, known BEFORE its backward (two sets by
+  // parity: the optimizer launch of step t marks step t + 1 while it consumes the marks of step t)
+  uint8_t* hv_flags[2];
+  int64_t hv_items;
+  int hv_parity, hv_prepared;
   const void* prep_Xall;
   int64_t prep_N;
   uint64_t prep_step, prep_seed;
@@ -103,6 +108,9 @@ struct dccf_opt_args;      // == dccf_opt_t of include/dccf_hip.h
 int dccf_opt_phase(const void* o, int phase, const int64_t* list, const int* cnt, int64_t max_rows, hipStream_t st);
 struct PrepNext;
 int dccf_opt_all_prep(const void* o, const PrepNext* pn, hipStream_t st);
+// the same with the flags of one segment replaced and only its MARKED rows belonging to the pass (the unmarked ones were
+// updated by the pass hosted in the backward launch) — for its first rows_hosted rows; the rest of the segment is ordinary
+int dccf_opt_all_prep_to(const void* o, int seg, uint8_t* flags, int64_t rows_hosted, const PrepNext* pn, hipStream_t st);
 struct OptJob;
 int dccf_opt_job(const void* o, OptJob* out);     // the validated job of a dccf_opt_t (for kernels that host a pass)
 // phase 1 (rows whose byte in `flags` is 0) + the next step's slots / marks in the same launch (dccf_dp_overlap)
@@ -283,6 +291,7 @@ struct PrepNext {
   uint8_t* gV;
   int G;
   rng_key gkey0;             // STREAM_CAND key of rank 0's next step; rank r draws with key + r
+  uint8_t* markV;            // != NULL: byte per item row the next step touches (dccf_train_step, hosted item table)
   // != NULL: the import tables of the next step, built here instead of by k_dp_scatter_ids after the all-gather:
   // nmask[gid] bit r = rank r touches the row; nwhere[r * R + gid] = the slot of rank r's buffer that will hold it = the
   // row's FIRST position in rank r's canonical (n, s) order (atomicMin: the same on every rank)
@@ -298,6 +307,7 @@ __device__ __forceinline__ void prep_next_slots(const PrepNext& pn, int64_t tid,
   for (int64_t i = tid; i < total; i += nthreads) {
     if (i < NS) {
       const int64_t it = prep_cand(pn.M, pn.X, nullptr, pn.cand, pn.eg, i, pn.S, pn.M.item_num, 1, pn.key);
+      if (pn.markV) pn.markV[it] = 1;
       if (pn.lm.list) {
         mark_row(pn.lm.flagV, it, pn.lm.tagV, pn.lm);
         if (i % S1 == 0) mark_row(pn.lm.flagU, pn.X[2 * (i / S1)], pn.lm.tagU, pn.lm);

@@ -68,7 +68,8 @@ static Lay make_layout(int64_t N, int D, int F, int S, int A) {
 __global__ void k_prep(dccf_model_t M, float* __restrict__ WT, int D, int F, int DP, int FP,
                        const int64_t* X, const int64_t* __restrict__ sample_item, int* __restrict__ cand,
                        float* __restrict__ eg, int64_t N, int S, int64_t item_num, int fused, rng_key key,
-                       float* __restrict__ m, int64_t Lm, float* __restrict__ loss, StepRef sr, MarkPlan mp) {
+                       float* __restrict__ m, int64_t Lm, float* __restrict__ loss, StepRef sr, MarkPlan mp,
+                       uint8_t* __restrict__ markV) {
   const float* __restrict__ W = M.W;
   {
     const int64_t k = step_k(sr);
@@ -88,6 +89,7 @@ __global__ void k_prep(dccf_model_t M, float* __restrict__ WT, int D, int F, int
       const int64_t n = j / (S + 1);
       const int s = (int)(j % (S + 1));
       const int64_t it = prep_cand(M, X, sample_item, cand, eg, j, S, item_num, fused, key);
+      if (markV) markV[it] = 1;         // hosted item table: the rows this step touches, known before its backward
       if (mp.list) {        // overlapped step: every row this batch reads/updates, once (wave-aggregated append)
         mark_row(mp.flagV, it, mp.tagV, mp);
         if (s == 0) mark_row(mp.flagU, X[2 * n], mp.tagU, mp);
@@ -895,6 +897,8 @@ struct StepPlan {
   const dccf_opt_t* opt;
   bool overlap;
   bool hosted;               // overlap == 2: the untouched-row pass rides in the backward launch (no side stream)
+  int hostv_seg;             // >= 0: segment of the item table; its untouched rows are updated by extra workgroups of the
+                             // backward launch (marks from the previous step's optimizer launch or from k_prep)
   MarkPlan mark;
   int64_t max_rows;
   const int64_t* X_next;     // same N, Philox step `step_next`: prepared inside the optimizer launch (NULL = not known)
@@ -949,6 +953,34 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
 
   // Did the previous dccf_train_step prepare exactly this step (same batch pointer, size, Philox step, seed, tables)?
   const bool prepared = train && !(plan && plan->overlap) && dccf_prep_matches(ctx, M, rnd, X, N);
+  // hosted item table (dccf_train_step, no other overlap mode): two sets of "item row touched" bytes owned by the context
+  const bool hostv = plan && !plan->overlap && plan->hostv_seg >= 0 && train;
+  if (hostv) {
+    const int64_t nb = (M->item_num + 3) / 4 * 4;
+    if (ctx->hv_items != nb) {
+      for (int q = 0; q < 2; ++q) {
+        if (ctx->hv_flags[q]) HIP_TRY(hipFree(ctx->hv_flags[q]));
+        HIP_TRY(hipMalloc((void**)&ctx->hv_flags[q], (size_t)nb));
+        HIP_TRY(hipMemsetAsync(ctx->hv_flags[q], 0, (size_t)nb, st));
+      }
+      ctx->hv_items = nb;
+      ctx->hv_prepared = 0;
+    }
+    // marks somebody prepared for a step that is not this one must not survive
+    if (ctx->hv_prepared && !prepared) HIP_TRY(hipMemsetAsync(ctx->hv_flags[ctx->hv_parity], 0, (size_t)nb, st));
+  } else if (ctx->hv_prepared && ctx->hv_items) {
+    HIP_TRY(hipMemsetAsync(ctx->hv_flags[ctx->hv_parity], 0, (size_t)ctx->hv_items, st));
+  }
+  ctx->hv_prepared = 0;
+  // how much of the item table rides in the backward launch: as much as streams while the roles compute (the hosted waves
+  // are few and share the issue pipe; the whole table would stretch the backward by 8 us at B=128)
+  int64_t hv_rows = 0;
+  if (hostv) {
+    const double frac = getenv("DCCF_HOSTV_FRAC") ? atof(getenv("DCCF_HOSTV_FRAC")) : 0.75;
+    const int64_t unit = 256 / M->D;
+    hv_rows = min(M->item_num, (int64_t)(frac * (double)M->item_num) / unit * unit);
+    if (frac >= 1.0) hv_rows = M->item_num * M->D % 256 == 0 ? M->item_num : M->item_num / unit * unit;
+  }
   ctx->prep_valid = 0;       // consumed — or overwritten by the k_prep below
   if (prepared) ++ctx->prep_hits;
   if (!prepared) {
@@ -960,7 +992,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     prof_begin(ctx, st);
     hipLaunchKernelGGL(k_prep, dim3(grid), dim3(256), 0, st, *M, WT, D, F, y.DP, y.FP, X, rnd->sample_item, cand, dmns, N,
                        M->S, M->item_num, fused_cand ? 1 : 0, ckey, m, y.GY > 1 ? y.L : (int64_t)0, train ? loss : nullptr, sr,
-                       mark);
+                       mark, hostv ? ctx->hv_flags[ctx->hv_parity] : (uint8_t*)nullptr);
     prof_end(ctx, 0, st);
   }
   if (plan && plan->overlap && !plan->hosted) {
@@ -1017,7 +1049,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     // small batches: ~1 workgroup per CU; large ones: ~4 per CU (4 waves per SIMD fill the shared VALU / fp32-MFMA pipe)
     const int64_t gx = max((int64_t)1, min((N + BWD_NW - 1) / BWD_NW, (int64_t)max(1, (N >= 2048 ? 1024 : 256) / roles)));
     // hosted optimizer pass: as many extra workgroups as CUs (one beside each role workgroup)
-    const int opt_rows_y = (plan && plan->overlap && plan->hosted) ? (int)(((getenv("DCCF_HOSTED_WGS") ? atoll(getenv("DCCF_HOSTED_WGS")) : 256) + gx - 1) / gx) : 0;
+    const int opt_rows_y = ((plan && plan->overlap && plan->hosted) || hostv) ? (int)(((getenv("DCCF_HOSTED_WGS") ? atoll(getenv("DCCF_HOSTED_WGS")) : 256) + gx - 1) / gx) : 0;
     const dim3 grid((unsigned)gx, (unsigned)(roles + opt_rows_y));
     const size_t smem = (size_t)4 * 32 * 64 * 4;
     prof_begin(ctx, st);
@@ -1043,6 +1075,21 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     ba.opt_rows_y = opt_rows_y;
     if (opt_rows_y) {
       if (int e = dccf_opt_job(plan->opt, &ba.oj)) return e;
+      if (hostv) {          // the item segment alone, as a job of its own: marks = this step's bytes
+        const int q = plan->hostv_seg;
+        OptJob& j = ba.oj;
+        const int w = j.sg.width[q];
+        const int64_t b0 = j.sg.begin[q], e0 = b0 + hv_rows * w;
+        j.p += b0; j.g += b0;
+        if (j.s1) j.s1 += b0;
+        if (j.s2) j.s2 += b0;
+        j.n = e0 - b0;
+        memset(&j.sg, 0, sizeof(j.sg));
+        j.sg.n = 1;
+        j.sg.begin[0] = 0; j.sg.end[0] = e0 - b0; j.sg.width[0] = w;
+        j.sg.flags[0] = ctx->hv_flags[ctx->hv_parity];
+        ba.touchedV = nullptr;       // (the bytes are there already; the optimizer launch consumes them)
+      }
     }
     BY_D(D, LAUNCH_BWD)
 #undef LAUNCH_BWD
@@ -1065,11 +1112,20 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
       pn.w_begin = M->W - plan->opt->p;
       pn.w_end = pn.w_begin + (int64_t)D * (D + F);
       pn.blocks = (int)min((int64_t)64, (y.NS + pn.Lm + 255) / 256);
-      if (int e = dccf_opt_all_prep(plan->opt, &pn, st)) return e;
+      if (hostv) {
+        pn.markV = ctx->hv_flags[1 - ctx->hv_parity];
+        if (int e = dccf_opt_all_prep_to(plan->opt, plan->hostv_seg, ctx->hv_flags[ctx->hv_parity], hv_rows, &pn, st)) return e;
+        ctx->hv_prepared = 1;
+      } else {
+        if (int e = dccf_opt_all_prep(plan->opt, &pn, st)) return e;
+      }
       dccf_prep_next_commit(ctx, M, N, plan->X_next, rnd->seed, plan->step_next);
+    } else if (hostv) {
+      if (int e = dccf_opt_all_prep_to(plan->opt, plan->hostv_seg, ctx->hv_flags[ctx->hv_parity], hv_rows, nullptr, st)) return e;
     } else {
       if (int e = dccf_opt_phase(plan->opt, OPT_PHASE_ALL, nullptr, nullptr, 0, st)) return e;
     }
+    if (hostv) ctx->hv_parity ^= 1;
     prof_end(ctx, 6, st);
   }
   return 0;
@@ -1085,6 +1141,15 @@ extern "C" int dccf_train_step(dccf_ctx* ctx, const dccf_model_t* M, const dccf_
   plan.opt = opt;
   plan.overlap = opt->overlap != 0 && N > 0;
   plan.hosted = opt->overlap == 2;
+  plan.hostv_seg = -1;
+  // (at 2B > 2048 the backward is long and the hosted pass buys nothing: measured +0.6 % at 2B = 8192)
+  if (!plan.overlap && N > 0 && N <= 2048 && rank == 1 && rnd->mode == 1 && opt->nseg >= 1 && opt->seg_begin && opt->seg_rows && opt->seg_width &&
+      G->touchedV && getenv("DCCF_NO_HOSTV") == nullptr) {
+    for (int q = 0; q < opt->nseg; ++q)
+      if (opt->p + opt->seg_begin[q] == M->V && opt->seg_rows[q] == M->item_num && opt->seg_width[q] == M->D &&
+          opt->seg_flags[q] == G->touchedV)
+        plan.hostv_seg = q;
+  }
   plan.X_next = (N > 0 && rank == 1) ? X_next : nullptr;
   plan.step_next = step_next;
   if (plan.overlap) {
@@ -1318,7 +1383,7 @@ extern "C" int dccf_eval_prepare(dccf_ctx* ctx, const dccf_model_t* M, float* Pf
     rng_key k0 = make_key(0, STREAM_CAND, 0);
     hipLaunchKernelGGL(k_prep, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, *M, WT, D, F, y.DP, y.FP, (const int64_t*)nullptr,
                        (const int64_t*)nullptr, (int*)nullptr, (float*)nullptr, (int64_t)0, M->S, M->item_num, 0, k0,
-                       (float*)nullptr, (int64_t)0, (float*)nullptr, sr, mark);
+                       (float*)nullptr, (int64_t)0, (float*)nullptr, sr, mark, (uint8_t*)nullptr);
   }
   const int grid = (int)min((int64_t)2048, ((M->item_num + 31) / 32 + 3) / 4);
 #define LAUNCH_FP(D_) hipLaunchKernelGGL(k_feat_proj<D_>, dim3(grid), dim3(256), 0, st, WT, M->feat, M->item_num, F, Pf)
@@ -1362,7 +1427,7 @@ extern "C" int dccf_predict_projected(dccf_ctx* ctx, const dccf_model_t* M, cons
     const int64_t total = (int64_t)(D + y.FP) * y.DP + y.NS + (y.GY > 1 ? y.L : 0) + 1;
     hipLaunchKernelGGL(k_prep, dim3((unsigned)min((int64_t)2048, (total + 255) / 256)), dim3(256), 0, st, *M, WT, D, F, y.DP, y.FP, X,
                        rnd->sample_item, cand, dmns, N, M->S, M->item_num, 1, make_key(rnd->seed, STREAM_CAND, rnd->step), m,
-                       y.GY > 1 ? y.L : (int64_t)0, (float*)nullptr, sr, mark);
+                       y.GY > 1 ? y.L : (int64_t)0, (float*)nullptr, sr, mark, (uint8_t*)nullptr);
   }
   const float kscale = dropout > 0.f ? 1.0f / (float)(1.0 - (double)dropout) : 1.0f;
   const uint32_t thr = dropout > 0.f ? drop_threshold(dropout) : 0u;

@@ -50,6 +50,7 @@ struct RowSegs {
   int width[4];
   uint8_t* flags[4];
   int n;
+  int to_mask;      // bit q: only the MARKED rows of segment q belong to this pass (the others were updated elsewhere)
 };
 
 // Everything a kernel needs to run (part of) one optimizer step.

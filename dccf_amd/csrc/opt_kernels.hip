@@ -42,6 +42,9 @@ extern "C" int dccf_ctx_create(dccf_ctx** out, int device) {
   c->prep_tables = c->cur_tables = 0;
   c->slot_where = nullptr;
   c->slot_rows = nullptr;
+  c->hv_flags[0] = c->hv_flags[1] = nullptr;
+  c->hv_items = 0;
+  c->hv_parity = c->hv_prepared = 0;
   c->cur_Xall = nullptr;
   c->prep_Xall = nullptr;
   *out = c;
@@ -231,7 +234,7 @@ __device__ __forceinline__ void touched_rows(float* __restrict__ p, float* __res
 // Row-aware variant: g of a row whose "touched" byte is 0 is all zeros by construction -> not read, not re-zeroed.
 // A wave handles 64 consecutive float4 = 256 consecutive floats = whole rows (row widths 16..128 divide 256 and segments
 // start on a 256-float boundary), so every lane of a row sees the byte before the row's first lane clears it.
-template <int KIND, int UN>
+template <int KIND, int UN, bool TO>
 __global__ __launch_bounds__(256) void k_dense_opt_rows(float* __restrict__ p, float* __restrict__ g, float* __restrict__ s1,
                                                         float* __restrict__ s2, int64_t n, OptArgs a, RowSegs sg,
                                                         int phase, PrepNext pn) {
@@ -266,18 +269,38 @@ __global__ __launch_bounds__(256) void k_dense_opt_rows(float* __restrict__ p, f
       const int64_t e = ic * 4;
       fl[u] = nullptr;
       first[u] = false;
+      bool tonly = false;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         if (q < sg.n && e >= sg.begin[q] && e < sg.end[q]) {
           const int64_t off = e - sg.begin[q];
           fl[u] = sg.flags[q] + (off >> wsh[q]);
           first[u] = (off & (sg.width[q] - 1)) == 0;
+          if (TO) tonly = (sg.to_mask >> q) & 1;
         }
-      pv[u] = reinterpret_cast<const float4*>(p)[ic];
       av[u] = bv[u] = gv[u] = make_float4(0, 0, 0, 0);
-      if (KIND != DCCF_OPT_GD) av[u] = reinterpret_cast<const float4*>(s1)[ic];
-      if (KIND == DCCF_OPT_ADAM) bv[u] = reinterpret_cast<const float4*>(s2)[ic];
-      touched[u] = fl[u] ? *fl[u] != 0 : true;
+      // a wave's 64 slots lie almost always in ONE segment (segments start on 256-float boundaries; only a segment's last
+      // wave may reach into what follows it), so this is a scalar branch and the common path keeps its unconditional loads
+      if (TO && __ballot(tonly) != 0) {
+        // (some lanes in) a segment whose unmarked rows were updated by the pass hosted in the backward launch: the byte
+        // decides before anything is loaded — most of these slots have nothing to do.  Lanes past the segment's end take
+        // the ordinary rule.
+        const bool marked = fl[u] ? *fl[u] != 0 : true;
+        touched[u] = marked;
+        const bool skip = tonly && !marked;
+        if (skip) live[u] = false;
+        pv[u] = make_float4(0, 0, 0, 0);
+        if (!skip) {
+          pv[u] = reinterpret_cast<const float4*>(p)[ic];
+          if (KIND != DCCF_OPT_GD) av[u] = reinterpret_cast<const float4*>(s1)[ic];
+          if (KIND == DCCF_OPT_ADAM) bv[u] = reinterpret_cast<const float4*>(s2)[ic];
+        }
+      } else {
+        pv[u] = reinterpret_cast<const float4*>(p)[ic];
+        if (KIND != DCCF_OPT_GD) av[u] = reinterpret_cast<const float4*>(s1)[ic];
+        if (KIND == DCCF_OPT_ADAM) bv[u] = reinterpret_cast<const float4*>(s2)[ic];
+        touched[u] = fl[u] ? *fl[u] != 0 : true;
+      }
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
@@ -423,15 +446,20 @@ static int launch_job(const OptJob& j, int phase, const int64_t* list, const int
   memset(&pn, 0, sizeof(pn));
   if (pnp) pn = *pnp;
   const int grid = (int)min(gmax, (work + 255) / 256) + pn.blocks;
+#define OPT_ROWS_LAUNCH(KIND_, UN_, TO_) \
+  hipLaunchKernelGGL((k_dense_opt_rows<KIND_, UN_, TO_>), dim3(grid), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.n, j.a, j.sg, phase, pn)
+#define OPT_ROWS_KIND(UN_, TO_)                                               \
+  if (j.kind == DCCF_OPT_GD) OPT_ROWS_LAUNCH(DCCF_OPT_GD, UN_, TO_);           \
+  else if (j.kind == DCCF_OPT_ADAGRAD) OPT_ROWS_LAUNCH(DCCF_OPT_ADAGRAD, UN_, TO_); \
+  else OPT_ROWS_LAUNCH(DCCF_OPT_ADAM, UN_, TO_)
+  // TO: a segment in "only the marked rows" mode (its other rows were updated by the pass hosted in the backward launch)
   if (j.n >= 100000000LL) {
-    if (j.kind == DCCF_OPT_GD) hipLaunchKernelGGL((k_dense_opt_rows<DCCF_OPT_GD, 2>), dim3(grid), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.n, j.a, j.sg, phase, pn);
-    else if (j.kind == DCCF_OPT_ADAGRAD) hipLaunchKernelGGL((k_dense_opt_rows<DCCF_OPT_ADAGRAD, 2>), dim3(grid), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.n, j.a, j.sg, phase, pn);
-    else hipLaunchKernelGGL((k_dense_opt_rows<DCCF_OPT_ADAM, 2>), dim3(grid), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.n, j.a, j.sg, phase, pn);
+    if (j.sg.to_mask) { OPT_ROWS_KIND(2, true); } else { OPT_ROWS_KIND(2, false); }
   } else {
-    if (j.kind == DCCF_OPT_GD) hipLaunchKernelGGL((k_dense_opt_rows<DCCF_OPT_GD, 1>), dim3(grid), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.n, j.a, j.sg, phase, pn);
-    else if (j.kind == DCCF_OPT_ADAGRAD) hipLaunchKernelGGL((k_dense_opt_rows<DCCF_OPT_ADAGRAD, 1>), dim3(grid), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.n, j.a, j.sg, phase, pn);
-    else hipLaunchKernelGGL((k_dense_opt_rows<DCCF_OPT_ADAM, 1>), dim3(grid), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.n, j.a, j.sg, phase, pn);
+    if (j.sg.to_mask) { OPT_ROWS_KIND(1, true); } else { OPT_ROWS_KIND(1, false); }
   }
+#undef OPT_ROWS_KIND
+#undef OPT_ROWS_LAUNCH
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -458,6 +486,30 @@ int dccf_opt_phase(const void* ov, int phase, const int64_t* list, const int* cn
   OptJob j;
   if (int e = opt_job(ov, &j)) return e;
   return launch_job(j, phase, list, cnt, max_rows, st);
+}
+
+int dccf_opt_all_prep_to(const void* ov, int seg, uint8_t* flags, int64_t rows_hosted, const PrepNext* pn, hipStream_t st) {
+  OptJob j;
+  if (int e = opt_job(ov, &j)) return e;
+  ARG_CHECK(seg >= 0 && seg < j.sg.n && flags, "bad segment / flags");
+  const int w = j.sg.width[seg];
+  const int64_t rows = (j.sg.end[seg] - j.sg.begin[seg]) / w;
+  ARG_CHECK(rows_hosted >= 0 && rows_hosted <= rows && (rows_hosted * w) % 256 == 0, "hosted rows must end on a 256-float boundary");
+  j.sg.flags[seg] = flags;
+  if (rows_hosted == rows) {
+    j.sg.to_mask = 1 << seg;
+  } else if (rows_hosted > 0) {
+    ARG_CHECK(j.sg.n < 4, "no free segment slot for the split");
+    const int q2 = j.sg.n++;                       // the ordinary rest of the segment
+    j.sg.begin[q2] = j.sg.begin[seg] + rows_hosted * w;
+    j.sg.end[q2] = j.sg.end[seg];
+    j.sg.width[q2] = w;
+    j.sg.flags[q2] = flags + rows_hosted;
+    j.sg.end[seg] = j.sg.begin[q2];
+    j.sg.to_mask = 1 << seg;
+  }
+  if (pn) ARG_CHECK(pn->w_begin % 4 == 0 && pn->w_end % 4 == 0 && pn->w_end <= j.n, "W must be 16-byte aligned inside the flat buffer");
+  return launch_job(j, OPT_PHASE_ALL, nullptr, nullptr, 0, st, pn);
 }
 
 // The whole pass + the next step's preparation in the same launch (dccf_train_step with X_next).

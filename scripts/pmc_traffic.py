@@ -20,7 +20,8 @@ NAMES = {'k_prep': 'prep', 'k_noise_fwd': 'noise_fwd', 'k_pair_epilogue': 'pair_
 
 
 def collect(counter, outdir):
-    env = dict(os.environ, TMPDIR='/tmp')
+    # DCCF_NO_HOSTV: every optimizer launch is then the ordinary whole pass — the launch bench.py's roofline describes
+    env = dict(os.environ, TMPDIR='/tmp', DCCF_NO_HOSTV='1')
     cmd = ['rocprofv3', '--pmc', counter, '--output-format', 'csv', '-d', outdir, '--', 'python3', os.path.join(REPO, 'bench.py'),
            '--steps', '100', '--warmup', '10', '--cpu_baseline', '0']
     subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
