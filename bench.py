@@ -92,8 +92,35 @@ def cpu_baseline(args, feat_cpu, seed):
                       'exposure rows of 2000 users), %.1f s' % (args.cpu_steps, args.batch_size, dt)}
 
 
+_REAL_STDOUT = None
+
+
+def quiet_stdout():
+    """The contract is ONE JSON line on stdout; RCCL prints a five-line version banner there when a communicator is created.
+    Everything the process (and the libraries it loads) writes to fd 1 goes to stderr until emit() puts the line out."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.environ['DCCF_BENCH_STDOUT_FD'] = str(_REAL_STDOUT)      # (this file is also imported as module `bench`)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    """Prints the result line on the real stdout (rank 0 calls this once)."""
+    line = json.dumps(obj)
+    sys.stdout.flush()
+    fd = _REAL_STDOUT if _REAL_STDOUT is not None else (int(os.environ['DCCF_BENCH_STDOUT_FD'])
+                                                        if 'DCCF_BENCH_STDOUT_FD' in os.environ else None)
+    if fd is not None:
+        os.write(fd, (line + '\n').encode())
+    else:
+        print(line, flush=True)
+
+
 def main():
     args = parse()
+    quiet_stdout()
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
@@ -277,7 +304,7 @@ def main():
     ebp['achieved_GBps'] = round(B * ebp['bytes_per_pair'] / (ebp['kernel_ms'] / 1e3) / 1e9, 2)
     if args.cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args, feat.cpu(), args.seed)
-    print(json.dumps(out), flush=True)
+    emit(out)
 
 
 if __name__ == '__main__':

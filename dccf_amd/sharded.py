@@ -274,5 +274,6 @@ def bench_main(args, rank, world, dev):
                           'batch_size_per_gpu': B, 'global_batch': B * world, 'optimizer': 'Adam lr=1e-3 l2=1e-4 dropout=0.2',
                           'collectives_per_step': 'all_to_all x3 (rows, feature rows, grad rows) + all_reduce([dW|db])'},
                'roofline': None, 'cpu_baseline': None}
-        print(json.dumps(out), flush=True)
+        import bench
+        bench.emit(out)
     dist.destroy_process_group()
