@@ -1,0 +1,50 @@
+# coding=utf-8
+"""bench.py's output contract: exactly ONE line on stdout, a JSON object with the driver's keys, BASELINE.json's metric,
+the `roofline` and `cpu_baseline` objects — single-GPU path and the replicated multi-GPU pipeline (world size 1 over RCCL,
+whose version banner must not reach stdout)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ['metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+        'dtype', 'data', 'config', 'roofline', 'cpu_baseline']
+
+
+def run(*flags):
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29741')
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--steps', '20', '--warmup', '5', '--users', '30000', '--items',
+                        '9000'] + list(flags), cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = r.stdout.decode().splitlines()
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line():
+    d = run('--cpu_steps', '2')
+    for k in KEYS:
+        assert k in d, k
+    base = json.load(open(os.path.join(REPO, 'BASELINE.json')))
+    assert d['metric'].split(',')[0] in base['metric'] and d['unit'] == 'pairs/s'
+    assert d['n_gpus'] == 1 and d['steps'] == 20 and d['warmup'] == 5 and d['higher_is_better'] is True
+    assert d['scaling'] == 'weak' and d['vs_baseline'] is None and d['dtype'] == 'f32' and d['data'] == 'synthetic'
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    assert d['value'] == pytest.approx(128 / (d['ms_per_step'] * 1e-3), rel=1e-3)
+    r = d['roofline']
+    assert r['bound'] in ('hbm', 'mfma') and r['unit'] in ('GB/s', 'TFLOP/s')
+    assert r['frac'] == pytest.approx(r['achieved'] / r['peak'], rel=1e-3) and 0 < r['frac'] < 1
+    c = d['cpu_baseline']
+    assert c['kind'] in ('port', 'reference') and c['value'] > 0 and c['cores'] >= 1 and c['unit'] == 'pairs/s' and c['sample']
+
+
+def test_replicated_pipeline_line():
+    d = run('--cpu_baseline', '0', '--force_replicated', '1')
+    for k in KEYS:
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['config']['replicas_bit_identical'] is True
+    assert d['roofline']['bound'] == 'hbm' and 0 < d['roofline']['frac'] < 1
