@@ -23,6 +23,25 @@
 #include "common.hpp"
 #include "opt_device.hpp"
 
+// Tuning knobs (environment, read once): the defaults are the measured optima of DESIGN.md section 4.
+struct Knobs {
+  double hostv_frac;      // DCCF_HOSTV_FRAC   share of the item table whose untouched-row pass rides in the backward launch
+  int64_t fold_max_n;     // DCCF_FOLD_MAX_N   largest 2B for which the pair epilogue is folded into the backward
+  int64_t hosted_wgs;     // DCCF_HOSTED_WGS   workgroups of a hosted optimizer pass
+  bool hostv;             // DCCF_NO_HOSTV=1   turns the hosted item-table pass off
+};
+static const Knobs& knobs() {
+  static const Knobs k = [] {
+    Knobs q;
+    q.hostv_frac = getenv("DCCF_HOSTV_FRAC") ? atof(getenv("DCCF_HOSTV_FRAC")) : 0.75;
+    q.fold_max_n = getenv("DCCF_FOLD_MAX_N") ? atoll(getenv("DCCF_FOLD_MAX_N")) : 1024;
+    q.hosted_wgs = getenv("DCCF_HOSTED_WGS") ? atoll(getenv("DCCF_HOSTED_WGS")) : 256;
+    q.hostv = getenv("DCCF_NO_HOSTV") == nullptr;
+    return q;
+  }();
+  return k;
+}
+
 // No implicit FMA contraction in this file: a*b+c written as two operations stays two roundings (explicit fmaf() calls
 // are still FMAs).  It keeps "fused draws == injected draws" bit for bit and the optimizer in torch's op order.
 #pragma clang fp contract(off)
@@ -976,7 +995,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
   // are few and share the issue pipe; the whole table would stretch the backward by 8 us at B=128)
   int64_t hv_rows = 0;
   if (hostv) {
-    const double frac = getenv("DCCF_HOSTV_FRAC") ? atof(getenv("DCCF_HOSTV_FRAC")) : 0.75;
+    const double frac = knobs().hostv_frac;
     const int64_t unit = 256 / M->D;
     hv_rows = min(M->item_num, (int64_t)(frac * (double)M->item_num) / unit * unit);
     if (frac >= 1.0) hv_rows = M->item_num * M->D % 256 == 0 ? M->item_num : M->item_num / unit * unit;
@@ -1029,7 +1048,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     prof_end(ctx, 2, st);
   }
   // training with at most 16 candidates per row: the pair epilogue is folded into the backward (wave_dm)
-  const bool fold = train && S1 <= 16 && A <= 4 && N <= (getenv("DCCF_FOLD_MAX_N") ? atoll(getenv("DCCF_FOLD_MAX_N")) : 1024);
+  const bool fold = train && S1 <= 16 && A <= 4 && N <= knobs().fold_max_n;
   if (!fold) {
     const int64_t units = (train && rank == 1) ? N / 2 : N;
     const int GS = S1 <= 16 ? 16 : (S1 <= 32 ? 32 : 64);
@@ -1049,7 +1068,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     // small batches: ~1 workgroup per CU; large ones: ~4 per CU (4 waves per SIMD fill the shared VALU / fp32-MFMA pipe)
     const int64_t gx = max((int64_t)1, min((N + BWD_NW - 1) / BWD_NW, (int64_t)max(1, (N >= 2048 ? 1024 : 256) / roles)));
     // hosted optimizer pass: as many extra workgroups as CUs (one beside each role workgroup)
-    const int opt_rows_y = ((plan && plan->overlap && plan->hosted) || hostv) ? (int)(((getenv("DCCF_HOSTED_WGS") ? atoll(getenv("DCCF_HOSTED_WGS")) : 256) + gx - 1) / gx) : 0;
+    const int opt_rows_y = ((plan && plan->overlap && plan->hosted) || hostv) ? (int)((knobs().hosted_wgs + gx - 1) / gx) : 0;
     const dim3 grid((unsigned)gx, (unsigned)(roles + opt_rows_y));
     const size_t smem = (size_t)4 * 32 * 64 * 4;
     prof_begin(ctx, st);
@@ -1144,7 +1163,7 @@ extern "C" int dccf_train_step(dccf_ctx* ctx, const dccf_model_t* M, const dccf_
   plan.hostv_seg = -1;
   // (at 2B > 2048 the backward is long and the hosted pass buys nothing: measured +0.6 % at 2B = 8192)
   if (!plan.overlap && N > 0 && N <= 2048 && rank == 1 && rnd->mode == 1 && opt->nseg >= 1 && opt->seg_begin && opt->seg_rows && opt->seg_width &&
-      G->touchedV && getenv("DCCF_NO_HOSTV") == nullptr) {
+      G->touchedV && knobs().hostv) {
     for (int q = 0; q < opt->nseg; ++q)
       if (opt->p + opt->seg_begin[q] == M->V && opt->seg_rows[q] == M->item_num && opt->seg_width[q] == M->D &&
           opt->seg_flags[q] == G->touchedV)
