@@ -668,6 +668,62 @@ def test_overlapped_train_step_equals_split_step(L, opt_name, B, l2, D):
                 close(b, a.cpu().numpy(), 1e-4, 1e-5, 'later predictions')
 
 
+def test_prepared_state_survives_nothing_it_should_not(L):
+    """The prepared-next-step state machine under abuse: a predict between two train steps, a tail batch of another size,
+    an announced batch that never comes, an announced batch replaced by another one at a different address — every
+    sequence must give what the split calls (forward/backward, then the dense step) give.  GD with a large l2 so that one
+    missed, doubled or misplaced row update would show; float atomics are the only tolerated difference."""
+    from dccf_amd.models import DCCF, FusedOptimizer
+    U, I, D, F, B = 901, 777, 64, 96, 64
+    g = torch.Generator(device='cuda').manual_seed(15)
+    feat = torch.randn(I, F, generator=g, device='cuda') * 0.05
+    expo = torch.randn(U, I, generator=g, device='cuda')
+
+    def batch(n):
+        return torch.stack([torch.randint(0, U, (2 * n,), generator=g, device='cuda'),
+                            torch.randint(0, I, (2 * n,), generator=g, device='cuda')], 1)
+    Xs = [batch(B) for _ in range(6)] + [batch(23)]
+    Xe = batch(200)
+    # (batch index, announced next batch index or None, predict before it?)
+    script = [(0, 1, False), (1, 2, True), (2, 3, False), (6, None, False), (3, 4, False), (5, 1, False), (1, None, True), (4, 0, False),
+              (0, None, False)]
+    states = []
+    for mode in ('split', 'step'):
+        m = DCCF(path=None, dataset=None, sentence_model=None, sample_num=10, attribute_num=2, std=0.1, label_min=0, label_max=1,
+                 feature_num=0, user_num=U, item_num=I, u_vector_size=D, i_vector_size=D, n_layers=1, random_seed=11,
+                 model_path='/tmp/x.pt', feature_embedding=feat, expo_prob=expo)
+        torch.manual_seed(3)
+        m.apply(m.init_paras)
+        m.optimizer = FusedOptimizer(m, 'gd', 0.01, 0.05)
+        preds = []
+        for k, nxt, pred_first in script:
+            if pred_first:                 # an evaluation call on the same context between two training steps
+                m.eval()
+                preds.append(m.predict({'X': Xe, 'rank': 1, 'train': False, 'dropout': 0.0})['prediction'].clone())
+            m.train()
+            X = Xs[k]
+            n = X.shape[0] // 2
+            y = torch.cat([torch.ones(n, device='cuda'), torch.zeros(n, device='cuda')])
+            fd = {'X': X, 'Y': y, 'rank': 1, 'train': True, 'dropout': 0.2}
+            if mode == 'split':
+                out = m(fd)
+                m.optimizer.step()
+            else:
+                out = m.train_step(fd, X_next=Xs[nxt] if nxt is not None else None)
+            preds.append(out['prediction'].clone())
+        torch.cuda.synchronize()
+        assert int(m.touchedU.sum()) == 0 and int(m.touchedV.sum()) == 0 and float(m.flat_g.abs().max()) == 0.0
+        if mode == 'step':
+            # 0->1 broken by the predict; 1->2 holds; 2->3 followed by the tail batch instead; 3->4 followed by batch 5
+            # instead; 5->1 broken by the predict; 4->0 holds
+            assert m.ctx.prepared_steps() == 2
+        states.append((m.flat_p.clone(), preds))
+    a, b = states
+    close(b[0], a[0].cpu().numpy(), 0, 2e-7, 'parameters after the scripted sequence')
+    for pa, pb in zip(a[1], b[1]):
+        close(pb, pa.cpu().numpy(), 1e-4, 1e-5, 'predictions along the sequence')
+
+
 def test_prepared_next_step_state_is_what_k_prep_writes(L, ctx):
     """dccf_train_step(X_next): after the call the workspace holds exactly what k_prep would write at the start of the
     next step — cand = [item ; Philox draws of step_next], the gathered exposures, and the transposed copy of
