@@ -206,19 +206,21 @@ def _rank_main(rank, world, port, out, overlap):
 W2 = dict(U=700, I=450, D=64, F=96, S=10, A=2, B=40, steps=5)
 
 
-@pytest.mark.parametrize('overlap', [False, True, 'prep'])
-def test_two_ranks_hip_backend_replicas_bit_identical(tmp_path, overlap):
-    """World size 2 with the HIP backend (both ranks on this box's one GPU, gloo as the transport): the replicas end
-    bit-identical, nothing is left in the gradient buffer or the flags, and the result equals the same two batches
-    accumulated into one gradient on one GPU, to the float-atomic tolerance."""
+@pytest.mark.parametrize('overlap,world', [(False, 2), (True, 2), ('prep', 2), ('prep', 3)])
+def test_two_ranks_hip_backend_replicas_bit_identical(tmp_path, overlap, world):
+    """World size 2 (and 3) with the HIP backend (the ranks share this box's one GPU, gloo as the transport): the replicas
+    end bit-identical, nothing is left in the gradient buffer, the flags or the tables, and the result equals the same
+    batches accumulated into one gradient on one GPU, to the float-atomic tolerance."""
     import torch.multiprocessing as mp
     from dccf_amd import _lib as L
-    port = 33000 + os.getpid() % 2000 + {False: 0, True: 11, 'prep': 23}[overlap]
-    mp.spawn(_rank_main, args=(2, port, str(tmp_path), overlap), nprocs=2, join=True)
-    r0, r1 = [dict(np.load(os.path.join(str(tmp_path), 'r%d_%s.npz' % (r, str(overlap))))) for r in range(2)]
-    assert np.array_equal(r0['p'], r1['p'])
-    assert np.array_equal(r0['losses'], r1['losses'])
-    assert r0['flags'].sum() == 0 and r1['flags'].sum() == 0 and r0['gmax'] == 0 and r1['gmax'] == 0
+    port = 33000 + os.getpid() % 2000 + {False: 0, True: 11, 'prep': 23}[overlap] + 7 * world
+    mp.spawn(_rank_main, args=(world, port, str(tmp_path), overlap), nprocs=world, join=True)
+    rs = [dict(np.load(os.path.join(str(tmp_path), 'r%d_%s.npz' % (r, str(overlap))))) for r in range(world)]
+    r0 = rs[0]
+    for r1 in rs[1:]:
+        assert np.array_equal(r0['p'], r1['p'])
+        assert np.array_equal(r0['losses'], r1['losses'])
+    assert all(r['flags'].sum() == 0 and r['gmax'] == 0 for r in rs)
     # one GPU, both batches into one gradient, one optimizer step
     c = W2
     from dccf_amd import replicated
@@ -236,11 +238,11 @@ def test_two_ranks_hip_backend_replicas_bit_identical(tmp_path, overlap):
     for t in range(c['steps']):
         X_all = torch.stack([torch.stack([torch.randint(0, c['U'], (2 * c['B'],), generator=gen, device='cuda'),
                                           torch.randint(0, c['I'], (2 * c['B'],), generator=gen, device='cuda')], 1)
-                             for _ in range(2)])
+                             for _ in range(world)])
         total = 0.0
-        for r in range(2):
+        for r in range(world):
             m = L.model_struct(tr.U, tr.V, tr.W, tr.b, feat, expo, c['S'], c['A'], 0.1)
-            _, loss = L.dccf_train_fwdbwd(ctx, m, L.rand_struct(seed=5, step=t * 2 + r), X_all[r].contiguous(), y, 1, 0.2,
+            _, loss = L.dccf_train_fwdbwd(ctx, m, L.rand_struct(seed=5, step=t * world + r), X_all[r].contiguous(), y, 1, 0.2,
                                           tr.gU, tr.gV, tr.gW, tr.gb)
             total += float(loss)
         assert total == pytest.approx(float(r0['losses'][t]), rel=1e-4)
