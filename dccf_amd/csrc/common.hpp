@@ -60,6 +60,7 @@ struct dccf_ctx {
   const int* slot_where;
   float* slot_rows;
   int64_t slot_offU, slot_offV;
+  int slot_cap;
   const void* cur_Xall;
   uint64_t cur_step0;
   int64_t cur_N;

@@ -443,6 +443,8 @@ struct BwdArgs {
   const int* slot_where;
   float* slot_rows;
   int64_t slot_offU, slot_offV;
+  int slot_cap;              // slots in the buffer: a lookup is clamped into it (a table that does not match the batch —
+                             // a caller that rewrote an announced batch in place — must not become a wild store)
   // hosted optimizer pass (dccf_train_step overlap == 2): the grid rows past the roles run the untouched-row pass of
   // `oj` while the roles compute — a backward workgroup is one wave per SIMD at <= 256 VGPRs, so a second workgroup fits
   // beside it on every CU, and the pass needs HBM, not the VALU / MFMA pipe
@@ -580,7 +582,7 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
     }
     float dmn = 0.f;
     int64_t urow_g = u;            // where gU[u] accumulates: the row itself, or its slot of the all-gather buffer
-    if (CHUNK && role == 0 && p.slot_where) urow_g = p.slot_where[p.slot_offU + u];
+    if (CHUNK && role == 0 && p.slot_where) urow_g = min((unsigned)p.slot_where[p.slot_offU + u], (unsigned)(p.slot_cap - 1));
     float uv[ND], asum[ND], due[ND], fb[NB];
 #pragma unroll
     for (int mt = 0; mt < ND; ++mt) {
@@ -763,7 +765,7 @@ __device__ __forceinline__ void bwd_dx_role(const BwdArgs& p, int dbase) {
           const int r = 2 * r2;
           const int ro = min(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, rpn - 1);
           const int ci = p.cand[n * S1 + (ro >> 1)];
-          sl8[r2] = p.slot_where ? p.slot_where[p.slot_offV + ci] : ci;
+          sl8[r2] = p.slot_where ? (int)min((unsigned)p.slot_where[p.slot_offV + ci], (unsigned)(p.slot_cap - 1)) : ci;
         }
       }
       f32x16 acc[ND];
@@ -813,7 +815,7 @@ __device__ __forceinline__ void bwd_dx_role(const BwdArgs& p, int dbase) {
             const int ro = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (ro < rpn && dd < D) {
               const int64_t ci = p.cand[n * S1 + ro / A];
-              float* gv = p.slot_where ? p.slot_rows + (int64_t)p.slot_where[p.slot_offV + ci] * D : p.gV + ci * D;
+              float* gv = p.slot_where ? p.slot_rows + (int64_t)min((unsigned)p.slot_where[p.slot_offV + ci], (unsigned)(p.slot_cap - 1)) * D : p.gV + ci * D;
               atomicAdd(&gv[dd], acc[nt][r]);
               if (p.touchedV && c31 == 0 && nt == 0) p.touchedV[ci] = 1;
             }
@@ -1090,6 +1092,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     ba.F = F; ba.NC = y.NC; ba.kscale = kscale; ba.nscale = nscale; ba.nkey = nkey; ba.sr = sr;
     ba.m = m; ba.Y = Y; ba.pred = pred; ba.loss = loss; ba.rank = rank;
     ba.slot_where = ctx->slot_where; ba.slot_rows = ctx->slot_rows; ba.slot_offU = ctx->slot_offU; ba.slot_offV = ctx->slot_offV;
+    ba.slot_cap = ctx->slot_cap;
     memset(&ba.oj, 0, sizeof(ba.oj));
     ba.opt_rows_y = opt_rows_y;
     if (opt_rows_y) {

@@ -638,6 +638,7 @@ extern "C" int dccf_dp_local(dccf_ctx* ctx, const dccf_model_t* model, const dcc
     gs.touchedU = gs.touchedV = nullptr;
     ctx->slot_where = dp->pwhere + ((int64_t)parity * dp->G + dp->rank) * R;
     ctx->slot_rows = dp->buf + y.rows_off;
+    ctx->slot_cap = (int)dp->cap;
     ctx->slot_offU = dp_rowoff(opt, dp->segU);
     ctx->slot_offV = dp_rowoff(opt, dp->segV);
     const int e = dccf_train_fwdbwd(ctx, model, rnd, X, Y, N, 1, dropout, &gs, prediction, dp->buf + 1, stream);
