@@ -10,11 +10,17 @@
 //            layout the MFMA wants).  Partials meet in LDS; the epilogue adds b, applies relu + dropout, stores h [L,D]
 //            and the row dot m[l] = <U[u], h[l]>.
 //   epilogue (k_pair_epilogue)  softmax over the candidates of Expo[u, cand] (one lane per candidate), prediction,
-//            BPR / MSE loss and d loss / d m.
+//            BPR / MSE loss and d loss / d m.  Its own kernel for predict and for large batches; at training batch sizes
+//            every backward wave recomputes it for the batch row it walks (wave_dm) and the kernel disappears.
 //   backward (k_bwd)  one barrier-free kernel of role waves that walk the batch rows: dW_f += dz^T eps with eps
 //            REGENERATED from the same counters directly as the MFMA B operand (+ one k-step per batch row for the
 //            feature term), dW_i += dz^T V[cand], dV[cand] += dz W_i, dU, db; 32x32 accumulators stay in registers over
-//            the workgroup's whole range and leave through one shaped float-atomic pass.
+//            the workgroup's whole range and leave through one shaped float-atomic pass.  Software-pipelined loads (a
+//            role workgroup is one wave per SIMD).  Extra grid rows host a slice of the dense optimizer pass
+//            (dccf_train_step), and in the replicated multi-GPU path the gradient rows go straight into the all-gather
+//            buffer ("slot mode").
+//   step     (run_dccf / dccf_train_step)  forward -> backward -> optimizer launch, which also prepares the next step
+//            (candidates, exposures, W^T, item-row marks) when the caller names the next batch: no k_prep in steady state.
 //
 // HBM layout (fp32 row-major): U [user_num,D], V [item_num,D], W [D,D+F], b [D], feat [item_num,F], expo [user_num,
 // item_num].  Workspace per call (ctx slab): cand int32 [N,S1]; WT [(D+FP),DP] = W transposed, zero padded (DP = D
