@@ -240,6 +240,30 @@ def test_mf_family_matches_reference(L, ctx, kind):
     close(L.mf_predict_full(struct(), device=dev()), g['full'], FWD_RTOL, FWD_ATOL, kind + ' full matrix')
 
 
+@pytest.mark.parametrize('D', [16, 32, 64, 128, 24])
+@pytest.mark.parametrize('kind', ['RecModel', 'BiasedMF', 'IPSBiasedMF'])
+def test_mf_full_matrix_every_kernel_form_ragged_sizes(L, D, kind):
+    """mf_predict_full for every D-specific kernel form (row-band D=16, LDS-band 32/64/128, generic tile 24) at sizes that
+    are multiples of nothing (user bands, 64- and 256-item tiles all end ragged) against the formula in fp64
+    (src/models/IPSBiasedMF.py:37-57: (P Q^T + bu + bi + b0) / max(prop, M))."""
+    U, I = 257 + 31, 2 * 256 + 77
+    g = torch.Generator(device='cuda').manual_seed(D)
+    P, Q = torch.randn(U, D, generator=g, device='cuda') * 0.3, torch.randn(I, D, generator=g, device='cuda') * 0.3
+    bu, bi = torch.randn(U, generator=g, device='cuda') * 0.1, torch.randn(I, generator=g, device='cuda') * 0.1
+    prop = torch.rand(I, generator=g, device='cuda')
+    b0 = torch.full((1,), 0.1, device='cuda')
+    m = L.mf_struct(kind, P, Q, bu, bi, b0, prop, 0.3)
+    out = torch.full((U + 1, I), float('nan'), device='cuda')          # one guard row: nothing may be written past the end
+    L.mf_predict_full(m, out=out[:U])
+    ref = P.double() @ Q.double().T
+    if kind != 'RecModel':
+        ref = ref + bu.double()[:, None] + bi.double()[None, :] + 0.1
+    if kind == 'IPSBiasedMF':
+        ref = ref / torch.clamp(prop.double(), min=0.3)[None, :]
+    assert bool(torch.isfinite(out[:U]).all()) and bool(torch.isnan(out[U]).all())
+    close(out[:U], ref.cpu().numpy(), 2e-6, 1e-6, 'full matrix D=%d %s' % (D, kind))
+
+
 def test_mf_train_mse_and_duplicates_vs_oracle(L, ctx):
     """rank==0 (MSE) and a batch full of duplicate users/items (exercises the LDS duplicate-row chains)."""
     rng = np.random.RandomState(8)
