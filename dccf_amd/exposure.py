@@ -65,6 +65,13 @@ def main(argv=None):
     ap.add_argument('--sep', type=str, default=',')
     ap.add_argument('--propensity_power', type=float, default=0.5)
     a, _ = ap.parse_known_args(argv)
+    if '-h' in argv or '--help' in argv:
+        print('usage: python -m dccf_amd.exposure [--dataset NAME] [--path DIR] [--sep ,] [--propensity_power 0.5] '
+              '[flags of dccf_amd.main: --epoch, --optimizer, --lr, --l2, ...]\n\n'
+              'Writes <path>/<dataset>/<dataset>.propensity.npy ((count_i / max count)^power over the training interactions) if it\n'
+              'is missing, trains IPSBiasedMF through the CLI mirror and writes the full U x I exposure matrix\n'
+              '<dataset>.ips_expo_prob.npy that DCCF loads (README.md:28-30 of the reference).')
+        return None
     prop_file = write_propensity(a.path, a.dataset, sep=a.sep, power=a.propensity_power)
     from dccf_amd import main as M
     passthrough, skip = [], False
