@@ -156,7 +156,8 @@ extern "C" int dccf_debug_trace_read(long long* out) {
 //   V[cand]) — its slices of W^T stay in registers.  Partials meet in LDS; the epilogue adds b, applies relu + dropout,
 //   stores h and m[l] = <U[u], h[l]>; its operands (user row, dropout draw, bias) are fetched before the k-loop.
 // NCM >= NC is the compile-time number of chunks (W^T is zero-padded to it: a group past F multiplies zeros).
-template <int D_, int MODE, int NCM>   // MODE 0: fused Philox draws, 1: injected noise / keep mask
+template <int D_, int MODE, int NCM, bool FAL>   // MODE 0: fused Philox draws, 1: injected noise / keep mask;
+                                                 // FAL: F == 128 * NCM exactly (no column clamp in the k-loop)
 __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT, const float* __restrict__ bias,
                                                    const float* __restrict__ U, const float* __restrict__ V,
                                                    const float* __restrict__ feat, const int64_t* X,
@@ -255,7 +256,9 @@ __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT,
         float a[4], fv[4];
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-          const int f = min(fbase + tq * 128 + 2 * c2 + 32 * o, F - 1);
+          // (F a whole number of chunks: no clamp, and the constant part of the column folds into the load's immediate
+          // offset — the pipe these kernels are bound by issues every one of those instructions)
+          const int f = FAL ? fbase + tq * 128 + 2 * c2 + 32 * o : min(fbase + tq * 128 + 2 * c2 + 32 * o, F - 1);
           fv[o] = frow[f];
           if (MODE == 1) a[o] = nrow[f];
         }
@@ -1035,19 +1038,21 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     const dim3 grid((unsigned)min((int64_t)1024, ntiles), y.GY), block(512);
     const size_t smem = (size_t)8 * 32 * y.ND * 32 * 4;
     prof_begin(ctx, st);
-#define LAUNCH_FWD3(D_, MODE_, NCM_)                                                                                  \
+#define LAUNCH_FWD3(D_, MODE_, NCM_, FAL_)                                                                            \
   {                                                                                                                  \
     static bool once = false;                                                                                        \
     if (!once) {                                                                                                     \
-      HIP_TRY(hipFuncSetAttribute((const void*)k_noise_fwd<D_, MODE_, NCM_>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
+      HIP_TRY(hipFuncSetAttribute((const void*)k_noise_fwd<D_, MODE_, NCM_, FAL_>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
       once = true;                                                                                                   \
     }                                                                                                                \
-    hipLaunchKernelGGL((k_noise_fwd<D_, MODE_, NCM_>), grid, block, smem, st, WT, M->b, M->U, M->V, M->feat, X, cand, \
+    hipLaunchKernelGGL((k_noise_fwd<D_, MODE_, NCM_, FAL_>), grid, block, smem, st, WT, M->b, M->U, M->V, M->feat, X, cand, \
                        rnd->noise, rnd->keep, hbuf, m, y.L, S1, A, F, nkey, dkey, nscale, thr, kscale, sr, train ? 1 : 0,  \
                        prepared ? loss : (float*)nullptr);                                                           \
   }
-#define LAUNCH_FWD2(D_, MODE_)                                              \
-  if (y.FP == 256) LAUNCH_FWD3(D_, MODE_, 2) else if (y.FP == 768) LAUNCH_FWD3(D_, MODE_, 6) else LAUNCH_FWD3(D_, MODE_, 7)
+#define LAUNCH_FWD2(D_, MODE_)                                                                          \
+  if (y.FP == 256) { if (F == 256) LAUNCH_FWD3(D_, MODE_, 2, true) else LAUNCH_FWD3(D_, MODE_, 2, false) }      \
+  else if (y.FP == 768) { if (F == 768) LAUNCH_FWD3(D_, MODE_, 6, true) else LAUNCH_FWD3(D_, MODE_, 6, false) } \
+  else LAUNCH_FWD3(D_, MODE_, 7, false)
 #define LAUNCH_FWD(D_) if (fused) LAUNCH_FWD2(D_, 0) else LAUNCH_FWD2(D_, 1)
     BY_D(D, LAUNCH_FWD)
 #undef LAUNCH_FWD
