@@ -189,7 +189,9 @@ __device__ __forceinline__ const int64_t* step_X(const StepRef& r, const int64_t
 }
 
 // 23-bit uniform strictly inside (0,1), exact in fp32.
-__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 9) + 0.5f) * 0x1p-23f; }
+// ((x >> 9) + 0.5) * 2^-23: the integer, its half and the product are all exact in fp32, so the single fma below gives the
+// same bits as the add and the multiply it replaces (one instruction less per uniform in kernels bound by instruction issue)
+__device__ __forceinline__ float u01(uint32_t x) { return fmaf((float)(x >> 9), 0x1p-23f, 0x1p-24f); }
 
 // Box-Muller on the hardware transcendentals: v_log_f32 is log2, v_sin/v_cos take revolutions (sin(2*pi*x)).
 // nscale = -2 * ln(2) * std^2, so r = std * sqrt(-2 ln u1).
