@@ -203,10 +203,22 @@ __device__ __forceinline__ void box_muller(uint32_t xa, uint32_t xb, float nscal
 }
 
 // the 4 normals of noise words (l, c1): f = 128*(c1/32) + (c1%32) + 32*o, o = 0..3
+// Same operations as two box_muller() calls, written on 2-vectors so that the uniform conversions, the scalings of the
+// logarithms and the final products issue as packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32: two IEEE operations
+// per issue slot — the MFMA kernels are bound by instruction issue, profiles/r01_mfma_pmc.md).  Bit-identical results.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void noise4(uint32_t l, uint32_t c1, const rng_key& k, float nscale, float out[4]) {
   const u32x4 r = philox4x32_10(l, c1, k.s0, k.s1, k.k0, k.k1);
-  box_muller(r.x, r.y, nscale, out[0], out[1]);
-  box_muller(r.z, r.w, nscale, out[2], out[3]);
+  const f32x2 ia = {(float)(r.x >> 9), (float)(r.z >> 9)}, ib = {(float)(r.y >> 9), (float)(r.w >> 9)};
+  const f32x2 sc = {0x1p-23f, 0x1p-23f}, hf = {0x1p-24f, 0x1p-24f};
+  const f32x2 u1 = __builtin_elementwise_fma(ia, sc, hf), u2 = __builtin_elementwise_fma(ib, sc, hf);
+  f32x2 lg = {__builtin_amdgcn_logf(u1.x), __builtin_amdgcn_logf(u1.y)};
+  lg = lg * nscale;
+  const f32x2 rr = {__builtin_amdgcn_sqrtf(lg.x), __builtin_amdgcn_sqrtf(lg.y)};
+  const f32x2 cs = {__builtin_amdgcn_cosf(u2.x), __builtin_amdgcn_cosf(u2.y)};
+  const f32x2 sn = {__builtin_amdgcn_sinf(u2.x), __builtin_amdgcn_sinf(u2.y)};
+  const f32x2 z0 = rr * cs, z1 = rr * sn;
+  out[0] = z0.x; out[1] = z1.x; out[2] = z0.y; out[3] = z1.y;
 }
 
 __device__ __forceinline__ uint32_t pick4(const u32x4& r, int i) {
