@@ -654,9 +654,19 @@ __global__ __launch_bounds__(256) void k_sample_neg(const int64_t* __restrict__ 
     for (int64_t r = r0; r < r1; ++r) {
       const int64_t remain = item_num - (h1 - h0) - (r - r0);
       const bool low = 5 * remain < item_num;   // remain / item_num < 0.2
-      int64_t it;
-      if (remain < 1) { neg_out[rows[r]] = -1; continue; }   // reference asserts (DataProcessor.py:495)
-      for (;;) {
+      int64_t it = -1;
+      // what can still be drawn: in the low regime the reference samples from range(1, item_num) (DataProcessor.py:490-493),
+      // so item 0 does not count unless it is already excluded (history is sorted: 0 can only sit first)
+      int64_t admissible = remain;
+      if (low) {
+        bool zero_out = h1 > h0 && hist_items[h0] == 0;
+        for (int64_t q = r0; q < r && !zero_out; ++q) zero_out = neg_out[rows[q]] == 0;
+        if (!zero_out) admissible -= 1;
+      }
+      // nothing left: the reference asserts (DataProcessor.py:495) or raises from np.random.choice; the host checks for -1
+      if (admissible < 1) { neg_out[rows[r]] = -1; continue; }
+      bool found = false;
+      for (uint32_t tries = 0; tries < (1u << 22); ++tries) {     // every thread has an exit (P(miss) < e^-800 when reached)
         if ((j & 3) == 0) cur = philox4x32_10((uint32_t)u, j >> 2, key.s0, key.s1, key.k0, key.k1);
         it = (int64_t)(((uint64_t)pick4(cur, j & 3) * (uint64_t)item_num) >> 32);
         ++j;
@@ -670,9 +680,9 @@ __global__ __launch_bounds__(256) void k_sample_neg(const int64_t* __restrict__ 
         bool dup = false;
         for (int64_t q = r0; q < r; ++q)
           if (neg_out[rows[q]] == it) { dup = true; break; }
-        if (!dup) break;
+        if (!dup) { found = true; break; }
       }
-      neg_out[rows[r]] = it;
+      neg_out[rows[r]] = found ? it : -1;
     }
   }
 }

@@ -313,6 +313,9 @@ class DeviceTrainSet(object):
 
     def epoch_batches(self, epoch, batch_size):
         neg = self.sample_negatives(epoch)
+        # a user whose history leaves nothing to draw: the reference asserts (DataProcessor.py:495); an id of -1 must never
+        # reach the kernels as a row index
+        assert self.n == 0 or int(neg.min()) >= 0, 'no admissible training negative left for some user'
         g = torch.Generator(device=self.uid.device)
         g.manual_seed((self.seed * 1000003 + int(epoch)) & 0x7FFFFFFFFFFFFFFF)
         perm = torch.randperm(self.n, generator=g, device=self.uid.device)

@@ -128,7 +128,11 @@ def train_negatives(seed, epoch, uids, item_num, hist_indptr, hist_items):
         for r in range(s, e):
             remain = item_num - len(hist) - len(drawn)
             low = (1.0 * remain / item_num) < 0.2
-            assert remain >= 1
+            # low regime: the reference samples from range(1, item_num), so item 0 only counts if it is excluded already
+            admissible = remain - (1 if low and 0 not in hist and 0 not in drawn else 0)
+            if admissible < 1:          # the reference asserts / np.random.choice raises; the device writes -1
+                out[order[r]] = -1
+                continue
             while True:
                 xs = philox4x32(u, j // 4, epoch, 0, k0, k1)
                 it = int(mulhi(np.asarray(xs[j % 4]).reshape(1), item_num)[0])

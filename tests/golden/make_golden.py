@@ -407,9 +407,18 @@ def gen_metrics(outdir):
 
 
 # ----------------------------------------------------------------------------- G5: end to end
-E2E = dict(user_num=800, item_num=600, n_draws=16000, feat_dim=64, data_seed=11, epochs=4,
-           seeds=[int(x) for x in os.environ.get('E2E_SEEDS', '2019,2020,2021,2022,2023').split(',')],
-           D=32, test_neg_n=100, lr=0.001, batch_size=128)
+E2E_CONFIGS = {
+    # small set the first e2e golden was captured on (tests/golden/e2e.npz)
+    'small': dict(user_num=800, item_num=600, n_draws=16000, feat_dim=64, data_seed=11, epochs=4, D=32, test_neg_n=100,
+                  lr=0.001, batch_size=128),
+    # BASELINE.json configs[0] / SURVEY.md §8d C1: 5k users x 5k items, D=16, F=768 (tests/golden/e2e_c1.npz)
+    'c1': dict(user_num=5000, item_num=5000, n_draws=200000, feat_dim=768, data_seed=7, epochs=3, D=16, test_neg_n=100,
+               lr=0.001, batch_size=128),
+}
+E2E = dict(E2E_CONFIGS[os.environ.get('E2E_CFG', 'small')])
+E2E['seeds'] = [int(x) for x in os.environ.get('E2E_SEEDS', '2019,2020,2021,2022,2023').split(',')]
+if 'E2E_THREADS' in os.environ:
+    torch.set_num_threads(int(os.environ['E2E_THREADS']))
 
 
 def gen_e2e(outdir):
@@ -442,6 +451,9 @@ def gen_e2e(outdir):
             logf = [os.path.join(r, f) for r, _, fs in os.walk(os.path.join(tmp, 'log')) for f in fs][0]
             txt = open(logf).read()
             ep = re.findall(r'Epoch\s+(\d+) \[[\d.]+ s\]\s+train= ([\d.,-]+) validation= ([\d.,-]+) test= ([\d.,-]+)', txt)
+            tms = re.findall(r'Epoch\s+\d+ \[([\d.]+) s\].*?\[([\d.]+) s\]', txt)
+            rec['seed%d/fit_eval_seconds' % seed] = np.array([[float(a), float(b)] for a, b in tms])
+            rec['threads'] = np.array(torch.get_num_threads())
             init = re.search(r'Init: \s+train= ([\d.,-]+) validation= ([\d.,-]+) test= ([\d.,-]+)', txt)
             rec['seed%d/init_valid' % seed] = np.array([float(x) for x in init.group(2).split(',')])
             rec['seed%d/init_test' % seed] = np.array([float(x) for x in init.group(3).split(',')])

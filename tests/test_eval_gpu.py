@@ -111,3 +111,63 @@ def test_runner_device_eval_equals_host_eval(tmp_path):
                    + r.evaluate(m, dp.get_train_data(-1), dp, metrics=['rmse', 'mae']))
     assert res[0][0] > 0.05
     np.testing.assert_allclose(res[0], res[1], rtol=2e-6, atol=1e-7)
+
+
+def test_device_train_set_epoch_batches_layout():
+    """The DEFAULT training feed (DeviceTrainSet.epoch_batches, --fused_sampling 1) on the dataset of the reference's batch
+    golden (tests/golden/batches.npz): the layout rules of DataProcessor._get_feed_dict_rk / _prepare_batches_rk
+    (src/data_processor/DataProcessor.py:160-207,227-250) and the negative rule of _sample_neg_from_uid_list (:446-524)."""
+    from conftest import load_golden
+    from dccf_amd.data_processor import DeviceTrainSet
+    g = load_golden('batches')
+    df = g['df/train']
+    uid, iid = df[:, 0].astype(np.int64), df[:, 1].astype(np.int64)
+    U_, I_, B = int(g['user_num']), int(g['item_num']), int(g['batch_size'])
+    n = len(uid)
+    ds = DeviceTrainSet(uid, iid, U_, I_, seed=2019)
+    hist = {u: set(iid[uid == u].tolist()) for u in np.unique(uid)}
+    pos_pairs = sorted(zip(uid.tolist(), iid.tolist()))
+    seen_epochs = []
+    for epoch in (0, 1):
+        full, tail = ds.epoch_batches(epoch, B)
+        nb = n // B
+        # shapes: full batches [nb, 2B, 2], tail [2r, 2] with r = n mod B (the reference's last, shorter batch)
+        assert tuple(full.shape) == (nb, 2 * B, 2) and full.dtype == torch.int64 and full.is_contiguous()
+        r = n % B
+        assert (tail is None) == (r == 0)
+        if tail is not None:
+            assert tuple(tail.shape) == (2 * r, 2)
+        f = full.cpu().numpy()
+        halves = [(f[k, :B], f[k, B:]) for k in range(nb)]
+        if tail is not None:
+            t = tail.cpu().numpy()
+            halves.append((t[:r], t[r:]))
+        P = np.concatenate([h[0] for h in halves])
+        Ng = np.concatenate([h[1] for h in halves])
+        # row k and row B+k of a batch carry the same uid (negatives are generated per positive row, :243-246)
+        assert np.array_equal(P[:, 0], Ng[:, 0])
+        # every positive of train_df exactly once per epoch
+        assert sorted(zip(P[:, 0].tolist(), P[:, 1].tolist())) == pos_pairs
+        # a negative is never in the user's train history and never repeated for that user within the epoch (tmp_history
+        # persists over the epoch for train=True, :479,516-517); ids are valid items
+        assert Ng[:, 1].min() >= 0 and Ng[:, 1].max() < I_
+        for u in np.unique(uid):
+            mine = Ng[Ng[:, 0] == u, 1]
+            assert len(mine) == len(hist[u])
+            assert len(set(mine.tolist())) == len(mine)
+            assert not (set(mine.tolist()) & hist[u])
+        seen_epochs.append((P.copy(), Ng.copy()))
+        # same (seed, epoch) -> same epoch again (the sharded / replicated trainers rely on it)
+        full2, tail2 = ds.epoch_batches(epoch, B)
+        assert torch.equal(full, full2) and (tail is None or torch.equal(tail, tail2))
+    # a new epoch reshuffles and redraws
+    assert not np.array_equal(seen_epochs[0][0], seen_epochs[1][0])
+    assert not np.array_equal(np.sort(seen_epochs[0][1][:, 1]), np.sort(seen_epochs[1][1][:, 1])) or n < 4
+    # the runner's Y / sizes for these batches (BaseRunner.fit): Y = [1]*B + [0]*B, real_batch_size = B
+    # (DataProcessor.py:197-206); the negatives of the kernel equal the oracle's restatement of the stream
+    from oracle import philox as PH
+    order = np.argsort(uid, kind='stable')
+    key = np.unique(uid * I_ + iid)
+    hist_indptr = np.searchsorted(key // I_, np.arange(U_ + 1)).astype(np.int64)
+    ref = PH.train_negatives(2019, 1, uid, I_, hist_indptr, (key % I_).astype(np.int64))
+    assert np.array_equal(ds.sample_negatives(1).cpu().numpy(), ref)

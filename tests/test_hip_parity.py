@@ -140,7 +140,11 @@ def test_fused_streams_match_oracle(L):
 
 @pytest.mark.parametrize('D,F,S,A,p,rank', [(64, 768, 10, 2, 0.2, 1), (16, 32, 10, 2, 0.2, 1), (128, 768, 10, 2, 0.2, 1),
                                             (32, 160, 4, 3, 0.5, 0), (64, 768, 10, 2, 0.0, 1),
-                                            (64, 160, 20, 1, 0.2, 1), (32, 32, 3, 5, 0.1, 1), (16, 96, 40, 2, 0.3, 0)])
+                                            (64, 160, 20, 1, 0.2, 1), (32, 32, 3, 5, 0.1, 1), (16, 96, 40, 2, 0.3, 0),
+                                            # config 1's shape (D=16, F=768) and the chunk counts / column clamps no golden
+                                            # reaches: 6 whole chunks at D=16/32, 3 chunks padded to 6, 7 chunks with a clamp
+                                            (16, 768, 10, 2, 0.2, 1), (32, 768, 3, 2, 0.2, 1), (64, 384, 3, 2, 0.2, 1),
+                                            (64, 800, 3, 2, 0.1, 1), (128, 300, 2, 2, 0.2, 0)])
 def test_fused_equals_injected_on_device_draws(L, ctx, D, F, S, A, p, rank):
     """Fused mode (Philox in registers) must equal injected mode fed with the very same draws written out by the
     debug entry points — and both must equal the oracle on those draws."""
@@ -358,6 +362,25 @@ def test_train_negative_sampler_matches_oracle(L):
     a = L.sample_train_negatives(T(rows_indptr), T(rows), T(hist_indptr), T(hist_items), U_, I_, 2019, 0).cpu().numpy()
     b = L.sample_train_negatives(T(rows_indptr), T(rows), T(hist_indptr), T(hist_items), U_, I_, 2019, 1).cpu().numpy()
     assert not np.array_equal(a, b)
+
+
+def test_train_negative_sampler_exhausted_users_terminate(L):
+    """in the low regime (< 20 % of the items remain) item 0 is never drawn (DataProcessor.py:490-493); a user whose
+    only remaining item is 0 must get -1 (the reference raises there) instead of spinning, and a user with exactly one
+    admissible item must get it."""
+    I_ = 120
+    hists = [np.arange(1, I_), np.arange(0, I_ - 1), np.arange(0, I_), np.array([3, 5])]      # only 0 left; only 119 left; nothing; plenty
+    nrows = [1, 2, 1, 3]
+    hist_indptr = np.concatenate([[0], np.cumsum([len(h) for h in hists])]).astype(np.int64)
+    hist_items = np.concatenate(hists).astype(np.int64)
+    uids = np.repeat(np.arange(4), nrows).astype(np.int64)
+    rows = np.arange(len(uids), dtype=np.int64)
+    rows_indptr = np.searchsorted(uids, np.arange(5)).astype(np.int64)
+    out = L.sample_train_negatives(T(rows_indptr), T(rows), T(hist_indptr), T(hist_items), 4, I_, 2019, 1).cpu().numpy()
+    ref = PH.train_negatives(2019, 1, uids, I_, hist_indptr, hist_items)
+    assert np.array_equal(out, ref)
+    assert out[0] == -1 and out[1] == I_ - 1 and out[2] == -1 and out[3] == -1
+    assert set(out[4:].tolist()).isdisjoint({3, 5}) and len(set(out[4:].tolist())) == 3 and out[4:].min() >= 0
 
 
 def test_argument_errors_are_reported(L, ctx):
