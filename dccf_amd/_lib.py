@@ -13,12 +13,13 @@ LIB_PATH = os.path.join(HERE, 'lib', 'libdccf_hip.so')
 EXPORTS = ['dccf_ctx_create', 'dccf_ctx_destroy', 'dccf_ctx_reserve', 'dccf_last_error', 'dccf_abi_version',
            'dccf_predict', 'dccf_train_fwdbwd', 'dccf_dense_opt_step', 'dccf_sumsq', 'mf_predict', 'mf_train_fwdbwd',
            'mf_predict_full', 'dccf_sample_train_negatives', 'dccf_debug_candidates', 'dccf_debug_noise',
-           'dccf_debug_keep', 'dccf_debug_workspace', 'dccf_profile', 'dccf_profile_read',
+           'dccf_debug_keep', 'dccf_debug_keep_layer', 'dccf_debug_workspace', 'dccf_profile', 'dccf_profile_read',
            'shard_pack_rows', 'shard_unpack_rows', 'shard_scatter_add', 'dccf_dense_opt_step_rows', 'dccf_dense_opt_step_dev', 'dccf_advance', 'rank_eval_topk', 'dccf_train_step', 'dp_buffer_words',
            'dp_export_touched', 'dp_import_touched', 'dp_mark_global', 'dccf_dense_opt_phase', 'dccf_ctx_side_stream', 'dp_import_apply',
            'dccf_sample_eval_negatives', 'dccf_eval_prepare', 'dccf_predict_projected', 'dccf_dp_local', 'dccf_dp_overlap',
            'dccf_dp_finish', 'dccf_ctx_prepared_steps']
 
+ABI_VERSION = 2
 OPT_KIND = {'gd': 0, 'adagrad': 1, 'adam': 2}
 MF_KIND = {'RecModel': 0, 'BiasedMF': 1, 'IPSBiasedMF': 2}
 
@@ -30,7 +31,8 @@ class ModelT(C.Structure):
                 ('S', C.c_int32), ('A', C.c_int32), ('std', C.c_float), ('reserved', C.c_float),
                 ('U', _f), ('V', _f), ('W', _f), ('b', _f), ('feat', _f), ('expo', _f),
                 ('ipsP', _f), ('ipsQ', _f), ('ipsBu', _f), ('ipsBi', _f), ('ipsProp', _f),
-                ('ipsB0', C.c_float), ('ipsM', C.c_float), ('ipsD', C.c_int32), ('reserved2', C.c_int32)]
+                ('ipsB0', C.c_float), ('ipsM', C.c_float), ('ipsD', C.c_int32), ('n_extra', C.c_int32),
+                ('Wl', _f * 7), ('bl', _f * 7)]
 
 
 class RandT(C.Structure):
@@ -39,7 +41,8 @@ class RandT(C.Structure):
 
 
 class GradsT(C.Structure):
-    _fields_ = [('gU', _f), ('gV', _f), ('gW', _f), ('gb', _f), ('touchedU', _f), ('touchedV', _f)]
+    _fields_ = [('gU', _f), ('gV', _f), ('gW', _f), ('gb', _f), ('touchedU', _f), ('touchedV', _f),
+                ('gWl', _f * 7), ('gbl', _f * 7)]
 
 
 class OptT(C.Structure):
@@ -86,6 +89,9 @@ def load():
     lib = C.CDLL(LIB_PATH)
     lib.dccf_last_error.restype = C.c_char_p
     lib.dccf_abi_version.restype = C.c_int
+    if lib.dccf_abi_version() != ABI_VERSION:      # the ctypes structs below mirror include/dccf_hip.h of exactly this version
+        raise RuntimeError('libdccf_hip.so has ABI version %d, this package needs %d: rebuild with `python -m dccf_amd.build`'
+                           % (lib.dccf_abi_version(), ABI_VERSION))
     i64, i32, u64, f32, vp = C.c_int64, C.c_int32, C.c_uint64, C.c_float, C.c_void_p
     sig = {
         'dccf_ctx_create': [C.POINTER(vp), C.c_int],
@@ -128,6 +134,7 @@ def load():
         'dccf_debug_candidates': [i64, i32, i64, u64, u64, vp, vp],
         'dccf_debug_noise': [i64, i32, f32, u64, u64, vp, vp],
         'dccf_debug_keep': [i64, i32, f32, u64, u64, vp, vp],
+        'dccf_debug_keep_layer': [i64, i32, f32, u64, u64, i32, vp, vp],
         'dccf_debug_workspace': [vp, i64, i32, i32, i32, i32, i32, vp, C.POINTER(C.c_int64), vp],
         'shard_pack_rows': [vp, vp, i64, C.POINTER(vp), C.POINTER(i32), i32, vp, i32, vp],
         'shard_unpack_rows': [vp, i32, i64, vp, C.POINTER(vp), C.POINTER(i32), i32, vp],
@@ -205,7 +212,8 @@ class Context(object):
             pass
 
 
-def model_struct(U, V, W, b, feat, expo, S, A, std, ips=None):
+def model_struct(U, V, W, b, feat, expo, S, A, std, ips=None, extra=None):
+    """extra: [(mlp.k.weight [D, D], mlp.k.bias [D]) for k = 1 .. n_layers - 1] (src/models/DCCF.py:61-62)."""
     m = ModelT()
     m.user_num, m.D = U.shape
     m.item_num = V.shape[0]
@@ -222,8 +230,24 @@ def model_struct(U, V, W, b, feat, expo, S, A, std, ips=None):
         m.ipsP, m.ipsQ = ptr(ips['P'], f32), ptr(ips['Q'], f32)
         m.ipsBu, m.ipsBi, m.ipsProp = ptr(ips['bu'], f32), ptr(ips['bi'], f32), ptr(ips['prop'], f32)
         m.ipsB0, m.ipsM, m.ipsD = float(ips['b0']), float(ips['M']), int(ips['P'].shape[1])
-    m._refs = (U, V, W, b, feat, expo, ips)   # the struct holds raw addresses: keep the tensors alive with it
+    extra = list(extra or [])
+    if len(extra) > 7:
+        raise RuntimeError('at most 8 mlp layers (n_layers <= 8)')
+    m.n_extra = len(extra)
+    for k, (Wk, bk) in enumerate(extra):
+        if tuple(Wk.shape) != (m.D, m.D) or tuple(bk.shape) != (m.D,):
+            raise RuntimeError('extra mlp layers must be [D, D] / [D]')
+        m.Wl[k], m.bl[k] = ptr(Wk, f32), ptr(bk, f32)
+    m._refs = (U, V, W, b, feat, expo, ips, extra)   # the struct holds raw addresses: keep the tensors alive with it
     return m
+
+
+def grads_struct(gU, gV, gW, gb, touchedU=None, touchedV=None, extra=None):
+    """extra: [(grad of mlp.k.weight, grad of mlp.k.bias) for k = 1 .. n_layers - 1]."""
+    g = GradsT(ptr(gU), ptr(gV), ptr(gW), ptr(gb), ptr(touchedU, torch.uint8), ptr(touchedV, torch.uint8))
+    for k, (a, b) in enumerate(extra or []):
+        g.gWl[k], g.gbl[k] = ptr(a, torch.float32), ptr(b, torch.float32)
+    return g
 
 
 def rand_struct(sample_item=None, noise=None, keep=None, seed=None, step=0, k_dev=None, x_stride=0, x_steps=1):
@@ -254,13 +278,14 @@ def dccf_predict(ctx, m, r, X, dropout, out=None):
     return out
 
 
-def dccf_train_fwdbwd(ctx, m, r, X, Y, rank, dropout, gU, gV, gW, gb, pred=None, loss=None, touchedU=None, touchedV=None):
+def dccf_train_fwdbwd(ctx, m, r, X, Y, rank, dropout, gU, gV, gW, gb, pred=None, loss=None, touchedU=None, touchedV=None,
+                      gextra=None):
     N = X.shape[0]
     if pred is None:
         pred = torch.empty(N, dtype=torch.float32, device=X.device)
     if loss is None:
         loss = torch.empty(1, dtype=torch.float32, device=X.device)
-    g = GradsT(ptr(gU), ptr(gV), ptr(gW), ptr(gb), ptr(touchedU, torch.uint8), ptr(touchedV, torch.uint8))
+    g = grads_struct(gU, gV, gW, gb, touchedU, touchedV, gextra)
     check(load().dccf_train_fwdbwd(ctx.h, C.byref(m), C.byref(r), ptr(X, torch.int64), ptr(Y), N, int(rank),
                                    float(dropout), C.byref(g), ptr(pred), ptr(loss), stream()))
     return pred, loss
@@ -281,7 +306,7 @@ def opt_struct(kind, p, g, s1, s2, lr, wd, l2, clip, segments, overlap):
 
 
 def dccf_train_step(ctx, m, r, X, Y, rank, dropout, gU, gV, gW, gb, opt, step, pred=None, loss=None, touchedU=None,
-                    touchedV=None, X_next=None, step_next=0):
+                    touchedV=None, X_next=None, step_next=0, gextra=None):
     """forward + loss + backward + regularised optimizer step (dccf_train_step): BaseRunner.py:172-188 in one call.
     X_next (same shape as X) = the next call's batch, whose Philox step will be step_next: prepared inside this call's
     optimizer launch."""
@@ -292,7 +317,7 @@ def dccf_train_step(ctx, m, r, X, Y, rank, dropout, gU, gV, gW, gb, opt, step, p
         pred = torch.empty(N, dtype=torch.float32, device=X.device)
     if loss is None:
         loss = torch.empty(1, dtype=torch.float32, device=X.device)
-    g = GradsT(ptr(gU), ptr(gV), ptr(gW), ptr(gb), ptr(touchedU, torch.uint8), ptr(touchedV, torch.uint8))
+    g = grads_struct(gU, gV, gW, gb, touchedU, touchedV, gextra)
     opt.step = int(step)
     check(load().dccf_train_step(ctx.h, C.byref(m), C.byref(r), ptr(X, torch.int64), ptr(Y), N, int(rank), float(dropout),
                                  C.byref(g), C.byref(opt), ptr(pred), ptr(loss), ptr(X_next, torch.int64), int(step_next),
@@ -394,9 +419,9 @@ def debug_noise(L, F, std, seed, step, device):
     return out
 
 
-def debug_keep(L, D, dropout, seed, step, device):
+def debug_keep(L, D, dropout, seed, step, device, layer=0):
     out = torch.empty((L, D), dtype=torch.uint8, device=device)
-    check(load().dccf_debug_keep(L, D, float(dropout), int(seed), int(step), ptr(out), stream()))
+    check(load().dccf_debug_keep_layer(L, D, float(dropout), int(seed), int(step), int(layer), ptr(out), stream()))
     return out
 
 

@@ -6,7 +6,7 @@
 #include <string.h>
 #include "../../include/dccf_hip.h"
 
-#define DCCF_ABI_VERSION 1
+#define DCCF_ABI_VERSION 2
 #pragma clang fp contract(off)
 
 // ---------------------------------------------------------------------------------------------- errors

@@ -59,20 +59,24 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define KEEP(x) asm volatile("" ::"v"(x))
 
 struct Lay {
-  int DP, FP, NC, S1, ND, GY;
+  int DP, FP, NC, S1, ND, GY, DT;      // DT: the kernels' column tile (template D_) for a model of width D
   int64_t N, L, NS;
   size_t cand, WT, h, m, dmns, total;
+  size_t hx, dh;             // n_layers > 1: outputs of the extra layers [NX][L, DP]; two d loss / d h buffers [2][L, DP]
 };
 
-static Lay make_layout(int64_t N, int D, int F, int S, int A) {
+static Lay make_layout(int64_t N, int D, int F, int S, int A, int NX = 0) {
   Lay y;
   y.S1 = S + 1;
   y.N = N;
   y.NS = N * y.S1;
   y.L = y.NS * A;
   y.DP = D <= 32 ? 32 : (int)align_up(D, 64);
+  y.DT = D <= 16 ? 16 : (D <= 32 ? 32 : (D <= 64 ? 64 : 128));
   y.NC = (int)align_up(F, 128) / 128;
-  y.FP = (y.NC <= 2 ? 2 : (y.NC <= 6 ? 6 : 7)) * 128;      // W^T is zero-padded to the small-L forward's compile-time chunk count
+  // W^T is zero-padded to the forward's compile-time chunk count: 2, 6 or 7 chunks in one pass, passes of 6 beyond (F > 896)
+  y.FP = (y.NC <= 2 ? 2 : (y.NC <= 6 ? 6 : (y.NC == 7 ? 7 : (y.NC + 5) / 6 * 6))) * 128;
+  if (D != (D <= 16 ? 16 : (D <= 32 ? 32 : (D <= 64 ? 64 : 128)))) y.FP = (y.NC + 5) / 6 * 6 * 128;   // (fewer kernel instances)
   y.ND = y.DP == 32 ? 1 : 2;
   y.GY = y.DP == 32 ? 1 : y.DP / 64;
   size_t o = 0;
@@ -81,6 +85,8 @@ static Lay make_layout(int64_t N, int D, int F, int S, int A) {
   y.h = o;     o += align_up((size_t)y.L * y.DP * 4, 256);
   y.m = o;     o += align_up((size_t)y.L * 4, 256);
   y.dmns = o;  o += align_up((size_t)y.NS * 4, 256);
+  y.hx = o;    o += (size_t)NX * align_up((size_t)y.L * y.DP * 4, 256);
+  y.dh = o;    o += (size_t)(NX ? 2 : 0) * align_up((size_t)y.L * y.DP * 4, 256);
   y.total = o;
   return y;
 }
@@ -156,7 +162,12 @@ extern "C" int dccf_debug_trace_read(long long* out) {
 //   V[cand]) — its slices of W^T stay in registers.  Partials meet in LDS; the epilogue adds b, applies relu + dropout,
 //   stores h and m[l] = <U[u], h[l]>; its operands (user row, dropout draw, bias) are fetched before the k-loop.
 // NCM >= NC is the compile-time number of chunks (W^T is zero-padded to it: a group past F multiplies zeros).
-template <int D_, int MODE, int NCM, bool FAL>   // MODE 0: fused Philox draws, 1: injected noise / keep mask;
+// D_ is the column TILE (16, 32, 64 or 128); the model's real width Dr <= D_ (src/models/RecModel.py:17-27 accepts any) is a
+// run-time value: it is the stride of U / V / keep rows and of the feature part inside W^T, columns d >= Dr and item
+// k-steps k >= Dr multiply zeros.  MP (multi-pass, F > 896): the feature chunks are walked in passes of NCM, the wave's W^T
+// slice is re-read per pass (the register-resident slice of the single-pass form does not fit).
+template <int D_, int MODE, int NCM, bool FAL, bool MP, bool GEN>   // MODE 0: fused Philox draws, 1: injected noise / keep mask;
+                                                 // GEN: Dr < D_ (run-time row width); else Dr == D_ at compile time
                                                  // FAL: F == 128 * NCM exactly (no column clamp in the k-loop)
 __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT, const float* __restrict__ bias,
                                                    const float* __restrict__ U, const float* __restrict__ V,
@@ -166,7 +177,8 @@ __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT,
                                                    float* __restrict__ m, int64_t L, int S1,
                                                    int A, int F, rng_key nkey, rng_key dkey, float nscale,
                                                    uint32_t drop_thr, float kscale, StepRef sr, int store_h,
-                                                   float* __restrict__ zero1) {
+                                                   float* __restrict__ zero1, int Dr_, int npass) {
+  const int Dr = GEN ? Dr_ : D_;
   extern __shared__ float zpart[];   // [8][32][DW]
   TRACE(0);
   // prepared step (no k_prep ran): the loss accumulator k_pair_epilogue adds into starts at 0
@@ -190,28 +202,30 @@ __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT,
   const int dbase = blockIdx.y * DW;
   // register-resident B operands
   float bf[NGF * 4 * ND], bi[NGI * 4 * ND];
-#pragma unroll
-  for (int g = 0; g < NGF; ++g) {
-    const int q = wave * NGF + g, tq = q >> 4, c2 = q & 15;
-#pragma unroll
-    for (int o = 0; o < 4; ++o)
-#pragma unroll
-      for (int nt = 0; nt < ND; ++nt)
-        bf[(g * 4 + o) * ND + nt] = WT[(int64_t)(D + tq * 128 + 2 * c2 + h + 32 * o) * DP + dbase + nt * 32 + c31];
+#define FWD_LOAD_BF(PASS)                                                                                             \
+  _Pragma("unroll") for (int g = 0; g < NGF; ++g) {                                                                   \
+    const int q = wave * NGF + g, tq = (PASS) * NCM + (q >> 4), c2 = q & 15;                                         \
+    _Pragma("unroll") for (int o = 0; o < 4; ++o)                                                                     \
+      _Pragma("unroll") for (int nt = 0; nt < ND; ++nt)                                                               \
+        bf[(g * 4 + o) * ND + nt] = WT[(int64_t)(Dr + tq * 128 + 2 * c2 + h + 32 * o) * DP + dbase + nt * 32 + c31]; \
   }
+  if (!MP) { FWD_LOAD_BF(0) }
 #pragma unroll
   for (int gi = 0; gi < NGI; ++gi) {
     const int jg = wave * NGI + gi;
 #pragma unroll
     for (int o = 0; o < 4; ++o)
 #pragma unroll
-      for (int nt = 0; nt < ND; ++nt)
-        bi[(gi * 4 + o) * ND + nt] = jg < GI ? WT[(int64_t)(2 * (jg * 4 + o) + h) * DP + dbase + nt * 32 + c31] : 0.f;
+      for (int nt = 0; nt < ND; ++nt) {
+        const int kk = 2 * (jg * 4 + o) + h;         // item k-step: rows >= Dr of W^T belong to the feature part
+        const float wv = WT[(int64_t)min(kk, Dr - 1) * DP + dbase + nt * 32 + c31];
+        bi[(gi * 4 + o) * ND + nt] = (jg < GI && kk < Dr) ? wv : 0.f;
+      }
   }
   const uint32_t rows_per_n = (uint32_t)(S1 * A);
   const int64_t ntiles = (L + 31) / 32;
   const int dcol = dbase + lane;
-  const bool dv = lane < DW && dcol < D;
+  const bool dv = lane < DW && dcol < Dr;
   const float bias_d = bias[dv ? dcol : 0];
   TRACE(1);
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -223,10 +237,10 @@ __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT,
       const int64_t lr = tile * 32 + wave + 8 * i;
       const int64_t lrc = lr < L ? lr : (L - 1);
       const int64_t u = X[2 * (int64_t)((uint32_t)lrc / rows_per_n)];
-      uval[i] = U[u * D + (dv ? dcol : 0)];
+      uval[i] = U[u * Dr + (dv ? dcol : 0)];
       bool kept = true;
       if (MODE == 1) {
-        if (keep) kept = keep[lrc * D + (dv ? dcol : 0)] != 0;
+        if (keep) kept = keep[lrc * Dr + (dv ? dcol : 0)] != 0;
       } else if (drop_thr) {
         const u32x4 r4 = philox4x32_10((uint32_t)(lrc >> 2), (uint32_t)(dv ? dcol : 0), dkey.s0, dkey.s1, dkey.k0, dkey.k1);
         kept = pick4(r4, (int)(lrc & 3)) >= drop_thr;
@@ -250,9 +264,11 @@ __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT,
       const float* nrow = MODE == 1 ? noise + lc * F : nullptr;
       int fbase = h;
       asm volatile("" : "+v"(fbase));               // opaque per tile: the clamped offsets below must not be hoisted
+      for (int pass = 0; pass < (MP ? npass : 1); ++pass) {
+      if (MP) { FWD_LOAD_BF(pass) }
 #pragma unroll                                      // out of the tile loop and kept live (they would spill the W slice)
       for (int g = 0; g < NGF; ++g) {
-        const int q = wave * NGF + g, tq = q >> 4, c2 = q & 15;
+        const int q = wave * NGF + g, tq = pass * NCM + (q >> 4), c2 = q & 15;
         float a[4], fv[4];
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
@@ -270,15 +286,16 @@ __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT,
           for (int nt = 0; nt < ND; ++nt) acc[nt] = MFMA32(a[o], bf[(g * 4 + o) * ND + nt], acc[nt]);
         }
       }
+      }
     }
     {
-      const float* vrow = V + (int64_t)cand[(uint32_t)lc / (uint32_t)A] * D;
+      const float* vrow = V + (int64_t)cand[(uint32_t)lc / (uint32_t)A] * Dr;
 #pragma unroll
       for (int gi = 0; gi < NGI; ++gi) {
         const int jg = min(wave * NGI + gi, GI - 1);      // waves past the item part multiply zeros (bi = 0)
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-          const float a = vrow[2 * (jg * 4 + o) + h];
+          const float a = vrow[min(2 * (jg * 4 + o) + h, Dr - 1)];    // (k >= Dr: a real element times a zero of W^T)
 #pragma unroll
           for (int nt = 0; nt < ND; ++nt) acc[nt] = MFMA32(a, bi[(gi * 4 + o) * ND + nt], acc[nt]);
         }
@@ -321,6 +338,7 @@ __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT,
     __syncthreads();
   }
   TRACE(5);
+#undef FWD_LOAD_BF
 }
 
 // ================================================================================================ K2: pair epilogue
@@ -437,10 +455,12 @@ struct BwdArgs {
   const int64_t* X;
   const int* cand;
   const float *dmns, *hbuf, *noise;
+  const float* dh;           // DH (n_layers > 1): d loss / d h0 [L, DP] from the layers above; dz0 = dh * [h0 > 0] * kscale
   float *gU, *gV, *gW, *gb;
   uint8_t *touchedU, *touchedV;
   int64_t N;
   int S1, A, F, NC;
+  int Dr;                    // the model's row width (<= the template's tile D): stride of U / V / gU / gV rows, W is [Dr][Dr+F]
   float kscale, nscale;
   rng_key nkey;
   StepRef sr;
@@ -522,7 +542,7 @@ __device__ __forceinline__ float wave_dm_calc(const BwdArgs& p, int64_t n, const
 }
 
 // roles "feature chunk" (CHUNK) and "item": A = dz^T for the rows of n, B = eps (regenerated / injected) or V[cand]
-template <int D, int MODE, bool CHUNK, bool FOLD>
+template <int D, int MODE, bool CHUNK, bool FOLD, bool DH, bool GEN>
 __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int role, int dbase) {
   constexpr int DP = D <= 32 ? 32 : (D + 63) / 64 * 64;
   constexpr int ND = D <= 32 ? 1 : 2;
@@ -530,7 +550,7 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
   constexpr int NB = CHUNK ? 4 : NT;      // N tiles of this role
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, c31 = lane & 31;
-  const int S1 = p.S1, A = p.A, F = p.F;
+  const int S1 = p.S1, A = p.A, F = p.F, Dr = GEN ? p.Dr : D;
   const int rpn = S1 * A;
   const int KS = (rpn + 1) / 2;
   const int64_t n0 = (int64_t)blockIdx.x * BWD_NW + wave, nstride = (int64_t)gridDim.x * BWD_NW;
@@ -547,7 +567,7 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
 #pragma unroll
   for (int mt = 0; mt < ND; ++mt) {
     gb_acc[mt] = 0.f;
-    dok[mt] = dbase + mt * 32 + c31 < D;
+    dok[mt] = dbase + mt * 32 + c31 < Dr;
   }
   float lsum = 0.f;
   // One wave per SIMD walks its batch rows alone, so nothing hides a load round trip but the code itself: the ids of the
@@ -556,17 +576,18 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
   // the MFMA pipe (5 exposed round trips per batch row -> 1; in-kernel timestamps: main loop 17.5 -> see DESIGN.md).
   // All loads are unconditional from clamped addresses (a load inside `cond ? load : 0` makes hipcc branch around it and
   // wait vmcnt(0)); rows past the batch row read its last row and are zeroed through dm.
-#define BWD_LOAD_BATCH(J0, HV, DMV, BQ)                                                                          \
+#define BWD_LOAD_BATCH(J0, HV, DMV, BQ, DHV)                                                                         \
   _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                             \
     const int r_ = 2 * ((J0) + jj) + h;                                                                          \
     const int rc_ = min(r_, rpn - 1);                                                                            \
     const int64_t lr_ = n * rpn + rc_;                                                                           \
     const int64_t ns_ = n * S1 + rc_ / A;                                                                        \
-    if (!FOLD) DMV[jj] = p.dmns[ns_];                                                                            \
+    if (!FOLD && !DH) DMV[jj] = p.dmns[ns_];                                                                     \
     _Pragma("unroll") for (int mt = 0; mt < ND; ++mt) HV[jj][mt] = p.hbuf[lr_ * DP + dbase + mt * 32 + c31];     \
+    if (DH) { _Pragma("unroll") for (int mt = 0; mt < ND; ++mt) DHV[jj][mt] = p.dh[lr_ * DP + dbase + mt * 32 + c31]; } \
     if (!CHUNK) {                                                                                                \
-      const float* vrow_ = p.V + (int64_t)p.cand[ns_] * D;                                                       \
-      _Pragma("unroll") for (int nt = 0; nt < NB; ++nt) BQ[jj][nt] = vrow_[min(nt * 32 + c31, D - 1)];           \
+      const float* vrow_ = p.V + (int64_t)p.cand[ns_] * Dr;                                                      \
+      _Pragma("unroll") for (int nt = 0; nt < NB; ++nt) BQ[jj][nt] = vrow_[min(nt * 32 + c31, Dr - 1)];          \
     } else if (MODE == 1) {                                                                                      \
       _Pragma("unroll") for (int o = 0; o < NB; ++o)                                                             \
         BQ[jj][o] = p.noise[lr_ * F + min(role * 128 + 32 * o + c31, F - 1)];                                    \
@@ -595,7 +616,7 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
     float uv[ND], asum[ND], due[ND], fb[NB];
 #pragma unroll
     for (int mt = 0; mt < ND; ++mt) {
-      uv[mt] = p.U[u * D + min(dbase + mt * 32 + c31, D - 1)];
+      uv[mt] = p.U[u * Dr + min(dbase + mt * 32 + c31, Dr - 1)];
       asum[mt] = 0.f;
       due[mt] = 0.f;
     }
@@ -603,8 +624,8 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
 #pragma unroll
       for (int o = 0; o < NB; ++o) fb[o] = frow[min(role * 128 + 32 * o + c31, F - 1)];   // columns >= F are never stored
     }
-    float hv[4][ND], dmv[4], bq[4][NB];
-    BWD_LOAD_BATCH(0, hv, dmv, bq)
+    float hv[4][ND], dmv[4], bq[4][NB], dhv[4][ND];
+    BWD_LOAD_BATCH(0, hv, dmv, bq, dhv)
     if (FOLD) {
       dmn = wave_dm_calc(p, n, din, lsum, CHUNK && role == 0 && dbase == 0);
       din = dnx;
@@ -616,24 +637,28 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
     }
     if (n == n0) TRACEB(role, 3);
     for (int j0 = 0; j0 < KS; j0 += 4) {
-      float hv2[4][ND], dmv2[4], bq2[4][NB];
-      BWD_LOAD_BATCH(j0 + 4, hv2, dmv2, bq2)          // the next batch (past the end: clamped rows, never used)
+      float hv2[4][ND], dmv2[4], bq2[4][NB], dhv2[4][ND];
+      BWD_LOAD_BATCH(j0 + 4, hv2, dmv2, bq2, dhv2)    // the next batch (past the end: clamped rows, never used)
       if (FOLD) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) dmv[jj] = __shfl(dmn, min(2 * (j0 + jj) + h, rpn - 1) / A, 64);
       }
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {              // pin the current batch (its loads only), then mask
-        KEEP(dmv[jj]);
+        if (!DH) KEEP(dmv[jj]);
 #pragma unroll
         for (int mt = 0; mt < ND; ++mt) KEEP(hv[jj][mt]);
+        if (DH) {
+#pragma unroll
+          for (int mt = 0; mt < ND; ++mt) KEEP(dhv[jj][mt]);
+        }
         if (!CHUNK || MODE == 1) {
 #pragma unroll
           for (int o = 0; o < NB; ++o) KEEP(bq[jj][o]);
         }
         dmv[jj] = 2 * (j0 + jj) + h < rpn ? dmv[jj] : 0.f;
 #pragma unroll
-        for (int mt = 0; mt < ND; ++mt) hv[jj][mt] = dok[mt] ? hv[jj][mt] : 0.f;
+        for (int mt = 0; mt < ND; ++mt) hv[jj][mt] = (dok[mt] && (!DH || 2 * (j0 + jj) + h < rpn)) ? hv[jj][mt] : 0.f;
       }
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
@@ -642,9 +667,10 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
         float a[ND];
 #pragma unroll
         for (int mt = 0; mt < ND; ++mt) {
-          a[mt] = hv[jj][mt] > 0.f ? (dmv[jj] * uv[mt]) * p.kscale : 0.f;     // 0 for the k-steps past KS (dm = 0)
+          if (DH) a[mt] = hv[jj][mt] > 0.f ? dhv[jj][mt] * p.kscale : 0.f;    // (rows past the batch row: h masked to 0 above)
+          else a[mt] = hv[jj][mt] > 0.f ? (dmv[jj] * uv[mt]) * p.kscale : 0.f;     // 0 for the k-steps past KS (dm = 0)
           asum[mt] += a[mt];
-          due[mt] = fmaf(dmv[jj], hv[jj][mt], due[mt]);
+          if (!DH) due[mt] = fmaf(dmv[jj], hv[jj][mt], due[mt]);
         }
 #pragma unroll
         for (int mt = 0; mt < ND; ++mt)
@@ -656,6 +682,10 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
         dmv[jj] = dmv2[jj];
 #pragma unroll
         for (int mt = 0; mt < ND; ++mt) hv[jj][mt] = hv2[jj][mt];
+        if (DH) {
+#pragma unroll
+          for (int mt = 0; mt < ND; ++mt) dhv[jj][mt] = dhv2[jj][mt];
+        }
         if (!CHUNK || MODE == 1) {
 #pragma unroll
           for (int o = 0; o < NB; ++o) bq[jj][o] = bq2[jj][o];
@@ -679,12 +709,14 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
       for (int mt = 0; mt < ND; ++mt) {
         const float dt = due[mt] + __shfl_xor(due[mt], 32, 64);
         if (h == 0 && dok[mt]) {
-          float* gu = (p.slot_where ? p.slot_rows : p.gU) + urow_g * D;
-          atomicAdd(&gu[dbase + mt * 32 + c31], dt);
+          if (!DH) {           // (n_layers > 1: the user gradient comes from the LAST layer's output, k_gu_last)
+            float* gu = (p.slot_where ? p.slot_rows : p.gU) + urow_g * Dr;
+            atomicAdd(&gu[dbase + mt * 32 + c31], dt);
+          }
           gb_acc[mt] += tot[mt];
         }
       }
-      if (p.touchedU && lane == 0) p.touchedU[u] = 1;
+      if (!DH && p.touchedU && lane == 0) p.touchedU[u] = 1;
     }
   }
   KEEP(acc[0][0][0]);
@@ -709,9 +741,9 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
 #pragma unroll
       for (int w = 1; w < BWD_NW; ++w) v += red[(w * RQ + qq) * 64 + lane];
       const int d = dbase + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      const int col = CHUNK ? D + role * 128 + 32 * o + c31 : o * 32 + c31;
-      const bool ok = d < D && (CHUNK ? (role * 128 + 32 * o + c31 < F) : (col < D));
-      if (ok) atomicAdd(&p.gW[(int64_t)d * (D + F) + col], v);
+      const int col = CHUNK ? Dr + role * 128 + 32 * o + c31 : o * 32 + c31;
+      const bool ok = d < Dr && (CHUNK ? (role * 128 + 32 * o + c31 < F) : (col < Dr));
+      if (ok) atomicAdd(&p.gW[(int64_t)d * (Dr + F) + col], v);
     }
   }
   if (CHUNK && role == 0 && h == 0) {
@@ -725,14 +757,14 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
 #undef BWD_LOAD_BATCH
 
 // role "dx": gV[cand] += dz W_i   (MFMA: M = rows of n, N = d', K = d)
-template <int D, bool FOLD>
+template <int D, bool FOLD, bool DH, bool GEN>
 __device__ __forceinline__ void bwd_dx_role(const BwdArgs& p, int dbase) {
   constexpr int DP = D <= 32 ? 32 : (D + 63) / 64 * 64;
   constexpr int ND = D <= 32 ? 1 : 2;
   constexpr int KD = D / 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, c31 = lane & 31;
-  const int S1 = p.S1, A = p.A, F = p.F;
+  const int S1 = p.S1, A = p.A, F = p.F, Dr = GEN ? p.Dr : D;
   const int rpn = S1 * A;
   const int64_t n0 = (int64_t)blockIdx.x * BWD_NW + wave, nstride = (int64_t)gridDim.x * BWD_NW;
   TRACEB(7, 0);
@@ -742,12 +774,12 @@ __device__ __forceinline__ void bwd_dx_role(const BwdArgs& p, int dbase) {
 #pragma unroll
     for (int nt = 0; nt < ND; ++nt) {
       const int dd = dbase + nt * 32 + c31;
-      const float wx = p.W[(int64_t)(2 * j + h) * (D + F) + min(dd, D - 1)];
-      wd[j][nt] = dd < D ? wx : 0.f;
+      const float wx = p.W[(int64_t)min(2 * j + h, Dr - 1) * (Dr + F) + min(dd, Dr - 1)];
+      wd[j][nt] = (dd < Dr && 2 * j + h < Dr) ? wx : 0.f;
     }
   const int RT = (rpn + 31) / 32;
   for (int64_t n = n0; n < p.N; n += nstride) {
-    const float* urow = p.U + p.X[2 * n] * D;
+    const float* urow = p.U + p.X[2 * n] * Dr;
     float dmn = 0.f, lnone = 0.f;
     if (FOLD) {
       DmIn din;
@@ -765,6 +797,7 @@ __device__ __forceinline__ void bwd_dx_role(const BwdArgs& p, int dbase) {
       KEEP(dm0);
       const float dmv = lv ? dm0 : 0.f;
       const float* hrow = p.hbuf + l * DP;
+      const float* dhrow = DH ? p.dh + l * DP : hrow;
       // where the 8 candidate rows this lane will emit go (A == 2): candidate id, or in slot mode its slot of the all-gather
       // buffer — fetched now, so the dependent lookups are over when the accumulators are ready
       int sl8[8];
@@ -788,8 +821,8 @@ __device__ __forceinline__ void bwd_dx_role(const BwdArgs& p, int dbase) {
         float hvv[JB], uxx[JB];
 #pragma unroll
         for (int jj = 0; jj < JB; ++jj) {           // issue the batch's loads ...
-          hvv[jj] = hrow[2 * (j0 + jj) + h];
-          uxx[jj] = urow[2 * (j0 + jj) + h];
+          hvv[jj] = hrow[2 * (j0 + jj) + h];                       // (columns >= Dr of h are never written: masked below)
+          uxx[jj] = DH ? dhrow[2 * (j0 + jj) + h] : urow[min(2 * (j0 + jj) + h, Dr - 1)];
         }
 #pragma unroll
         for (int jj = 0; jj < JB; ++jj) {           // ... then pin them (one wait for the batch)
@@ -798,7 +831,8 @@ __device__ __forceinline__ void bwd_dx_role(const BwdArgs& p, int dbase) {
         }
 #pragma unroll
         for (int jj = 0; jj < JB; ++jj) {
-          const float a = hvv[jj] > 0.f ? (dmv * uxx[jj]) * p.kscale : 0.f;
+          const bool on = hvv[jj] > 0.f && (D == Dr || 2 * (j0 + jj) + h < Dr);
+          const float a = DH ? ((on && lv) ? uxx[jj] * p.kscale : 0.f) : (on ? (dmv * uxx[jj]) * p.kscale : 0.f);
 #pragma unroll
           for (int nt = 0; nt < ND; ++nt) acc[nt] = MFMA32(a, wd[j0 + jj][nt], acc[nt]);
         }
@@ -811,9 +845,9 @@ __device__ __forceinline__ void bwd_dx_role(const BwdArgs& p, int dbase) {
 #pragma unroll
           for (int r = 0; r < 16; r += 2) {
             const int ro = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (ro < rpn && dd < D) {
+            if (ro < rpn && dd < Dr) {
               const int64_t ci = sl8[r >> 1];
-              float* gv = (p.slot_where ? p.slot_rows : p.gV) + ci * D;
+              float* gv = (p.slot_where ? p.slot_rows : p.gV) + ci * Dr;
               atomicAdd(&gv[dd], acc[nt][r] + acc[nt][r + 1]);
               if (p.touchedV && c31 == 0 && nt == 0) p.touchedV[ci] = 1;
             }
@@ -822,9 +856,9 @@ __device__ __forceinline__ void bwd_dx_role(const BwdArgs& p, int dbase) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int ro = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (ro < rpn && dd < D) {
+            if (ro < rpn && dd < Dr) {
               const int64_t ci = p.cand[n * S1 + ro / A];
-              float* gv = p.slot_where ? p.slot_rows + (int64_t)min((unsigned)p.slot_where[p.slot_offV + ci], (unsigned)(p.slot_cap - 1)) * D : p.gV + ci * D;
+              float* gv = p.slot_where ? p.slot_rows + (int64_t)min((unsigned)p.slot_where[p.slot_offV + ci], (unsigned)(p.slot_cap - 1)) * Dr : p.gV + ci * Dr;
               atomicAdd(&gv[dd], acc[nt][r]);
               if (p.touchedV && c31 == 0 && nt == 0) p.touchedV[ci] = 1;
             }
@@ -835,7 +869,7 @@ __device__ __forceinline__ void bwd_dx_role(const BwdArgs& p, int dbase) {
   }
 }
 
-template <int D_, int MODE, bool FOLD>
+template <int D_, int MODE, bool FOLD, bool DH, bool GEN>
 __global__ __launch_bounds__(64 * BWD_NW) BWD_WPE void k_bwd(BwdArgs p) {
   extern __shared__ float red[];          // [BWD_NW waves][128 / BWD_NW regs][64 lanes]
   {
@@ -856,32 +890,260 @@ __global__ __launch_bounds__(64 * BWD_NW) BWD_WPE void k_bwd(BwdArgs p) {
     else opt_untouched_pass<DCCF_OPT_ADAM, 4>(p.oj, bid, nblk, 64 * BWD_NW);
     return;
   }
-  if (role < p.NC) bwd_col_role<D_, MODE, true, FOLD>(p, red, role, dbase);
-  else if (role == p.NC) bwd_col_role<D_, MODE, false, FOLD>(p, red, role, dbase);
-  else bwd_dx_role<D_, FOLD>(p, dbase);
+  if (role < p.NC) bwd_col_role<D_, MODE, true, FOLD, DH, GEN>(p, red, role, dbase);
+  else if (role == p.NC) bwd_col_role<D_, MODE, false, FOLD, DH, GEN>(p, red, role, dbase);
+  else bwd_dx_role<D_, FOLD, DH, GEN>(p, dbase);
   if (role > p.NC) TRACEB(7, 2);
+}
+
+// ================================================================================================ K4: extra mlp layers
+// --n_layers > 1 (src/models/DMF.py:14): after mlp.0 the reference runs n_layers - 1 more Linear(D -> D) + relu + dropout
+// (src/models/DCCF.py:61-62,91-94) before the dot with the user row.  Each extra layer is one forward launch over the rows l
+// (h_k = drop(relu(h_{k-1} W_k^T + b_k)), the last one also writes m[l] = <U[u], h_k[l]>) and one backward launch
+// (dz_k = dh_k * [h_k > 0] * kscale;  gW_k += dz_k^T h_{k-1};  gb_k += sum dz_k;  dh_{k-1} = dz_k W_k).  The first layer's
+// backward (k_bwd, DH) then starts from dh_0 instead of dm * U[u].  fp32 MFMA like the rest; W_k (<= 64 KB) sits in LDS.
+// These launches exist only for n_layers > 1: the default path is untouched.
+struct MlpArgs {
+  const float* hin;          // [L, DP] h_{k-1}
+  float* hout;               // forward: [L, DP] h_k (written);  backward: read as h_k
+  const float* W;            // mlp.k.weight [Dr, Dr]
+  const float* b;            // mlp.k.bias [Dr]
+  const float* U;
+  const int64_t* X;
+  const uint8_t* keep;       // injected keep mask of this layer [L, Dr] (NULL: keep all / fused draws)
+  float* m;                  // forward, last layer: m[l] = <U[u(l)], h_k[l]>
+  const float* dmns;         // backward, last layer: d loss / d (mean_a m) per (n, s)
+  const float* dhin;         // backward, other layers: dh_k [L, DP]
+  float* dhout;              // backward: dh_{k-1} [L, DP]
+  float* gW;                 // backward: [Dr, Dr] (+=)
+  float* gb;                 // backward: [Dr] (+=)
+  int64_t L;
+  int rpn, A, Dr, DP, layer, last, fused;
+  uint32_t drop_thr;
+  float kscale;
+  rng_key dkey;
+  StepRef sr;
+};
+
+template <int D_>
+__global__ __launch_bounds__(256) void k_mlp_fwd(MlpArgs p) {
+  extern __shared__ float wl[];            // [DPF][DPF]: wl[k][n] = W[n][k] (zero beyond Dr)
+  constexpr int DPF = D_ <= 32 ? 32 : (D_ <= 64 ? 64 : 128);
+  constexpr int NT = DPF / 32, KH = DPF / 2;
+  {
+    const int64_t k = step_k(p.sr);
+    p.X = step_X(p.sr, p.X, k);
+    p.dkey = key_plus(p.dkey, k);
+  }
+  const int Dr = p.Dr, DP = p.DP;
+  for (int idx = threadIdx.x; idx < DPF * DPF; idx += blockDim.x) {
+    const int k = idx / DPF, n = idx % DPF;
+    wl[idx] = (k < Dr && n < Dr) ? p.W[(int64_t)n * Dr + k] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, c31 = lane & 31;
+  const int64_t ntiles = (p.L + 31) / 32;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t l = tile * 32 + c31;
+    const float* hrow = p.hin + (l < p.L ? l : p.L - 1) * DP;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    for (int j0 = 0; j0 < KH; j0 += 8) {
+      float a[8];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) a[jj] = hrow[h * KH + j0 + jj];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const int k = h * KH + j0 + jj;
+        const float av = (k < Dr && l < p.L) ? a[jj] : 0.f;      // columns >= Dr of the first layer's h are never written
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = MFMA32(av, wl[k * DPF + nt * 32 + c31], acc[nt]);
+      }
+    }
+    // epilogue: + b, relu, dropout; h_k stored over the whole padded width (zeros beyond Dr)
+    float part[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[r] = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = nt * 32 + c31;
+      const bool cv = col < Dr;
+      const float bd = p.b[cv ? col : 0];
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int64_t l4 = tile * 32 + 8 * rq + 4 * h;          // 4 consecutive rows, l4 % 4 == 0: one Philox call
+        u32x4 r4{0, 0, 0, 0};
+        if (p.fused && p.drop_thr)
+          r4 = philox4x32_10((uint32_t)(l4 >> 2), (uint32_t)(cv ? col : 0) | ((uint32_t)p.layer << 16), p.dkey.s0, p.dkey.s1,
+                             p.dkey.k0, p.dkey.k1);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const int64_t lr = l4 + w;
+          const int64_t lrc = lr < p.L ? lr : p.L - 1;
+          bool kept = true;
+          if (!p.fused) {
+            if (p.keep) kept = p.keep[lrc * Dr + (cv ? col : 0)] != 0;
+          } else if (p.drop_thr) {
+            kept = pick4(r4, w) >= p.drop_thr;
+          }
+          const float z = acc[nt][rq * 4 + w] + bd;
+          const float hv = (cv && z > 0.f && kept) ? z * p.kscale : 0.f;
+          if (lr < p.L) p.hout[lr * DP + col] = hv;
+          if (p.last) {
+            const int64_t u = p.X[2 * (int64_t)((uint32_t)lrc / (uint32_t)p.rpn)];
+            part[rq * 4 + w] += p.U[u * Dr + (cv ? col : 0)] * hv;
+          }
+        }
+      }
+    }
+    if (p.last) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = part[r];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 1, 64);
+        const int64_t lr = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (c31 == 0 && lr < p.L) p.m[lr] = v;
+      }
+    }
+  }
+}
+
+// dz of layer k at (row l, column d) — shared by the two operand layouts of k_mlp_bwd
+__device__ __forceinline__ float mlp_dz(const MlpArgs& p, int64_t l, int d) {
+  if (l >= p.L || d >= p.Dr) return 0.f;
+  const float hk = p.hout[l * p.DP + d];
+  float dh;
+  if (p.last) {
+    const int64_t u = p.X[2 * (int64_t)((uint32_t)l / (uint32_t)p.rpn)];
+    dh = p.dmns[(uint32_t)l / (uint32_t)p.A] * p.U[u * p.Dr + d];
+  } else {
+    dh = p.dhin[l * p.DP + d];
+  }
+  return hk > 0.f ? dh * p.kscale : 0.f;
+}
+
+template <int D_>
+__global__ __launch_bounds__(256) void k_mlp_bwd(MlpArgs p) {
+  extern __shared__ float wl[];            // [DPF][DPF]: wl[d][d'] = W[d][d'] (zero beyond Dr)
+  constexpr int DPF = D_ <= 32 ? 32 : (D_ <= 64 ? 64 : 128);
+  constexpr int NT = DPF / 32, KH = DPF / 2, MT = NT, TS = 4 / MT;
+  {
+    const int64_t k = step_k(p.sr);
+    p.X = step_X(p.sr, p.X, k);
+  }
+  const int Dr = p.Dr, DP = p.DP;
+  for (int idx = threadIdx.x; idx < DPF * DPF; idx += blockDim.x) {
+    const int d = idx / DPF, n = idx % DPF;
+    wl[idx] = (d < Dr && n < Dr) ? p.W[(int64_t)d * Dr + n] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, c31 = lane & 31;
+  const int cm = wave % MT, ts = wave / MT;          // this wave's 32-column block and tile sub-stream
+  const int64_t ntiles = (p.L + 31) / 32;
+  f32x16 accW[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accW[nt][r] = 0.f;
+  float gbacc = 0.f;
+  for (int64_t tile = (int64_t)blockIdx.x * TS + ts; tile < ntiles; tile += (int64_t)gridDim.x * TS) {
+    // (1) dh_{k-1}[rows of the tile][cm*32 ..] = dz W_k : M = rows, N = this wave's columns, K = d (k-step j: d = h*KH + j)
+    {
+      const int64_t l = tile * 32 + c31;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      for (int j = 0; j < KH; ++j) {
+        const int d = h * KH + j;
+        acc = MFMA32(mlp_dz(p, l, d), wl[d * DPF + cm * 32 + c31], acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t lr = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (lr < p.L) p.dhout[lr * DP + cm * 32 + c31] = acc[r];
+      }
+    }
+    // (2) gW_k[cm*32 + m][:] += dz^T h_{k-1} : M = this wave's d block, N = d', K = rows (k-step j: row = 2j + h)
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {
+      const int64_t lr = tile * 32 + 2 * j + h;
+      const float a = mlp_dz(p, lr, cm * 32 + c31);
+      gbacc += a;
+      const float* hp = p.hin + (lr < p.L ? lr : p.L - 1) * DP;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float bv = hp[nt * 32 + c31];
+        accW[nt] = MFMA32(a, (nt * 32 + c31 < Dr && lr < p.L) ? bv : 0.f, accW[nt]);
+      }
+    }
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int mrow = cm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, n = nt * 32 + c31;
+      if (mrow < Dr && n < Dr && accW[nt][r] != 0.f) atomicAdd(&p.gW[(int64_t)mrow * Dr + n], accW[nt][r]);
+    }
+  gbacc += __shfl_xor(gbacc, 32, 64);
+  if (h == 0 && cm * 32 + c31 < Dr && gbacc != 0.f) atomicAdd(&p.gb[cm * 32 + c31], gbacc);
+}
+
+// gU[u(n)] += sum_l dm[l] h_last[l]  (n_layers > 1: the user row meets the LAST layer's output, src/models/DCCF.py:96);
+// one wave per batch row, one atomic row add (into gU or, in the replicated path's slot mode, the row's buffer slot)
+__global__ __launch_bounds__(256) void k_gu_last(const float* __restrict__ hlast, const float* __restrict__ dmns, const int64_t* X,
+                                                 float* gU, uint8_t* touchedU, int64_t N, int S1, int A, int Dr, int DP,
+                                                 const int* slot_where, float* slot_rows, int64_t slot_offU, int slot_cap,
+                                                 StepRef sr) {
+  X = step_X(sr, X, step_k(sr));
+  const int lane = threadIdx.x & 63;
+  const int64_t w0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int rpn = S1 * A;
+  for (int64_t n = w0; n < N; n += nw) {
+    float a0 = 0.f, a1 = 0.f;
+    for (int r = 0; r < rpn; ++r) {
+      const float dm = dmns[n * S1 + r / A];
+      const float* hr = hlast + (n * rpn + r) * DP;
+      if (lane < Dr) a0 = fmaf(dm, hr[lane], a0);
+      if (lane + 64 < Dr) a1 = fmaf(dm, hr[lane + 64], a1);
+    }
+    const int64_t u = X[2 * n];
+    float* g = slot_where ? slot_rows + (int64_t)min((unsigned)slot_where[slot_offU + u], (unsigned)(slot_cap - 1)) * Dr : gU + u * Dr;
+    if (lane < Dr) atomicAdd(&g[lane], a0);
+    if (lane + 64 < Dr) atomicAdd(&g[lane + 64], a1);
+    if (touchedU && lane == 0) touchedU[u] = 1;
+  }
 }
 
 // ================================================================================================ host side
 static int check_model(const dccf_model_t* M) {
   ARG_CHECK(M != nullptr, "model is NULL");
-  ARG_CHECK(M->D == 16 || M->D == 32 || M->D == 64 || M->D == 128, "D must be 16, 32, 64 or 128");
-  ARG_CHECK(M->F >= 1 && M->F <= 896, "F must be in [1, 896] (at most 7 feature chunks of 128)");
+  ARG_CHECK(M->D >= 1 && M->D <= 128, "D must be in [1, 128]");
+  ARG_CHECK(M->F >= 1 && M->F <= 65536, "F must be in [1, 65536]");
   ARG_CHECK(M->S >= 0 && M->S <= 63 && M->A >= 1 && M->A <= 64, "S in [0,63], A in [1,64]");
   ARG_CHECK(M->user_num > 0 && M->item_num > 0 && M->item_num < 2147483647LL, "bad user_num / item_num");
   ARG_CHECK(M->U && M->V && M->W && M->b && M->feat, "NULL parameter / feature pointer");
   ARG_CHECK(M->expo || (M->ipsP && M->ipsQ && M->ipsBu && M->ipsBi && M->ipsProp && M->ipsD > 0),
             "need expo or the IPS factors");
+  ARG_CHECK(M->n_extra >= 0 && M->n_extra <= DCCF_MAX_EXTRA, "n_extra (--n_layers - 1) must be in [0, 7]");
+  for (int k = 0; k < M->n_extra; ++k) ARG_CHECK(M->Wl[k] && M->bl[k], "NULL weight / bias of an extra mlp layer");
   return 0;
 }
 
-#define BY_D(D, CALL)              \
-  switch (D) {                     \
-    case 16: { CALL(16); } break;  \
-    case 32: { CALL(32); } break;  \
-    case 64: { CALL(64); } break;  \
-    default: { CALL(128); } break; \
-  }
+// the column tile of a model of width D (any D in [1, 128]: src/models/RecModel.py:17-27)
+#define BY_D(D, CALL)                   \
+  if ((D) <= 16) { CALL(16); }          \
+  else if ((D) <= 32) { CALL(32); }     \
+  else if ((D) <= 64) { CALL(64); }     \
+  else { CALL(128); }
 
 // The optimizer half of dccf_train_step, threaded through run_dccf: `overlap` forks the untouched-row pass onto the
 // context's side stream right after k_prep has marked the rows of this batch.
@@ -895,7 +1157,7 @@ bool dccf_prep_matches(const dccf_ctx* ctx, const dccf_model_t* M, const dccf_ra
 
 int dccf_prep_next_fill(dccf_ctx* ctx, const dccf_model_t* M, int64_t N, const int64_t* X_next, uint64_t seed, uint64_t step_next,
                         PrepNext* pn) {
-  const Lay y = make_layout(N, M->D, M->F, M->S, M->A);
+  const Lay y = make_layout(N, M->D, M->F, M->S, M->A, M->n_extra);
   if (int e = dccf_ws_ensure(ctx, y.total)) return e;
   memset(pn, 0, sizeof(*pn));
   char* ws = ctx->ws;
@@ -959,8 +1221,11 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     if (plan) return dccf_opt_phase(plan->opt, OPT_PHASE_ALL, nullptr, nullptr, 0, st);
     return 0;
   }
-  const int D = M->D, F = M->F, S1 = M->S + 1, A = M->A;
-  const Lay y = make_layout(N, D, F, M->S, A);
+  const int D = M->D, F = M->F, S1 = M->S + 1, A = M->A, NX = M->n_extra;
+  if (train && NX > 0) {
+    for (int k = 0; k < NX; ++k) ARG_CHECK(G->gWl[k] && G->gbl[k], "NULL gradient pointer of an extra mlp layer");
+  }
+  const Lay y = make_layout(N, D, F, M->S, A, NX);
   if (int e = dccf_ws_ensure(ctx, y.total)) return e;
   char* ws = ctx->ws;
   int* cand = (int*)(ws + y.cand);
@@ -968,6 +1233,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
   float* hbuf = (float*)(ws + y.h);
   float* m = (float*)(ws + y.m);
   float* dmns = (float*)(ws + y.dmns);
+  const size_t hstride = align_up((size_t)y.L * y.DP * 4, 256);     // bytes between the h / dh buffers of the extra layers
 
   const rng_key ckey = make_key(rnd->seed, STREAM_CAND, rnd->step);
   const rng_key nkey = make_key(rnd->seed, STREAM_NOISE, rnd->step);
@@ -1038,21 +1304,23 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     const dim3 grid((unsigned)min((int64_t)1024, ntiles), y.GY), block(512);
     const size_t smem = (size_t)8 * 32 * y.ND * 32 * 4;
     prof_begin(ctx, st);
-#define LAUNCH_FWD3(D_, MODE_, NCM_, FAL_)                                                                            \
+#define LAUNCH_FWD3(D_, MODE_, NCM_, FAL_, MP_, GEN_)                                                                 \
   {                                                                                                                  \
     static bool once = false;                                                                                        \
     if (!once) {                                                                                                     \
-      HIP_TRY(hipFuncSetAttribute((const void*)k_noise_fwd<D_, MODE_, NCM_, FAL_>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
+      HIP_TRY(hipFuncSetAttribute((const void*)k_noise_fwd<D_, MODE_, NCM_, FAL_, MP_, GEN_>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
       once = true;                                                                                                   \
     }                                                                                                                \
-    hipLaunchKernelGGL((k_noise_fwd<D_, MODE_, NCM_, FAL_>), grid, block, smem, st, WT, M->b, M->U, M->V, M->feat, X, cand, \
-                       rnd->noise, rnd->keep, hbuf, m, y.L, S1, A, F, nkey, dkey, nscale, thr, kscale, sr, train ? 1 : 0,  \
-                       prepared ? loss : (float*)nullptr);                                                           \
+    hipLaunchKernelGGL((k_noise_fwd<D_, MODE_, NCM_, FAL_, MP_, GEN_>), grid, block, smem, st, WT, M->b, M->U, M->V, M->feat, X, cand, \
+                       rnd->noise, rnd->keep, hbuf, m, y.L, S1, A, F, nkey, dkey, nscale, thr, kscale, sr,          \
+                       (train || NX > 0) ? 1 : 0, prepared ? loss : (float*)nullptr, D, y.FP / 768);                 \
   }
 #define LAUNCH_FWD2(D_, MODE_)                                                                          \
-  if (y.FP == 256) { if (F == 256) LAUNCH_FWD3(D_, MODE_, 2, true) else LAUNCH_FWD3(D_, MODE_, 2, false) }      \
-  else if (y.FP == 768) { if (F == 768) LAUNCH_FWD3(D_, MODE_, 6, true) else LAUNCH_FWD3(D_, MODE_, 6, false) } \
-  else LAUNCH_FWD3(D_, MODE_, 7, false)
+  if (D != D_) { if (y.FP == 768) LAUNCH_FWD3(D_, MODE_, 6, false, false, true) else LAUNCH_FWD3(D_, MODE_, 6, false, true, true) } \
+  else if (y.FP == 256) { if (F == 256) LAUNCH_FWD3(D_, MODE_, 2, true, false, false) else LAUNCH_FWD3(D_, MODE_, 2, false, false, false) }      \
+  else if (y.FP == 768) { if (F == 768) LAUNCH_FWD3(D_, MODE_, 6, true, false, false) else LAUNCH_FWD3(D_, MODE_, 6, false, false, false) } \
+  else if (y.FP == 896) LAUNCH_FWD3(D_, MODE_, 7, false, false, false)                                  \
+  else LAUNCH_FWD3(D_, MODE_, 6, false, true, false)
 #define LAUNCH_FWD(D_) if (fused) LAUNCH_FWD2(D_, 0) else LAUNCH_FWD2(D_, 1)
     BY_D(D, LAUNCH_FWD)
 #undef LAUNCH_FWD
@@ -1060,8 +1328,35 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
 #undef LAUNCH_FWD3
     prof_end(ctx, 2, st);
   }
+  // --n_layers > 1: the extra D -> D layers, one launch each (the last writes m)
+  MlpArgs ma;
+  memset(&ma, 0, sizeof(ma));
+  const size_t mlp_smem = (size_t)y.DP * y.DP * 4;
+  const int mlp_grid = (int)max((int64_t)1, min((int64_t)1024, (ntiles + 3) / 4));
+#define MLP_ATTR(KERNEL)                                                                                              \
+  {                                                                                                                  \
+    static bool once = false;                                                                                        \
+    if (!once) {                                                                                                     \
+      HIP_TRY(hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));      \
+      once = true;                                                                                                   \
+    }                                                                                                                \
+  }
+  if (NX > 0) {
+    ma.U = M->U; ma.X = X; ma.m = m; ma.dmns = dmns; ma.L = y.L; ma.rpn = S1 * A; ma.A = A; ma.Dr = D; ma.DP = y.DP;
+    ma.fused = fused ? 1 : 0; ma.drop_thr = thr; ma.kscale = kscale; ma.dkey = dkey; ma.sr = sr;
+    for (int k = 1; k <= NX; ++k) {
+      ma.hin = k == 1 ? hbuf : (const float*)(ws + y.hx + (size_t)(k - 2) * hstride);
+      ma.hout = (float*)(ws + y.hx + (size_t)(k - 1) * hstride);
+      ma.W = M->Wl[k - 1]; ma.b = M->bl[k - 1];
+      ma.keep = (!fused && rnd->keep) ? rnd->keep + (size_t)k * (size_t)y.L * D : nullptr;
+      ma.layer = k; ma.last = k == NX ? 1 : 0;
+#define LAUNCH_MF(D_) MLP_ATTR(k_mlp_fwd<D_>) hipLaunchKernelGGL(k_mlp_fwd<D_>, dim3(mlp_grid), dim3(256), mlp_smem, st, ma)
+      BY_D(D, LAUNCH_MF)
+#undef LAUNCH_MF
+    }
+  }
   // training with at most 16 candidates per row: the pair epilogue is folded into the backward (wave_dm)
-  const bool fold = train && S1 <= 16 && A <= 4 && N <= knobs().fold_max_n;
+  const bool fold = train && NX == 0 && D == y.DT && S1 <= 16 && A <= 4 && N <= knobs().fold_max_n;
   if (!fold) {
     const int64_t units = (train && rank == 1) ? N / 2 : N;
     const int GS = S1 <= 16 ? 16 : (S1 <= 32 ? 32 : 64);
@@ -1085,22 +1380,49 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     const dim3 grid((unsigned)gx, (unsigned)(roles + opt_rows_y));
     const size_t smem = (size_t)4 * 32 * 64 * 4;
     prof_begin(ctx, st);
-#define LAUNCH_BWD3(D_, MODE_, FOLD_)                                                                                \
+#define LAUNCH_BWD3(D_, MODE_, FOLD_, DH_, GEN_)                                                                     \
   {                                                                                                                  \
     static bool once = false;                                                                                        \
     if (!once) {                                                                                                     \
-      HIP_TRY(hipFuncSetAttribute((const void*)k_bwd<D_, MODE_, FOLD_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+      HIP_TRY(hipFuncSetAttribute((const void*)k_bwd<D_, MODE_, FOLD_, DH_, GEN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
       once = true;                                                                                                   \
     }                                                                                                                \
-    hipLaunchKernelGGL((k_bwd<D_, MODE_, FOLD_>), grid, dim3(64 * BWD_NW), smem, st, ba);                            \
+    hipLaunchKernelGGL((k_bwd<D_, MODE_, FOLD_, DH_, GEN_>), grid, dim3(64 * BWD_NW), smem, st, ba);                 \
   }
-#define LAUNCH_BWD2(D_, MODE_) if (fold) LAUNCH_BWD3(D_, MODE_, true) else LAUNCH_BWD3(D_, MODE_, false)
+#define LAUNCH_BWD2(D_, MODE_)                                                                                       \
+  if (D != D_) { if (NX > 0) LAUNCH_BWD3(D_, MODE_, false, true, true) else LAUNCH_BWD3(D_, MODE_, false, false, true) } \
+  else if (NX > 0) LAUNCH_BWD3(D_, MODE_, false, true, false)                                                       \
+  else if (fold) LAUNCH_BWD3(D_, MODE_, true, false, false)                                                         \
+  else LAUNCH_BWD3(D_, MODE_, false, false, false)
 #define LAUNCH_BWD(D_) if (fused) LAUNCH_BWD2(D_, 0) else LAUNCH_BWD2(D_, 1)
     BwdArgs ba;
+    ba.dh = nullptr;
+    if (NX > 0) {
+      // the extra layers, last to first: gW_k, gb_k and dh_{k-1}; then the user gradient from the last layer's output
+      float* dhA = (float*)(ws + y.dh);
+      float* dhB = (float*)(ws + y.dh + hstride);
+      const int bgrid = (int)max((int64_t)1, min((int64_t)512, (ntiles + 3) / 4));
+      for (int k = NX; k >= 1; --k) {
+        ma.hin = k == 1 ? hbuf : (const float*)(ws + y.hx + (size_t)(k - 2) * hstride);
+        ma.hout = (float*)(ws + y.hx + (size_t)(k - 1) * hstride);
+        ma.W = M->Wl[k - 1]; ma.b = M->bl[k - 1];
+        ma.gW = G->gWl[k - 1]; ma.gb = G->gbl[k - 1];
+        ma.layer = k; ma.last = k == NX ? 1 : 0;
+        ma.dhin = ((NX - k) & 1) ? dhA : dhB;          // (unused by the last layer)
+        ma.dhout = ((NX - k) & 1) ? dhB : dhA;
+#define LAUNCH_MB(D_) MLP_ATTR(k_mlp_bwd<D_>) hipLaunchKernelGGL(k_mlp_bwd<D_>, dim3(bgrid), dim3(256), mlp_smem, st, ma)
+        BY_D(D, LAUNCH_MB)
+#undef LAUNCH_MB
+      }
+      ba.dh = ma.dhout;
+      hipLaunchKernelGGL(k_gu_last, dim3((unsigned)min((int64_t)1024, (N + 3) / 4)), dim3(256), 0, st,
+                         (const float*)(ws + y.hx + (size_t)(NX - 1) * hstride), (const float*)dmns, X, G->gU, G->touchedU, N, S1, A,
+                         D, y.DP, ctx->slot_where, ctx->slot_rows, ctx->slot_offU, ctx->slot_cap, sr);
+    }
     ba.W = M->W; ba.U = M->U; ba.V = M->V; ba.feat = M->feat; ba.X = X; ba.cand = cand; ba.dmns = dmns; ba.hbuf = hbuf;
     ba.noise = rnd->noise; ba.gU = G->gU; ba.gV = G->gV; ba.gW = G->gW; ba.gb = G->gb;
     ba.touchedU = G->touchedU; ba.touchedV = G->touchedV; ba.N = N; ba.S1 = S1; ba.A = A;
-    ba.F = F; ba.NC = y.NC; ba.kscale = kscale; ba.nscale = nscale; ba.nkey = nkey; ba.sr = sr;
+    ba.F = F; ba.NC = y.NC; ba.Dr = D; ba.kscale = kscale; ba.nscale = nscale; ba.nkey = nkey; ba.sr = sr;
     ba.m = m; ba.Y = Y; ba.pred = pred; ba.loss = loss; ba.rank = rank;
     ba.slot_where = ctx->slot_where; ba.slot_rows = ctx->slot_rows; ba.slot_offU = ctx->slot_offU; ba.slot_offV = ctx->slot_offV;
     ba.slot_cap = ctx->slot_cap;
@@ -1226,7 +1548,7 @@ extern "C" int dccf_train_step(dccf_ctx* ctx, const dccf_model_t* M, const dccf_
 //   k_fwd_proj    z = V[cand] W_i^T + xi Lt + Pf[i0] + b, relu, dropout, m = <U[u], h>   (rows-per-wave, K = 2D)
 template <int D_>
 __global__ __launch_bounds__(256) void k_feat_proj(const float* __restrict__ WT, const float* __restrict__ feat, int64_t item_num,
-                                                   int F, float* __restrict__ Pf) {
+                                                   int F, float* __restrict__ Pf, int Dr) {
   constexpr int D = D_;
   constexpr int DP = D <= 32 ? 32 : (D + 63) / 64 * 64;
   constexpr int NT = DP / 32;
@@ -1248,7 +1570,7 @@ __global__ __launch_bounds__(256) void k_feat_proj(const float* __restrict__ WT,
         const int f = min(k + 2 * o + h, F - 1);
         a[o] = frow[f];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b[o][nt] = WT[(int64_t)(D + f) * DP + nt * 32 + c31];
+        for (int nt = 0; nt < NT; ++nt) b[o][nt] = WT[(int64_t)(Dr + f) * DP + nt * 32 + c31];
       }
 #pragma unroll
       for (int o = 0; o < 4; ++o) {
@@ -1263,7 +1585,7 @@ __global__ __launch_bounds__(256) void k_feat_proj(const float* __restrict__ WT,
       for (int r = 0; r < 16; ++r) {
         const int64_t row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const int d = nt * 32 + c31;
-        if (row < item_num && d < D) Pf[row * D + d] = acc[nt][r];
+        if (row < item_num && d < Dr) Pf[row * Dr + d] = acc[nt][r];
       }
   }
 }
@@ -1308,8 +1630,8 @@ __global__ __launch_bounds__(512) void k_fwd_proj(const float* __restrict__ WT, 
                                                   const float* __restrict__ Pf, const float* __restrict__ bias,
                                                   const float* __restrict__ U, const float* __restrict__ V, const int64_t* X,
                                                   const int* __restrict__ cand, float* __restrict__ m, int64_t L, int S1, int A,
-                                                  rng_key xkey, rng_key dkey, uint32_t drop_thr, float kscale) {
-  extern __shared__ float wl[];                       // [2D][DW]: rows 0..D-1 = W_i^T, rows D..2D-1 = Lt
+                                                  rng_key xkey, rng_key dkey, uint32_t drop_thr, float kscale, int Dr) {
+  extern __shared__ float wl[];                       // [2D][DW]: rows 0..D-1 = W_i^T, rows D..2D-1 = Lt (zero beyond Dr)
   constexpr int D = D_;
   constexpr int DP = D <= 32 ? 32 : (D + 63) / 64 * 64;
   constexpr int ND = D <= 32 ? 1 : 2;
@@ -1322,7 +1644,7 @@ __global__ __launch_bounds__(512) void k_fwd_proj(const float* __restrict__ WT, 
   for (int idx = threadIdx.x; idx < 2 * D * DW; idx += blockDim.x) {
     const int k = idx / DW, c = idx % DW;
     const int d = dbase + c;
-    wl[idx] = k < D ? WT[(int64_t)k * DP + d] : (d < D ? Lt[(k - D) * D + d] : 0.f);
+    wl[idx] = k < D ? (k < Dr ? WT[(int64_t)k * DP + d] : 0.f) : ((d < Dr && k - D < Dr) ? Lt[(k - D) * Dr + d] : 0.f);
   }
   __syncthreads();
   const int64_t ntiles = (L + 31) / 32;
@@ -1330,7 +1652,7 @@ __global__ __launch_bounds__(512) void k_fwd_proj(const float* __restrict__ WT, 
   for (int64_t tile = (int64_t)blockIdx.x * NWV + wave; tile < ntiles; tile += (int64_t)gridDim.x * NWV) {
     const int64_t l = tile * 32 + c31;
     const int64_t lc = l < L ? l : L - 1;
-    const float* vrow = V + (int64_t)cand[(uint32_t)lc / (uint32_t)A] * D;
+    const float* vrow = V + (int64_t)cand[(uint32_t)lc / (uint32_t)A] * Dr;
     f32x16 acc[ND];
 #pragma unroll
     for (int nt = 0; nt < ND; ++nt)
@@ -1340,7 +1662,7 @@ __global__ __launch_bounds__(512) void k_fwd_proj(const float* __restrict__ WT, 
     for (int g = 0; g < D / 8; ++g) {                 // 4 k-steps: k = 8g + 2o + h
       float av[4], xi[4];
 #pragma unroll
-      for (int o = 0; o < 4; ++o) av[o] = vrow[8 * g + 2 * o + h];
+      for (int o = 0; o < 4; ++o) av[o] = vrow[min(8 * g + 2 * o + h, Dr - 1)];
       noise4((uint32_t)l, (uint32_t)(2 * g + h), xkey, one, xi);
 #pragma unroll
       for (int o = 0; o < 4; ++o) {
@@ -1361,13 +1683,13 @@ __global__ __launch_bounds__(512) void k_fwd_proj(const float* __restrict__ WT, 
       for (int w = 0; w < 4; ++w) {
         const int64_t lr = base + w + 8 * g4 + 4 * h;
         const int64_t n = (int64_t)((uint32_t)(lr < L ? lr : L - 1) / rows_per_n);
-        urow[w] = X[2 * n] * D;
-        prow[w] = X[2 * n + 1] * D;
+        urow[w] = X[2 * n] * Dr;
+        prow[w] = X[2 * n + 1] * Dr;
       }
 #pragma unroll
       for (int nt = 0; nt < ND; ++nt) {
         const int d = dbase + nt * 32 + c31;
-        const bool dv = d < D;
+        const bool dv = d < Dr;
         const int dc = dv ? d : 0;
         const float bd = bias[dc];
         u32x4 r4{0, 0, 0, 0};
@@ -1401,6 +1723,7 @@ __global__ __launch_bounds__(512) void k_fwd_proj(const float* __restrict__ WT, 
 extern "C" int dccf_eval_prepare(dccf_ctx* ctx, const dccf_model_t* M, float* Pf, float* Lt, void* stream) {
   ARG_CHECK(ctx && Pf && Lt, "NULL argument");
   if (int e = check_model(M)) return e;
+  ARG_CHECK(M->n_extra == 0, "projected evaluation noise covers --n_layers 1 (use --eval_noise full)");
   hipStream_t st = (hipStream_t)stream;
   const int D = M->D, F = M->F;
   const Lay y = make_layout(0, D, F, M->S, M->A);
@@ -1419,7 +1742,7 @@ extern "C" int dccf_eval_prepare(dccf_ctx* ctx, const dccf_model_t* M, float* Pf
                        (float*)nullptr, (int64_t)0, (float*)nullptr, sr, mark, (uint8_t*)nullptr);
   }
   const int grid = (int)min((int64_t)2048, ((M->item_num + 31) / 32 + 3) / 4);
-#define LAUNCH_FP(D_) hipLaunchKernelGGL(k_feat_proj<D_>, dim3(grid), dim3(256), 0, st, WT, M->feat, M->item_num, F, Pf)
+#define LAUNCH_FP(D_) hipLaunchKernelGGL(k_feat_proj<D_>, dim3(grid), dim3(256), 0, st, WT, M->feat, M->item_num, F, Pf, D)
   BY_D(D, LAUNCH_FP)
 #undef LAUNCH_FP
   const size_t smem = (size_t)D * (D + 1) * sizeof(double);
@@ -1438,6 +1761,7 @@ extern "C" int dccf_predict_projected(dccf_ctx* ctx, const dccf_model_t* M, cons
   ARG_CHECK(ctx && rnd && Pf && Lt, "NULL argument");
   if (int e = check_model(M)) return e;
   ARG_CHECK(rnd->mode == 1 && rnd->k_dev == nullptr, "projected predict draws everything on the device (rnd.mode = 1)");
+  ARG_CHECK(M->n_extra == 0, "projected evaluation noise covers --n_layers 1 (use --eval_noise full)");
   ARG_CHECK(N >= 0 && N * (int64_t)(M->S + 1) * M->A < 4294967296LL, "N*(S+1)*A must be < 2^32");
   ARG_CHECK(N == 0 || (X && prediction), "NULL X / prediction");
   ARG_CHECK(dropout >= 0.f && dropout < 1.f, "dropout must be in [0,1)");
@@ -1466,7 +1790,7 @@ extern "C" int dccf_predict_projected(dccf_ctx* ctx, const dccf_model_t* M, cons
   const uint32_t thr = dropout > 0.f ? drop_threshold(dropout) : 0u;
   const int64_t ntiles = (y.L + 31) / 32;
   const dim3 grid((unsigned)min((int64_t)1024, (ntiles + 7) / 8), y.GY);
-  const size_t smem = (size_t)2 * D * (y.ND * 32) * 4;
+  const size_t smem = (size_t)2 * y.DT * (y.ND * 32) * 4;
 #define LAUNCH_PJ(D_)                                                                                               \
   {                                                                                                                  \
     static bool once = false;                                                                                        \
@@ -1475,7 +1799,7 @@ extern "C" int dccf_predict_projected(dccf_ctx* ctx, const dccf_model_t* M, cons
       once = true;                                                                                                   \
     }                                                                                                                \
     hipLaunchKernelGGL(k_fwd_proj<D_>, grid, dim3(512), smem, st, WT, Lt, Pf, M->b, M->U, M->V, X, cand, m, y.L, S1, A, \
-                       make_key(rnd->seed, STREAM_XI, rnd->step), make_key(rnd->seed, STREAM_DROP, rnd->step), thr, kscale); \
+                       make_key(rnd->seed, STREAM_XI, rnd->step), make_key(rnd->seed, STREAM_DROP, rnd->step), thr, kscale, D); \
   }
   BY_D(D, LAUNCH_PJ)
 #undef LAUNCH_PJ
@@ -1551,11 +1875,11 @@ __global__ void k_dbg_noise(int64_t L, int F, rng_key key, float nscale, float* 
     }
   }
 }
-__global__ void k_dbg_keep(int64_t L, int D, rng_key key, uint32_t thr, uint8_t* out) {
+__global__ void k_dbg_keep(int64_t L, int D, rng_key key, uint32_t thr, uint8_t* out, int layer) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < L * D; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t l = i / D;
     const int d = (int)(i % D);
-    const u32x4 r = philox4x32_10((uint32_t)(l >> 2), (uint32_t)d, key.s0, key.s1, key.k0, key.k1);
+    const u32x4 r = philox4x32_10((uint32_t)(l >> 2), (uint32_t)d | ((uint32_t)layer << 16), key.s0, key.s1, key.k0, key.k1);
     out[i] = (thr == 0 || pick4(r, (int)(l & 3)) >= thr) ? 1 : 0;
   }
 }
@@ -1577,12 +1901,16 @@ extern "C" int dccf_debug_noise(int64_t L, int32_t F, float std, uint64_t seed, 
   HIP_TRY(hipGetLastError());
   return 0;
 }
-extern "C" int dccf_debug_keep(int64_t L, int32_t D, float dropout, uint64_t seed, uint64_t step, uint8_t* out,
-                               void* stream) {
-  ARG_CHECK(out && L >= 0 && D > 0 && dropout >= 0.f && dropout < 1.f, "bad arguments");
+extern "C" int dccf_debug_keep_layer(int64_t L, int32_t D, float dropout, uint64_t seed, uint64_t step, int32_t layer,
+                                     uint8_t* out, void* stream) {
+  ARG_CHECK(out && L >= 0 && D > 0 && dropout >= 0.f && dropout < 1.f && layer >= 0 && layer <= DCCF_MAX_EXTRA, "bad arguments");
   if (L == 0) return 0;
   hipLaunchKernelGGL(k_dbg_keep, dim3(1024), dim3(256), 0, (hipStream_t)stream, L, D, make_key(seed, STREAM_DROP, step),
-                     dropout > 0.f ? drop_threshold(dropout) : 0u, out);
+                     dropout > 0.f ? drop_threshold(dropout) : 0u, out, layer);
   HIP_TRY(hipGetLastError());
   return 0;
+}
+extern "C" int dccf_debug_keep(int64_t L, int32_t D, float dropout, uint64_t seed, uint64_t step, uint8_t* out,
+                               void* stream) {
+  return dccf_debug_keep_layer(L, D, dropout, seed, step, 0, out, stream);
 }

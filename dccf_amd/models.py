@@ -337,9 +337,9 @@ class DCCF(DMF):
         ``ips_factors`` (dict P,Q,bu,bi,prop,b0,M) replaces the dense exposure matrix by on-the-fly IPSBiasedMF scores."""
         self.path, self.dataset, self.sentence_model = path, dataset, sentence_model
         self.sample_num, self.attribute_num, self.std = sample_num, attribute_num, std
-        self.n_layers = n_layers
-        if n_layers != 1:
-            raise NotImplementedError('the HIP path implements the default --n_layers 1 (src/models/DMF.py:14)')
+        self.n_layers = int(n_layers)
+        if not 1 <= self.n_layers <= 8:
+            raise ValueError('--n_layers must be in [1, 8] (src/models/DMF.py:14; the HIP path holds up to 7 extra D x D layers)')
         self._feat_in, self._expo_in, self.ips_factors = feature_embedding, expo_prob, ips_factors
         RecModel.__init__(self, label_min=label_min, label_max=label_max, feature_num=feature_num, user_num=user_num,
                           item_num=item_num, u_vector_size=u_vector_size, i_vector_size=i_vector_size,
@@ -367,19 +367,29 @@ class DCCF(DMF):
         self._declare('iid_embeddings.weight', (self.item_num, D), 'embedding')
         self._declare('mlp.0.weight', (D, D + F), 'linear_w')
         self._declare('mlp.0.bias', (D,), 'linear_b')
+        for k in range(1, self.n_layers):        # src/models/DCCF.py:61-62: n_layers - 1 more Linear(D, D)
+            self._declare('mlp.%d.weight' % k, (D, D), 'linear_w')
+            self._declare('mlp.%d.bias' % k, (D,), 'linear_b')
+
+    def _extra(self, views):
+        return [(views['mlp.%d.weight' % k], views['mlp.%d.bias' % k]) for k in range(1, self.n_layers)]
 
     def _allocate(self):
         BaseModel._allocate(self)
         p = self.params
-        self._modules = [_ParamModule('embedding', p['uid_embeddings.weight']), _ParamModule('embedding', p['iid_embeddings.weight']),
-                         _ParamModule('linear', p['mlp.0.weight'], p['mlp.0.bias'])]
+        self._modules = [_ParamModule('embedding', p['uid_embeddings.weight']), _ParamModule('embedding', p['iid_embeddings.weight'])] + \
+                        [_ParamModule('linear', p['mlp.%d.weight' % k], p['mlp.%d.bias' % k]) for k in range(self.n_layers)]
         # one "touched" byte per embedding row, set by the backward, consumed by the row-aware dense optimizer step
         # (padded to whole 32-bit words: the overlapped step marks them with word atomics)
         self.touchedU = torch.zeros((self.user_num + 3) // 4 * 4, dtype=torch.uint8, device=self.device)[:self.user_num]
         self.touchedV = torch.zeros((self.item_num + 3) // 4 * 4, dtype=torch.uint8, device=self.device)[:self.item_num]
         D = self.ui_vector_size
-        self.row_segments = [(self.offsets['uid_embeddings.weight'], self.user_num, D, self.touchedU),
-                             (self.offsets['iid_embeddings.weight'], self.item_num, D, self.touchedV)]
+        if D in (16, 32, 64, 128):
+            self.row_segments = [(self.offsets['uid_embeddings.weight'], self.user_num, D, self.touchedU),
+                                 (self.offsets['iid_embeddings.weight'], self.item_num, D, self.touchedV)]
+        else:        # any other width (src/models/RecModel.py:17-27): the row-aware optimizer wants power-of-two rows; the
+            self.row_segments = []     # plain dense step (gradient read and re-zeroed everywhere) takes over
+            self.touchedU = self.touchedV = None
 
     def _struct(self):
         """The C view of the model; parameter storage never moves, so it is built once."""
@@ -387,7 +397,7 @@ class DCCF(DMF):
             p = self.params
             self._ms = _lib.model_struct(p['uid_embeddings.weight'], p['iid_embeddings.weight'], p['mlp.0.weight'],
                                          p['mlp.0.bias'], self.feature_embedding, self.expo_prob, self.sample_num,
-                                         self.attribute_num, self.std, ips=self.ips_factors)
+                                         self.attribute_num, self.std, ips=self.ips_factors, extra=self._extra(p))
             self._rs = _lib.rand_struct(seed=self.random_seed, step=0)
             self._loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         return self._ms
@@ -428,7 +438,8 @@ class DCCF(DMF):
         pred, loss = _lib.dccf_train_fwdbwd(self.ctx, ms, self._rand(feed_dict), feed_dict['X'].contiguous(),
                                             feed_dict['Y'], feed_dict['rank'], feed_dict['dropout'],
                                             g['uid_embeddings.weight'], g['iid_embeddings.weight'], g['mlp.0.weight'],
-                                            g['mlp.0.bias'], loss=self._loss, touchedU=self.touchedU, touchedV=self.touchedV)
+                                            g['mlp.0.bias'], loss=self._loss, touchedU=self.touchedU, touchedV=self.touchedV,
+                                            gextra=self._extra(g))
         return {'prediction': pred, 'check': [('prediction', pred)], 'loss': loss[0]}
 
     def train_step(self, feed_dict, overlap=0, X_next=None):
@@ -452,7 +463,7 @@ class DCCF(DMF):
                                           feed_dict['Y'], feed_dict['rank'], feed_dict['dropout'],
                                           g['uid_embeddings.weight'], g['iid_embeddings.weight'], g['mlp.0.weight'],
                                           g['mlp.0.bias'], self._opt_struct, o.t, loss=self._loss, touchedU=self.touchedU,
-                                          touchedV=self.touchedV, X_next=X_next, step_next=self._call + 1)
+                                          touchedV=self.touchedV, X_next=X_next, step_next=self._call + 1, gextra=self._extra(g))
         return {'prediction': pred, 'check': [('prediction', pred)], 'loss': loss[0]}
 
 
@@ -484,7 +495,7 @@ class StepGraph(object):
         m, o, g = self.model, self.opt, self.model.grads
         _lib.dccf_train_fwdbwd(m.ctx, self.ms, rs, X, Y, 1, self.dropout, g['uid_embeddings.weight'], g['iid_embeddings.weight'],
                                g['mlp.0.weight'], g['mlp.0.bias'], pred=pred, loss=m._loss, touchedU=m.touchedU,
-                               touchedV=m.touchedV)
+                               touchedV=m.touchedV, gextra=m._extra(g))
         _lib.dense_opt_step_rows(o.name, m.flat_p, m.flat_g, o.s1, o.s2, o.lr, o.l2, o.l2, o.clip, self.t0, m.row_segments,
                                  k_dev=self.k)
         _lib.advance(self.k)

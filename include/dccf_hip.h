@@ -43,8 +43,8 @@ int dccf_profile_read(dccf_ctx* ctx, double* ms, int64_t* counts);
 /* ---- DCCF model view: replaces the attributes set up by DCCF._init_weights (src/models/DCCF.py:47-64) ----- */
 typedef struct {
   int64_t user_num, item_num;
-  int32_t D;            /* --u_vector_size == --i_vector_size (src/models/RecModel.py:17-27); 16, 32, 64 or 128 */
-  int32_t F;            /* feature width, taken from the .npy (src/models/DCCF.py:59); <= 896                  */
+  int32_t D;            /* --u_vector_size == --i_vector_size (src/models/RecModel.py:17-27); any 1 <= D <= 128   */
+  int32_t F;            /* feature width, taken from the .npy (src/models/DCCF.py:59); any F >= 1               */
   int32_t S;            /* --sample-num   (src/models/DCCF.py:19)                                              */
   int32_t A;            /* --attribute-num (src/models/DCCF.py:20)                                             */
   float   std;          /* --std          (src/models/DCCF.py:21)                                              */
@@ -63,8 +63,13 @@ typedef struct {
   const float* ipsBi;   /* [item_num]       */
   const float* ipsProp; /* [item_num]       */
   float   ipsB0, ipsM;
-  int32_t ipsD, reserved2;
+  int32_t ipsD;
+  int32_t n_extra;      /* --n_layers - 1 (src/models/DMF.py:14): D -> D layers after mlp.0 (src/models/DCCF.py:61-62,   */
+                        /* 91-94), each Linear + relu + dropout; 0 <= n_extra <= DCCF_MAX_EXTRA                          */
+  const float* Wl[7];   /* mlp.k.weight [D, D], k = 1 .. n_extra  (Wl[k-1])                                             */
+  const float* bl[7];   /* mlp.k.bias   [D]                                                                             */
 } dccf_model_t;
+#define DCCF_MAX_EXTRA 7
 
 /* ---- the random draws of DCCF.predict (src/models/DCCF.py:72,87,94) ---------------------------------------- */
 typedef struct {
@@ -73,7 +78,7 @@ typedef struct {
   int32_t reserved;
   const int64_t* sample_item;  /* [N, S]      candidates as torch.randint would return them                      */
   const float*   noise;        /* [N*(S+1)*A, F]  N(0, std^2) draws (already scaled by std)                       */
-  const uint8_t* keep;         /* [N*(S+1)*A, D]  dropout keep mask (1 = kept) or NULL = keep all                 */
+  const uint8_t* keep;         /* [1 + n_extra][N*(S+1)*A, D]  dropout keep masks, layer-major (1 = kept) or NULL = keep all */
   uint64_t seed;               /* fused mode: stream key                                                        */
   uint64_t step;               /* fused mode: call counter (one value per forward)                              */
   /* Optional device-side step counter, so that one captured hipGraph can be replayed for every step of a run: with
@@ -90,6 +95,8 @@ typedef struct {             /* dense-shaped gradients of the LOSS term, accumul
   float* gb;                 /* [D]             */
   uint8_t* touchedU;         /* optional [user_num]: set to 1 for every row of gU this call adds to (NULL = not kept)   */
   uint8_t* touchedV;         /* optional [item_num]: same for gV; consumed by dccf_dense_opt_step_rows                  */
+  float* gWl[7];             /* [D, D] gradients of mlp.k.weight, k = 1 .. n_extra (unused entries NULL)                  */
+  float* gbl[7];             /* [D]                                                                                     */
 } dccf_grads_t;
 
 /* DCCF.predict (src/models/DCCF.py:66-107): X int64 [N,2] -> prediction fp32 [N].  `dropout` is feed_dict['dropout']. */
@@ -352,6 +359,9 @@ int shard_scatter_add(const int32_t* idx, int64_t n, const float* rows, int32_t 
 int dccf_debug_candidates(int64_t N, int32_t S, int64_t item_num, uint64_t seed, uint64_t step, int64_t* out, void* stream);
 int dccf_debug_noise(int64_t L, int32_t F, float std, uint64_t seed, uint64_t step, float* out, void* stream);
 int dccf_debug_keep(int64_t L, int32_t D, float dropout, uint64_t seed, uint64_t step, uint8_t* out, void* stream);
+/* the keep mask of mlp layer `layer` (0 = mlp.0; the extra layers of --n_layers > 1 draw with the layer index in the counter) */
+int dccf_debug_keep_layer(int64_t L, int32_t D, float dropout, uint64_t seed, uint64_t step, int32_t layer, uint8_t* out,
+                          void* stream);
 
 /* Copies one workspace array of the last call with these shapes to dst (device; NULL = only fill info[4] =
  * {DP, FP, element count, element size}).  which: 0 cand(int32) 1 WT 3 h 4 m 5 dmns.  Tests only. */

@@ -36,35 +36,59 @@ def dropout_scale(p):
     return F32(1.0) / F32(1.0 - p) if p > 0.0 else F32(1.0)
 
 
+def n_mlp_layers(P):
+    """Number of mlp layers in a parameter dict (mlp.0, mlp.1, ...; src/models/DCCF.py:59-62)."""
+    k = 0
+    while 'mlp.%d.weight' % k in P:
+        k += 1
+    return k
+
+
 def dccf_forward(P, feat, expo, X, sample_item, noise, keep, p, A):
     """models/DCCF.py:66-107 with the random draws injected.
 
     P: dict with 'uid_embeddings.weight' [U,D], 'iid_embeddings.weight' [I,D], 'mlp.0.weight' [D,D+F], 'mlp.0.bias' [D]
-    noise: [L,F] (already multiplied by std, as captured); keep: [L,D] 0/1 or None; p: dropout probability.
-    Returns dict of prediction [N] and the intermediates the backward needs.
+    and, for --n_layers > 1, 'mlp.k.weight' [D,D] / 'mlp.k.bias' [D] (src/models/DCCF.py:61-62).
+    noise: [L,F] (already multiplied by std, as captured); keep: [L,D] 0/1 (one layer), [n_layers,L,D] or None;
+    p: dropout probability.  Returns dict of prediction [N] and the intermediates the backward needs.
     """
     Ue, Ve = P['uid_embeddings.weight'], P['iid_embeddings.weight']
     W, b = P['mlp.0.weight'], P['mlp.0.bias']
+    NL = n_mlp_layers(P)
     uid, iid, fid, cand = expand_indices(X, sample_item, A)
     N, S1 = cand.shape
     ue = Ue[uid]
     ie = Ve[iid]
     fe = feat[fid] + noise.astype(F32)
     x = np.concatenate([ie, fe], axis=1).astype(F32)
+    if keep is not None:
+        keep = np.asarray(keep)
+        if keep.ndim == 2:
+            keep = keep[None]
+
+    def act(z, layer):       # relu + dropout (models/DCCF.py:92-94)
+        r = np.maximum(z, F32(0))
+        if keep is None or p == 0.0:
+            km = np.ones_like(z)
+        else:
+            km = keep[layer].astype(F32) * dropout_scale(p)
+        return (r * km).astype(F32), km
+
     z = (x @ W.T + b).astype(F32)
-    r = np.maximum(z, F32(0))
-    if keep is None or p == 0.0:
-        km = np.ones_like(z)
-    else:
-        km = keep.astype(F32) * dropout_scale(p)
-    h = (r * km).astype(F32)
+    h, km = act(z, 0)
+    layers = [dict(inp=x, z=z, km=km, h=h)]
+    for k in range(1, NL):
+        zk = (h @ P['mlp.%d.weight' % k].T + P['mlp.%d.bias' % k]).astype(F32)
+        hk, kmk = act(zk, k)
+        layers.append(dict(inp=h, z=zk, km=kmk, h=hk))
+        h = hk
     m = (ue * h).sum(axis=1, dtype=F32).reshape(N, S1, A)
     e = expo[uid, iid].reshape(N, S1, A).astype(F32)
     e = e - e.max(axis=1, keepdims=True)
     ee = np.exp(e, dtype=F32)
     w = (ee / ee.sum(axis=1, keepdims=True, dtype=F32)).astype(F32)
     pred = (w * m).sum(axis=1, dtype=F32).mean(axis=1, dtype=F32).astype(F32)
-    return dict(prediction=pred, uid=uid, iid=iid, fid=fid, cand=cand, ue=ue, x=x, z=z, km=km, h=h, m=m, w=w)
+    return dict(prediction=pred, uid=uid, iid=iid, fid=fid, cand=cand, ue=ue, x=x, z=z, km=km, h=h, m=m, w=w, layers=layers)
 
 
 def sigmoid(x):
@@ -96,10 +120,18 @@ def dccf_backward(P, fw, dpred, A):
     W = P['mlp.0.weight']
     D = Ue.shape[1]
     N, S1, _ = fw['m'].shape
+    layers = fw['layers']
     dm = (dpred[:, None, None] * fw['w'] / F32(A)).astype(F32).reshape(-1)            # [L]
-    due = (dm[:, None] * fw['h']).astype(F32)
+    due = (dm[:, None] * layers[-1]['h']).astype(F32)
     dh = (dm[:, None] * fw['ue']).astype(F32)
-    dz = (dh * fw['km'] * (fw['z'] > 0)).astype(F32)
+    out = {}
+    for k in range(len(layers) - 1, 0, -1):           # the extra D -> D layers (models/DCCF.py:61-62,91-94), last to first
+        ly = layers[k]
+        dzk = (dh * ly['km'] * (ly['z'] > 0)).astype(F32)
+        out['mlp.%d.weight' % k] = (dzk.T @ ly['inp']).astype(F32)
+        out['mlp.%d.bias' % k] = dzk.sum(axis=0, dtype=F32)
+        dh = (dzk @ P['mlp.%d.weight' % k]).astype(F32)
+    dz = (dh * layers[0]['km'] * (layers[0]['z'] > 0)).astype(F32)
     gW = (dz.T @ fw['x']).astype(F32)
     gb = dz.sum(axis=0, dtype=F32)
     dx = (dz @ W).astype(F32)
@@ -107,7 +139,8 @@ def dccf_backward(P, fw, dpred, A):
     gV = np.zeros_like(Ve)
     np.add.at(gU, fw['uid'], due)
     np.add.at(gV, fw['iid'], dx[:, :D])
-    return {'uid_embeddings.weight': gU, 'iid_embeddings.weight': gV, 'mlp.0.weight': gW, 'mlp.0.bias': gb, 'dz': dz, 'dm': dm}
+    out.update({'uid_embeddings.weight': gU, 'iid_embeddings.weight': gV, 'mlp.0.weight': gW, 'mlp.0.bias': gb, 'dz': dz, 'dm': dm})
+    return out
 
 
 # ----------------------------------------------------------------------------------------------

@@ -93,14 +93,15 @@ def drop_threshold(p):
     return int(min(max(p, 0.0) * 4294967296.0, 4294967295.0))
 
 
-def dropout_keep(seed, step, L, D, p):
-    """Device restatement of models/DCCF.py:94 (Bernoulli keep mask).  -> uint8 [L, D] (1 = kept)"""
+def dropout_keep(seed, step, L, D, p, layer=0):
+    """Device restatement of models/DCCF.py:94 (Bernoulli keep mask) of mlp layer `layer` (the layer index sits in bits
+    16.. of the column counter: mlp.0 draws as it always did).  -> uint8 [L, D] (1 = kept)"""
     if p <= 0.0:
         return np.ones((L, D), dtype=np.uint8)
     k0, k1 = _key(seed, STREAM_DROP)
     G = (L + 3) // 4
     g = np.arange(G)[:, None]
-    d = np.arange(D)[None, :]
+    d = np.arange(D)[None, :] | (int(layer) << 16)
     xs = philox4x32(g, d, step & 0xFFFFFFFF, (step >> 32) & 0xFFFFFFFF, k0, k1)      # 4 x [G, D]: word w = row 4g+w
     x = np.stack(xs, axis=1).reshape(G * 4, D)[:L]
     return (x >= np.uint32(drop_threshold(p))).astype(np.uint8)

@@ -162,10 +162,10 @@ def fit_like_reference(model, runner, batch):
 
 
 # ----------------------------------------------------------------------------- G1: DCCF
-def gen_dccf(outdir):
+def gen_dccf(outdir, cases=None):
     from models.DCCF import DCCF
     from runners.BaseRunner import BaseRunner
-    cases = [
+    cases = cases or [
         # name, U, I, D, F, pairs, S, A, std, dropout, optimizer, lr, l2, steps, rank, init_scale
         ('dccf_d16_f32_adam', 50, 40, 16, 32, 4, 10, 2, 0.1, 0.2, 'Adam', 0.001, 1e-4, 3, 1, 1.0),
         ('dccf_d64_f768_adam', 50, 40, 64, 768, 4, 10, 2, 0.1, 0.2, 'Adam', 0.001, 1e-4, 3, 1, 1.0),
@@ -174,7 +174,9 @@ def gen_dccf(outdir):
         ('dccf_d128_f768_adam', 20, 25, 128, 768, 2, 10, 2, 0.1, 0.2, 'Adam', 0.001, 1e-4, 2, 1, 10.0),
         ('dccf_d64_f768_mse', 50, 40, 64, 768, 4, 10, 2, 0.1, 0.2, 'Adam', 0.001, 1e-4, 2, 0, 20.0),
     ]
-    for (name, U, I, D, F, pairs, S, A, std, p, opt, lr, l2, steps, rank, scale) in cases:
+    for case in cases:
+        (name, U, I, D, F, pairs, S, A, std, p, opt, lr, l2, steps, rank, scale) = case[:16]
+        n_layers = case[16] if len(case) > 16 else 1          # --n_layers (src/models/DMF.py:14)
         tmp = tempfile.mkdtemp()
         try:
             rng = np.random.RandomState(zlib.crc32(name.encode()) % (2 ** 31))
@@ -184,7 +186,7 @@ def gen_dccf(outdir):
             np.save(os.path.join(tmp, 'toy.ips_expo_prob.npy'), expo)
             model = DCCF(path=tmp, dataset='toy', sentence_model='sm', sample_num=S, attribute_num=A, std=std,
                          label_min=0, label_max=1, feature_num=0, user_num=U, item_num=I, u_vector_size=D,
-                         i_vector_size=D, n_layers=1, random_seed=2019, model_path=os.path.join(tmp, 'm.pt'))
+                         i_vector_size=D, n_layers=n_layers, random_seed=2019, model_path=os.path.join(tmp, 'm.pt'))
             model.apply(model.init_paras)
             if scale != 1.0:   # larger weights: exercises relu / softmax / sigmoid away from the linear regime
                 with torch.no_grad():
@@ -195,6 +197,8 @@ def gen_dccf(outdir):
             rec = {'U': U, 'I': I, 'D': D, 'F': F, 'pairs': pairs, 'S': S, 'A': A, 'std': std, 'dropout': p,
                    'lr': lr, 'l2': l2, 'steps': steps, 'rank': rank, 'optimizer': opt,
                    'feat': feat, 'expo': expo}
+            if n_layers != 1:
+                rec['n_layers'] = n_layers
             for k, v in params_of(model).items():
                 rec['init/' + k] = v
             for s in range(steps):
@@ -208,7 +212,11 @@ def gen_dccf(outdir):
                 rec[pre + 'X'], rec[pre + 'Y'] = X, Y
                 rec[pre + 'sample_item'] = t2n(CAP.sample_item[0])
                 rec[pre + 'noise'] = t2n(CAP.noise[0])
-                rec[pre + 'mask'] = t2n(CAP.masks[0]).astype(np.uint8)
+                if n_layers == 1:
+                    rec[pre + 'mask'] = t2n(CAP.masks[0]).astype(np.uint8)
+                else:          # one keep mask per mlp layer (src/models/DCCF.py:91-94), layer-major
+                    assert len(CAP.masks) == n_layers
+                    rec[pre + 'mask'] = np.stack([t2n(mk).astype(np.uint8) for mk in CAP.masks])
                 rec[pre + 'prediction'] = t2n(out['prediction'])
                 rec[pre + 'loss'] = t2n(out['loss'])
                 rec[pre + 'l2'] = l2v
@@ -232,6 +240,21 @@ def gen_dccf(outdir):
             print('wrote', name, 'loss', [float(rec['s%d/loss' % s]) for s in range(steps)])
         finally:
             shutil.rmtree(tmp)
+
+
+def gen_dccf_ext(outdir):
+    """Round-2 cases, generated AFTER everything else with their own torch seed so that the round-1 fixtures regenerate bit
+    for bit: --n_layers > 1 (src/models/DMF.py:14, src/models/DCCF.py:61-62,91-94), embedding widths that are not a kernel
+    tile (src/models/RecModel.py:17-27 accepts any) and feature files wider than 896 (src/models/DCCF.py:59)."""
+    torch.manual_seed(2020)
+    gen_dccf(outdir, cases=[
+        # name, U, I, D, F, pairs, S, A, std, dropout, optimizer, lr, l2, steps, rank, init_scale, n_layers
+        ('dccf_d64_f768_l2_adam', 50, 40, 64, 768, 4, 10, 2, 0.1, 0.2, 'Adam', 0.001, 1e-4, 3, 1, 8.0, 2),
+        ('dccf_d24_f100_l3_adagrad', 40, 30, 24, 100, 5, 6, 2, 0.2, 0.3, 'Adagrad', 0.01, 1e-3, 2, 1, 25.0, 3),
+        ('dccf_d48_f1024_adam', 30, 35, 48, 1024, 3, 10, 2, 0.1, 0.2, 'Adam', 0.001, 1e-4, 2, 1, 10.0, 1),
+        ('dccf_d100_f800_gd', 20, 25, 100, 800, 2, 10, 2, 0.1, 0.2, 'GD', 0.01, 1e-4, 2, 0, 10.0, 1),
+        ('dccf_d128_f32_l2_mse', 20, 25, 128, 32, 3, 4, 3, 0.1, 0.2, 'Adam', 0.001, 1e-4, 2, 0, 20.0, 2),
+    ])
 
 
 # ----------------------------------------------------------------------------- G2: MF family
@@ -485,5 +508,7 @@ if __name__ == '__main__':
         gen_batches(HERE)
     if 'metrics' in which:
         gen_metrics(HERE)
+    if 'dccf_ext' in which:
+        gen_dccf_ext(HERE)
     if 'e2e' in which:
         gen_e2e(HERE)

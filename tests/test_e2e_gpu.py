@@ -107,3 +107,27 @@ def test_exposure_pipeline_ipsbiasedmf_then_dccf(tmp_path):
     r3 = run_cli(tmp, ['--model_name', 'DCCF', '--epoch', '1', '--load', '1', '--model_path', '../model/DCCF/x.pt',
                        '--eval_noise', 'projected'] + common)       # evaluation through dccf_predict_projected
     assert np.isfinite(r3.valid_results[-1][0]) and r3.valid_results[-1][0] > 0.5 * r2.valid_results[-1][0]
+
+
+def test_cli_n_layers_and_any_embedding_width(tmp_path):
+    """--n_layers 2 (src/models/DMF.py:14, src/models/DCCF.py:61-62,91-94) with a width that is not a kernel tile
+    (src/models/RecModel.py:17-27 only asks u_vector_size == i_vector_size) through the CLI: trains, evaluates, and the
+    checkpoint carries the reference's state_dict keys and shapes for the extra layer."""
+    from dccf_amd import synth
+    tmp = str(tmp_path)
+    synth.write_dataset(os.path.join(tmp, 'dataset'), 'toy', 300, 200, 6000, feat_dim=40, seed=3)
+    r = run_cli(tmp, ['--rank', '1', '--model_name', 'DCCF', '--dataset', 'toy', '--path', '../dataset/', '--metric', 'ndcg@5,recall@5',
+                      '--test_neg_n', '50', '--u_vector_size', '24', '--i_vector_size', '24', '--n_layers', '2', '--check_epoch', '0',
+                      '--optimizer', 'Adam', '--lr', '0.01', '--epoch', '4', '--model_path', '../model/DCCF/l2.pt'])
+    v = [x[0] for x in r.valid_results]
+    assert len(v) == 4 and all(np.isfinite(v)) and max(v) > 0.05
+    sd = torch.load(os.path.join(tmp, 'model', 'DCCF', 'l2.pt'), map_location='cpu')
+    assert list(sd.keys()) == ['uid_embeddings.weight', 'iid_embeddings.weight', 'mlp.0.weight', 'mlp.0.bias', 'mlp.1.weight',
+                               'mlp.1.bias']
+    assert tuple(sd['mlp.0.weight'].shape) == (24, 24 + 40) and tuple(sd['mlp.1.weight'].shape) == (24, 24)
+    assert tuple(sd['mlp.1.bias'].shape) == (24,) and float(sd['mlp.1.weight'].abs().max()) > 0.011      # it was trained
+    # the projected evaluation noise covers one mlp layer only: the library says so instead of computing something else
+    with pytest.raises(RuntimeError, match='n_layers 1'):
+        run_cli(tmp, ['--rank', '1', '--model_name', 'DCCF', '--dataset', 'toy', '--path', '../dataset/', '--metric', 'ndcg@5',
+                      '--test_neg_n', '50', '--u_vector_size', '24', '--i_vector_size', '24', '--n_layers', '2', '--epoch', '1',
+                      '--eval_noise', 'projected'])

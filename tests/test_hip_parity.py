@@ -12,8 +12,23 @@ from oracle import philox as PH
 pytestmark = pytest.mark.gpu
 
 DCCF_CASES = ['dccf_d16_f32_adam', 'dccf_d64_f768_adam', 'dccf_d64_f32_nodrop_gd', 'dccf_d32_f160_adagrad',
-              'dccf_d128_f768_adam', 'dccf_d64_f768_mse']
+              'dccf_d128_f768_adam', 'dccf_d64_f768_mse',
+              # round 2: --n_layers 2 / 3 (src/models/DCCF.py:61-62,91-94), widths that are not a kernel tile
+              # (src/models/RecModel.py:17-27), feature files wider than 896 (src/models/DCCF.py:59)
+              'dccf_d64_f768_l2_adam', 'dccf_d24_f100_l3_adagrad', 'dccf_d48_f1024_adam', 'dccf_d100_f800_gd',
+              'dccf_d128_f32_l2_mse']
 PKEYS = ['uid_embeddings.weight', 'iid_embeddings.weight', 'mlp.0.weight', 'mlp.0.bias']
+
+
+def pkeys(g):
+    """state_dict keys of a golden case in the reference's order: PKEYS + mlp.k.weight / mlp.k.bias for k >= 1."""
+    return [k[5:] for k in g if k.startswith('init/')]
+
+
+def extra_of(views, keys):
+    """[(mlp.k.weight, mlp.k.bias) for k >= 1] out of a dict of tensors."""
+    n = (len(keys) - 4) // 2
+    return [(views['mlp.%d.weight' % k], views['mlp.%d.bias' % k]) for k in range(1, n + 1)]
 
 # fp32 tolerances (relative to the largest magnitude of the compared tensor): summation order differs between
 # ATen / numpy / the MFMA k-order, and float atomics reorder the scatter sums.
@@ -83,28 +98,31 @@ class FlatParams(object):
 def test_dccf_injected_train_steps_match_reference(L, ctx, name):
     g = load_golden(name)
     A, S, p, rank = int(g['A']), int(g['S']), float(g['dropout']), int(g['rank'])
-    fp = FlatParams({k: g['init/' + k] for k in PKEYS})
+    keys = pkeys(g)
+    fp = FlatParams({k: g['init/' + k] for k in keys})
     feat, expo = T(g['feat']), T(g['expo'])
     kind = str(g['optimizer']).lower()
     for s in range(int(g['steps'])):
         pre = 's%d/' % s
         v = fp.views
-        m = L.model_struct(v[PKEYS[0]], v[PKEYS[1]], v[PKEYS[2]], v[PKEYS[3]], feat, expo, S, A, float(g['std']))
+        m = L.model_struct(v[PKEYS[0]], v[PKEYS[1]], v[PKEYS[2]], v[PKEYS[3]], feat, expo, S, A, float(g['std']),
+                           extra=extra_of(v, keys))
         X, Y = T(g[pre + 'X']), T(g[pre + 'Y'])
         r = L.rand_struct(sample_item=T(g[pre + 'sample_item']), noise=T(g[pre + 'noise']),
                           keep=T(g[pre + 'mask']) if p > 0 else None)
         # predict-only entry point on the same draws
         close(L.dccf_predict(ctx, m, r, X, p), g[pre + 'prediction'], FWD_RTOL, FWD_ATOL, name + ' predict')
         gv = fp.gviews
-        pred, loss = L.dccf_train_fwdbwd(ctx, m, r, X, Y, rank, p, gv[PKEYS[0]], gv[PKEYS[1]], gv[PKEYS[2]], gv[PKEYS[3]])
+        pred, loss = L.dccf_train_fwdbwd(ctx, m, r, X, Y, rank, p, gv[PKEYS[0]], gv[PKEYS[1]], gv[PKEYS[2]], gv[PKEYS[3]],
+                                         gextra=extra_of(gv, keys))
         close(pred, g[pre + 'prediction'], FWD_RTOL, FWD_ATOL, name + ' pred')
         close(loss, g[pre + 'loss'].reshape(1), FWD_RTOL, FWD_ATOL, name + ' loss')
-        for k in PKEYS:
+        for k in keys:
             close(gv[k], g[pre + 'gloss/' + k], GRAD_RTOL, GRAD_ATOL, name + ' gloss ' + k)
         close(L.sumsq(fp.p), g[pre + 'l2'].reshape(1), 1e-5, 0, name + ' l2')
         L.dense_opt_step(kind, fp.p, fp.g, fp.s1, fp.s2, float(g['lr']), float(g['l2']), float(g['l2']), 50.0, s + 1)
         assert float(fp.g.abs().max()) == 0.0     # fused zero_grad
-        for k in PKEYS:
+        for k in keys:
             close(fp.views[k], g[pre + 'after/' + k], PARAM_RTOL, PARAM_ATOL + STEP_FRAC * float(g['lr']), name + ' after ' + k)
 
 
@@ -112,8 +130,11 @@ def test_dccf_injected_train_steps_match_reference(L, ctx, name):
 def test_dccf_injected_eval_predict(L, ctx, name):
     g = load_golden(name)
     last = 's%d/after/' % (int(g['steps']) - 1)
-    P = [T(g[last + k]) for k in PKEYS]
-    m = L.model_struct(P[0], P[1], P[2], P[3], T(g['feat']), T(g['expo']), int(g['S']), int(g['A']), float(g['std']))
+    keys = pkeys(g)
+    Pd = {k: T(g[last + k]) for k in keys}
+    P = [Pd[k] for k in PKEYS]
+    m = L.model_struct(P[0], P[1], P[2], P[3], T(g['feat']), T(g['expo']), int(g['S']), int(g['A']), float(g['std']),
+                       extra=extra_of(Pd, keys))
     r = L.rand_struct(sample_item=T(g['eval/sample_item']), noise=T(g['eval/noise']))
     close(L.dccf_predict(ctx, m, r, T(g['eval/X']), 0.0), g['eval/prediction'], FWD_RTOL, FWD_ATOL, name + ' eval')
 
@@ -184,6 +205,60 @@ def test_fused_equals_injected_on_device_draws(L, ctx, D, F, S, A, p, rank):
     grads = O.dccf_backward(P, fw, dpred, A)
     for k, a in zip(PKEYS, outs[0][2]):
         close(a, grads[k], GRAD_RTOL, GRAD_ATOL, 'fused grad vs oracle ' + k)
+
+
+@pytest.mark.parametrize('D,F,S,A,p,rank,NL', [(64, 768, 10, 2, 0.2, 1, 2), (24, 100, 4, 2, 0.3, 1, 3), (128, 160, 3, 2, 0.2, 0, 2),
+                                               (16, 32, 10, 2, 0.5, 1, 4), (48, 1024, 3, 2, 0.2, 1, 1), (100, 1500, 2, 2, 0.1, 1, 2),
+                                               (7, 33, 5, 3, 0.2, 0, 1)])
+def test_fused_equals_injected_extra_layers_generic_shapes(L, ctx, D, F, S, A, p, rank, NL):
+    """--n_layers > 1 (src/models/DCCF.py:61-62,91-94), any embedding width (src/models/RecModel.py:17-27) and any feature
+    width (src/models/DCCF.py:59): fused draws == injected draws (the per-layer keep masks written out by
+    dccf_debug_keep_layer) == the oracle on those draws."""
+    rng = np.random.RandomState(1000 * NL + D + F)
+    U_, I_, pairs = 120, 90, 19
+    N = 2 * pairs
+    keys = list(PKEYS)
+    P = {'uid_embeddings.weight': (rng.randn(U_, D) * 0.3).astype(np.float32),
+         'iid_embeddings.weight': (rng.randn(I_, D) * 0.3).astype(np.float32),
+         'mlp.0.weight': (rng.randn(D, D + F) * 0.1).astype(np.float32),
+         'mlp.0.bias': (rng.randn(D) * 0.1).astype(np.float32)}
+    for k in range(1, NL):
+        P['mlp.%d.weight' % k] = (rng.randn(D, D) * (0.8 / np.sqrt(D))).astype(np.float32)
+        P['mlp.%d.bias' % k] = (rng.randn(D) * 0.1).astype(np.float32)
+        keys += ['mlp.%d.weight' % k, 'mlp.%d.bias' % k]
+    feat = (rng.randn(I_, F) * 0.5).astype(np.float32)
+    expo = rng.randn(U_, I_).astype(np.float32)
+    u = rng.randint(0, U_, pairs)
+    X = np.concatenate([np.stack([u, rng.randint(0, I_, pairs)], 1), np.stack([u, rng.randint(0, I_, pairs)], 1)]).astype(np.int64)
+    Y = rng.randint(0, 2, N).astype(np.float32)
+    seed, step, std = 77001, 9, 0.1
+    Ld = N * (S + 1) * A
+    tp = {k: T(v) for k, v in P.items()}
+    m = L.model_struct(tp[PKEYS[0]], tp[PKEYS[1]], tp[PKEYS[2]], tp[PKEYS[3]], T(feat), T(expo), S, A, std, extra=extra_of(tp, keys))
+    si = L.debug_candidates(N, S, I_, seed, step, dev())
+    nz = L.debug_noise(Ld, F, std, seed, step, dev())
+    kp = torch.stack([L.debug_keep(Ld, D, p, seed, step, dev(), layer=k) for k in range(NL)]).contiguous()
+    kpo = np.stack([PH.dropout_keep(seed, step, Ld, D, float(np.float32(p)), layer=k) for k in range(NL)])
+    assert np.array_equal(kp.cpu().numpy(), kpo)
+    assert NL == 1 or not np.array_equal(kpo[0], kpo[1])
+    outs = []
+    for r in (L.rand_struct(seed=seed, step=step), L.rand_struct(sample_item=si, noise=nz, keep=kp)):
+        gr = {k: torch.zeros_like(tp[k]) for k in keys}
+        pred, loss = L.dccf_train_fwdbwd(ctx, m, r, T(X), T(Y), rank, p, *[gr[k] for k in PKEYS], gextra=extra_of(gr, keys))
+        pe = L.dccf_predict(ctx, m, r, T(X), p)
+        torch.cuda.synchronize()
+        assert torch.equal(pe, pred)           # the predict-only entry runs the same forward
+        outs.append((pred.cpu().numpy(), loss.cpu().numpy(), {k: v.cpu().numpy() for k, v in gr.items()}))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    for k in keys:
+        close(outs[0][2][k], outs[1][2][k], 2e-6, 1e-8, 'fused vs injected grads ' + k)
+    fw = O.dccf_forward(P, feat, expo, X, si.cpu().numpy(), nz.cpu().numpy(), kpo, p, A)
+    close(outs[0][0], fw['prediction'], FWD_RTOL, FWD_ATOL, 'fused pred vs oracle')
+    loss, dpred = O.loss_and_dpred(fw['prediction'], Y, rank)
+    close(outs[0][1], np.asarray(loss).reshape(1), FWD_RTOL, FWD_ATOL, 'fused loss vs oracle')
+    grads = O.dccf_backward(P, fw, dpred, A)
+    for k in keys:
+        close(outs[0][2][k], grads[k], GRAD_RTOL, GRAD_ATOL, 'fused grad vs oracle ' + k)
 
 
 def test_dccf_on_the_fly_exposure_equals_dense(L, ctx):
@@ -389,11 +464,20 @@ def test_argument_errors_are_reported(L, ctx):
         L.dense_opt_step('adam', t.view(-1), t.view(-1), None, None, 0.1, 0, 0, 50, 1)
     with pytest.raises(RuntimeError):
         L.dense_opt_step('adam', torch.zeros(4), torch.zeros(4), torch.zeros(4), torch.zeros(4), 0.1, 0, 0, 50, 1)  # CPU tensors
-    W = torch.zeros(24, 24 + 8, device=dev())
-    m = L.model_struct(torch.zeros(5, 24, device=dev()), torch.zeros(5, 24, device=dev()), W, torch.zeros(24, device=dev()),
+    W = torch.zeros(130, 130 + 8, device=dev())      # wider than the largest column tile
+    m = L.model_struct(torch.zeros(5, 130, device=dev()), torch.zeros(5, 130, device=dev()), W, torch.zeros(130, device=dev()),
                        torch.zeros(5, 8, device=dev()), torch.zeros(5, 5, device=dev()), 10, 2, 0.1)
     with pytest.raises(RuntimeError, match='D must be'):
         L.dccf_predict(ctx, m, L.rand_struct(seed=1), torch.zeros(2, 2, dtype=torch.int64, device=dev()), 0.0)
+    # gradients of an extra mlp layer missing
+    Wx, bx = torch.zeros(16, 16, device=dev()), torch.zeros(16, device=dev())
+    m2 = L.model_struct(torch.zeros(5, 16, device=dev()), torch.zeros(5, 16, device=dev()), torch.zeros(16, 24, device=dev()),
+                        torch.zeros(16, device=dev()), torch.zeros(5, 8, device=dev()), torch.zeros(5, 5, device=dev()), 10, 2, 0.1,
+                        extra=[(Wx, bx)])
+    with pytest.raises(RuntimeError, match='extra mlp layer'):
+        L.dccf_train_fwdbwd(ctx, m2, L.rand_struct(seed=1), torch.zeros(2, 2, dtype=torch.int64, device=dev()),
+                            torch.zeros(2, device=dev()), 1, 0.0, torch.zeros(5, 16, device=dev()), torch.zeros(5, 16, device=dev()),
+                            torch.zeros(16, 24, device=dev()), torch.zeros(16, device=dev()))
     # empty batch is legal
     m = L.model_struct(torch.zeros(5, 16, device=dev()), torch.zeros(5, 16, device=dev()), torch.zeros(16, 24, device=dev()),
                        torch.zeros(16, device=dev()), torch.zeros(5, 8, device=dev()), torch.zeros(5, 5, device=dev()), 10, 2, 0.1)
@@ -650,9 +734,11 @@ def test_large_batch_forward_equals_small_batches(L, ctx):
     assert torch.equal(big_inj, torch.cat(parts))                     # same kernel, same per-row arithmetic: bit-identical
 
 
-@pytest.mark.parametrize('opt_name,B,l2,D', [('gd', 128, 0.05, 64), ('gd', 600, 0.05, 64), ('adam', 128, 1e-4, 64),
-                                             ('adagrad', 37, 1e-4, 64), ('gd', 64, 0.05, 128), ('gd', 50, 0.05, 16)])
-def test_overlapped_train_step_equals_split_step(L, opt_name, B, l2, D):
+@pytest.mark.parametrize('opt_name,B,l2,D,NL', [('gd', 128, 0.05, 64, 1), ('gd', 600, 0.05, 64, 1), ('adam', 128, 1e-4, 64, 1),
+                                                ('adagrad', 37, 1e-4, 64, 1), ('gd', 64, 0.05, 128, 1), ('gd', 50, 0.05, 16, 1),
+                                                # --n_layers > 1 and widths that are not a kernel tile go through the same entry
+                                                ('gd', 128, 0.05, 64, 2), ('gd', 40, 0.05, 48, 3), ('gd', 50, 0.05, 24, 1)])
+def test_overlapped_train_step_equals_split_step(L, opt_name, B, l2, D, NL):
     """dccf_train_step with the untouched-row optimizer pass on the side stream ('overlap'), hosted as extra workgroups of
     the backward launch ('hosted'), or with every step prepared by the one before ('prep') == forward/backward followed by the
     row-aware dense step over several steps (duplicate users/items inside a batch included).  Same arithmetic per
@@ -670,9 +756,10 @@ def test_overlapped_train_step_equals_split_step(L, opt_name, B, l2, D):
     gen = torch.Generator(device='cuda').manual_seed(9)
     full = torch.stack([torch.stack([torch.randint(0, U // 2 if k % 2 else 40, (2 * B,), generator=gen, device='cuda'),
                                      torch.randint(0, I, (2 * B,), generator=gen, device='cuda')], 1) for k in range(6)])
-    for mode in ('split', 'step', 'overlap', 'prep', 'hosted'):
+    tile = D in (16, 32, 64, 128)       # other widths have no row segments: the overlapped forms do not apply
+    for mode in ('split', 'step', 'overlap', 'prep', 'hosted') if tile else ('split', 'step', 'prep'):
         m = DCCF(path=None, dataset=None, sentence_model=None, sample_num=10, attribute_num=2, std=0.1, label_min=0, label_max=1,
-                 feature_num=0, user_num=U, item_num=I, u_vector_size=D, i_vector_size=D, n_layers=1, random_seed=11,
+                 feature_num=0, user_num=U, item_num=I, u_vector_size=D, i_vector_size=D, n_layers=NL, random_seed=11,
                  model_path='/tmp/x.pt', feature_embedding=feat, expo_prob=expo)
         torch.manual_seed(3)
         m.apply(m.init_paras)
@@ -695,8 +782,9 @@ def test_overlapped_train_step_equals_split_step(L, opt_name, B, l2, D):
             preds.append(out['prediction'].clone())
         torch.cuda.synchronize()
         assert m.ctx.prepared_steps() == (5 if mode == 'prep' else 0)
-        assert int(m.touchedU.sum()) == 0 and int(m.touchedV.sum()) == 0
+        assert not tile or (int(m.touchedU.sum()) == 0 and int(m.touchedV.sum()) == 0)
         assert float(m.flat_g.abs().max()) == 0.0
+        assert len(m.state_dict()) == 2 + 2 * NL
         states.append([m.flat_p.clone(), m.optimizer.s1, m.optimizer.s2, seen] + preds)
     for other in states[1:]:
         assert torch.equal(states[0][3], other[3])

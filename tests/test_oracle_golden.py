@@ -8,8 +8,15 @@ from conftest import load_golden
 from oracle import dccf_oracle as O
 
 DCCF_CASES = ['dccf_d16_f32_adam', 'dccf_d64_f768_adam', 'dccf_d64_f32_nodrop_gd', 'dccf_d32_f160_adagrad',
-              'dccf_d128_f768_adam', 'dccf_d64_f768_mse']
-PKEYS = ['uid_embeddings.weight', 'iid_embeddings.weight', 'mlp.0.weight', 'mlp.0.bias']
+              'dccf_d128_f768_adam', 'dccf_d64_f768_mse',
+              # round 2 (make_golden.py dccf_ext): --n_layers 2 / 3, widths that are not a kernel tile, F > 896
+              'dccf_d64_f768_l2_adam', 'dccf_d24_f100_l3_adagrad', 'dccf_d48_f1024_adam', 'dccf_d100_f800_gd',
+              'dccf_d128_f32_l2_mse']
+
+
+def pkeys(g):
+    """state_dict keys of the case, in the reference's order (mlp.k.* for k < n_layers after the embeddings)."""
+    return [k[5:] for k in g if k.startswith('init/')]
 
 # fp32 tolerances: the oracle sums in numpy/BLAS order, the reference in ATen order.
 FWD_RTOL, FWD_ATOL = 2e-5, 1e-6
@@ -45,6 +52,8 @@ def test_index_expansion_bit_exact(name):
 def test_dccf_train_steps_match_reference(name):
     g = load_golden(name)
     A, p, rank = int(g['A']), float(g['dropout']), int(g['rank'])
+    PKEYS = pkeys(g)
+    assert len(PKEYS) == 2 + 2 * int(g.get('n_layers', 1))
     P = {k: g['init/' + k].copy() for k in PKEYS}
     opt = O.DenseOptimizer(str(g['optimizer']), float(g['lr']), float(g['l2']))
     for s in range(int(g['steps'])):
@@ -72,7 +81,7 @@ def test_dccf_train_steps_match_reference(name):
 def test_dccf_eval_predict(name):
     g = load_golden(name)
     last = 's%d/after/' % (int(g['steps']) - 1)
-    P = {k: g[last + k] for k in PKEYS}
+    P = {k: g[last + k] for k in pkeys(g)}
     fw = O.dccf_forward(P, g['feat'], g['expo'], g['eval/X'], g['eval/sample_item'], g['eval/noise'], None, 0.0,
                         int(g['A']))
     close(fw['prediction'], g['eval/prediction'], FWD_RTOL, FWD_ATOL, name + ' eval')
