@@ -41,11 +41,13 @@ def parse():
     p.add_argument('--feat', type=int, default=768)
     p.add_argument('--expo', type=str, default='auto', help='dense | factors | auto (dense when it fits one GPU)')
     p.add_argument('--cpu_baseline', type=int, default=1)
-    p.add_argument('--cpu_steps', type=int, default=60)
+    p.add_argument('--cpu_steps', type=int, default=150, help='steps of the timed CPU-baseline sample (~15 s at the best thread count)')
     p.add_argument('--seed', type=int, default=2019)
     p.add_argument('--mp', type=str, default='auto', help='multi-GPU layout: replicated (full model per GPU, one all-gather '
-                                                          'per step) | sharded (rows mod G, 4 collectives) | auto (replicated '
-                                                          'while the redundant dense optimizer pass is cheap: <= 1e8 params)')
+                                                          'per step) | sharded (BASELINE north_star: rows mod G, all-to-all row '
+                                                          'exchange + all-reduce of [dW|db]) | auto (replicated while the redundant '
+                                                          'dense optimizer pass is cheap: <= 1e8 params).  The layout that ran is '
+                                                          'named in config.workload / config.layout')
     p.add_argument('--dp_overlap', type=int, default=1, help='replicated path: run the optimizer pass over the rows no rank '
                                                              'touches on a side stream while the gradient exchange is in flight')
     p.add_argument('--force_replicated', type=int, default=0, help='run the replicated data-parallel pipeline even at --gpus 1')
@@ -75,21 +77,38 @@ def synthetic_interactions(n, users, items, seed):
 
 def cpu_baseline(args, feat_cpu, seed):
     """The reference's op sequence on the host (oracle/torch_port.py), bounded: `cpu_steps` steps of the same batch
-    size on the full-size embedding tables; exposure rows only for the 2000 users the sample touches."""
+    size on the full-size embedding tables; exposure rows only for the 2000 users the sample touches.  The intra-op thread
+    count is swept first (10 steps each: small ops oversubscribe a 128-thread pool) and the best one is used and reported."""
     from oracle import torch_port as TP
     us = 2000
     g = torch.Generator().manual_seed(seed)
     expo_rows = torch.randn(us, args.items, generator=g)
     model = TP.DCCFPort(args.users, args.items, args.dim, feat_cpu, expo_rows, seed=seed)
-    batches = TP.synthetic_batches(us, args.items, args.batch_size, args.cpu_steps + 3, seed=seed)
+    n_sweep = 10
+    batches = TP.synthetic_batches(us, args.items, args.batch_size, args.cpu_steps + 3 + 6 * (n_sweep + 1), seed=seed)
+    ncpu = os.cpu_count() or 1
+    default_threads = torch.get_num_threads()
+    cands = sorted({t for t in (4, 8, 16, 32, 64, 128, default_threads) if 1 <= t <= max(ncpu, default_threads)})[-6:]
     TP.train_steps(model, batches[:3])
+    sweep, used = {}, 3
+    for t in cands:
+        torch.set_num_threads(t)
+        TP.train_steps(model, batches[used:used + 1])
+        t0 = time.time()
+        TP.train_steps(model, batches[used + 1:used + 1 + n_sweep])
+        sweep[t] = n_sweep * args.batch_size / (time.time() - t0)
+        used += n_sweep + 1
+    best = max(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    rest = batches[used:used + args.cpu_steps]
     t0 = time.time()
-    TP.train_steps(model, batches[3:])
+    TP.train_steps(model, rest)
     dt = time.time() - t0
-    return {'value': args.cpu_steps * args.batch_size / dt, 'unit': 'pairs/s', 'cores': torch.get_num_threads(),
-            'kind': 'port',
+    torch.set_num_threads(default_threads)
+    return {'value': len(rest) * args.batch_size / dt, 'unit': 'pairs/s', 'cores': best, 'kind': 'port',
+            'thread_sweep_pairs_per_s': {str(k): round(v, 1) for k, v in sweep.items()}, 'host_cpus': ncpu,
             'sample': '%d steps of batch_size %d (reference op sequence in PyTorch-CPU, full-size embedding tables, '
-                      'exposure rows of 2000 users), %.1f s' % (args.cpu_steps, args.batch_size, dt)}
+                      'exposure rows of 2000 users) at the best of %s intra-op threads, %.1f s' % (len(rest), args.batch_size, cands, dt)}
 
 
 _REAL_STDOUT = None
@@ -136,6 +155,10 @@ def main():
     dev = torch.device('cuda', local)
     if args.stream:
         torch.cuda.set_stream(torch.cuda.Stream(device=dev))
+    if args.mp == 'sharded' and world == 1:
+        args.force_sharded = 1              # --mp names the layout at any N (N = 1: the pipeline with a one-rank communicator)
+    if args.mp == 'replicated' and world == 1:
+        args.force_replicated = 1
     if world > 1 or args.force_sharded or args.force_replicated:
         import torch.distributed as dist
         if world == 1:
@@ -147,7 +170,7 @@ def main():
         n_params = (args.users + args.items) * args.dim + args.dim * (args.dim + args.feat) + args.dim
         if args.mp == 'auto':
             args.mp = 'replicated' if n_params <= 1e8 else 'sharded'
-        if args.mp == 'sharded' or args.force_sharded:
+        if (args.mp == 'sharded' or args.force_sharded) and not args.force_replicated:
             from dccf_amd import sharded
             return sharded.bench_main(args, rank, world, dev)
         from dccf_amd import replicated
@@ -190,21 +213,10 @@ def main():
     y = torch.cat([torch.ones(B, device=dev), torch.zeros(B, device=dev)])
     batch = {'Y': y, 'rank': 1, 'train': True, 'dropout': p_drop}
 
-    def run(full, k0, k1, events=None):
-        if events is None:      # one library call per step (dccf_train_step)
-            for k in range(k0, k1):
-                batch['X'] = full[k]
-                model.train_step(batch, overlap=args.overlap, X_next=full[k + 1] if args.prep_next and k + 1 < k1 else None)
-            return
+    def run(full, k0, k1):      # one library call per step (dccf_train_step)
         for k in range(k0, k1):
             batch['X'] = full[k]
-            model(batch)
-            if events is not None:
-                events[k - k0][0].record()
-            opt.step()
-            if events is not None:
-                events[k - k0][1].record()
-                events[k - k0][2].record()      # empty bracket: what one event boundary costs on this stream
+            model.train_step(batch, overlap=args.overlap, X_next=full[k + 1] if args.prep_next and k + 1 < k1 else None)
 
     from dccf_amd.models import StepGraph
     sg = StepGraph(model, opt, args.warmup + args.steps, 2 * B, p_drop) if args.graph else None
@@ -235,55 +247,127 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
 
-    # per-kernel durations for the roofline: an eager pass of the same steps with HIP events on the launch stream
-    # (inside a replayed graph the kernels cannot be bracketed individually); not part of the timed region
+    # ---- per-kernel durations, measured live with HIP events on the launch stream; none of this is in the timed region.
+    # Pass A = the launch structure the timed region runs (dccf_train_step with X_next: forward, backward + hosted slice of the
+    # optimizer pass, optimizer launch + the next step's preparation), bracketed inside the library (dccf_profile).
+    # Pass B = the split calls (forward/backward, then the WHOLE dense pass as one launch), for the stand-alone pass.
     n_prof = min(args.steps, 100)
-    events = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(n_prof)]
-    model.ctx.profile(True)
     full = epoch_tensor(2)
     # ~25 ms of queued streaming work first: the host enqueues the whole pass while the GPU is still busy, so no bracket
     # contains a host launch gap (on a slow host the brackets of an idle queue read 5-10 us long)
     blocker = torch.zeros(256 << 20, device=dev)
-    for _ in range(64):
-        blocker.add_(1.0)
-    run(full, 0, n_prof, events)
+
+    def fill_queue():
+        for _ in range(64):
+            blocker.add_(1.0)
+
+    # [event, event] with nothing between: what one event boundary costs on this stream — every bracket contains it once
+    empties = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(2)) for _ in range(n_prof)]
+    model.ctx.profile(True)
+    fill_queue()
+    for k in range(n_prof):
+        batch['X'] = full[k]
+        model.train_step(batch, overlap=args.overlap, X_next=full[k + 1] if args.prep_next and k + 1 < n_prof else None)
+        empties[k][0].record()
+        empties[k][1].record()
     torch.cuda.synchronize()
-    del blocker
-    args_steps_prof = n_prof
-    prof = model.ctx.profile_read()
+    hosted_rows = model.ctx.hosted_rows()
+    prof_a = model.ctx.profile_read()
+    ev_ms = sum(a.elapsed_time(b) for a, b in empties) / n_prof
+    timed = {k: max(v[0] / max(v[1], 1) - ev_ms, 1e-6) for k, v in prof_a.items()}         # ms per launch
+    timed_counts = {k: int(v[1]) for k, v in prof_a.items()}
+    events = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(2)) for _ in range(n_prof)]
+    full = epoch_tensor(3)
+    fill_queue()
+    for k in range(n_prof):
+        batch['X'] = full[k]
+        model(batch)
+        events[k][0].record()
+        opt.step()
+        events[k][1].record()
+    torch.cuda.synchronize()
+    split = {k: max(v[0] / max(v[1], 1) - ev_ms, 1e-6) for k, v in model.ctx.profile_read().items()}
     model.ctx.profile(False)
-    # [event, kernel, event, event]: the second bracket is empty, its duration is the cost of an event boundary, which the
-    # first bracket contains once on top of the kernel (without the correction the figure sits ~4 us above rocprofv3's)
-    ev_ms = sum(b.elapsed_time(c) for _, b, c in events) / args_steps_prof
-    opt_ms = max(sum(a.elapsed_time(b) for a, b, _ in events) / args_steps_prof - ev_ms, 1e-6)
-    kernels = {k: max(v[0] / max(v[1], 1) - ev_ms, 0.0) for k, v in prof.items()}     # ms per launch (same correction)
-    kernels['dense_adam'] = opt_ms
+    whole_pass_ms = max(sum(a.elapsed_time(b) for a, b in events) / n_prof - ev_ms, 1e-6)
+    del blocker
     n_params = model.flat_p.numel()
     L_rows = 2 * B * (S + 1) * A
-    # algorithmic work per launch: dense Adam 28 B/param; noise GEMMs 2*L*F*D flop each
-    cand = {
-        # dense Adam: p, m, v read + written = 24 B per parameter; the gradient is touched only for the rows the step
-        # reached (SURVEY.md §8d prices a gradient-streaming Adam at 28 B/param; the row-aware step moves less)
-        'dense_adam': dict(bound='hbm', work=24.0 * n_params / 1e9, unit='GB/s', peak=HBM_PEAK_GBS),
-        'noise_fwd': dict(bound='mfma', work=2.0 * L_rows * F * D / 1e12, unit='TFLOP/s', peak=MFMA_F32_PEAK_TFLOPS),
-        'noise_bwd_eps': dict(bound='mfma', work=2.0 * L_rows * F * D / 1e12, unit='TFLOP/s', peak=MFMA_F32_PEAK_TFLOPS),
-    }
-    dom = max(cand, key=lambda k: kernels.get(k, 0.0))
-    c = cand[dom]
-    achieved = c['work'] / (kernels[dom] / 1e3)
-    # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    # separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), scaled by the parameter count
-    traffic = None
+    # ---- the same optimizer kernel on a working set far beyond the 256 MiB Infinity Cache (p + m + v = 3.2 GB): at
+    # Electronics size p + m + v = 197 MB sits in that cache and FETCH_SIZE counts its hits, so the in-step figure is a
+    # cache-assisted one; this is the HBM figure
+    big_rows = 4 << 20
+    bp, bg = torch.zeros(big_rows * 64, device=dev), torch.zeros(big_rows * 64, device=dev)
+    b1, b2 = torch.zeros_like(bp), torch.zeros_like(bp)
+    bfl = torch.zeros(big_rows, dtype=torch.uint8, device=dev)
+    bp.normal_(0.0, 0.01)
+    big_ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(2)) for _ in range(12)]
+    for i in range(12):
+        big_ev[i][0].record()
+        L.dense_opt_step_rows('adam', bp, bg, b1, b2, lr, l2, l2, 50.0, i + 1, [(0, big_rows, 64, bfl)])
+        big_ev[i][1].record()
+    torch.cuda.synchronize()
+    big_ms = sum(a.elapsed_time(b) for a, b in big_ev[2:]) / 10 - ev_ms
+    big_gb = 24.0 * big_rows * 64 / 1e9
+    del bp, bg, b1, b2, bfl
+    # ---- algorithmic work per launch.  Dense Adam: p, m, v read + written = 24 B per parameter
+    # (the gradient is touched only for the rows the step reached; SURVEY.md section 8d prices a gradient-streaming Adam at 28).
+    hosted_params = hosted_rows * D
+    opt_gb = 24.0 * (n_params - hosted_params) / 1e9
+    fwd_tf = 2.0 * L_rows * (D + F) * D / 1e12
+    bwd_tf = (2.0 * L_rows * (D + F) * D + 2.0 * L_rows * D * D) / 1e12
+    kernels = {'opt_launch': timed.get('opt_launch', whole_pass_ms), 'noise_fwd': timed['noise_fwd'], 'k_bwd': timed['noise_bwd_eps']}
+    if 'prep' in timed:
+        kernels['k_prep (unprepared steps only: %d of %d)' % (timed_counts['prep'], n_prof)] = timed['prep']
+    dom = max(('opt_launch', 'noise_fwd', 'k_bwd'), key=lambda k: kernels[k])
+    pmc = None
     try:
-        pm = json.load(open(os.path.join(REPO, 'profiles', 'r01_pmc_traffic.json')))
-        if dom == 'dense_adam':
-            traffic = round(pm['_meta']['dense_adam_bytes_per_param'] * n_params / 1e9, 4)      # GB per launch
+        pmc = json.load(open(os.path.join(REPO, 'profiles', 'r02_pmc_traffic.json')))['_meta']
     except Exception:
         pass
-    roofline = {'kernel': dom, 'bound': c['bound'], 'achieved': round(achieved, 2), 'peak': c['peak'], 'unit': c['unit'],
-                'frac': round(achieved / c['peak'], 4), 'traffic': traffic, 'traffic_unit': 'GB per launch (PMC)',
-                'algorithmic_per_launch': round(c['work'], 4), 'avg_launch_ms': round(kernels[dom], 5),
-                'event_boundary_ms': round(ev_ms, 5)}
+    if dom == 'opt_launch':
+        achieved = opt_gb / (kernels[dom] / 1e3)
+        roofline = {'kernel': 'k_dense_opt_rows<Adam> as launched by dccf_train_step (U, W, b, the marked rows of V and the rows '
+                              'of V not hosted in the backward launch; + the next step\'s preparation)',
+                    'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(achieved / HBM_PEAK_GBS, 4),
+                    'traffic': round(pmc['dense_adam_bytes_per_param'] * (n_params - hosted_params) / 1e9, 4) if pmc else None,
+                    'traffic_unit': 'GB per launch; NOT measured in this run: bytes/param of the separate rocprofv3 --pmc '
+                                    'FETCH_SIZE / WRITE_SIZE passes committed as profiles/r02_pmc_traffic.json',
+                    'algorithmic_per_launch': round(opt_gb, 4), 'avg_launch_ms': round(kernels[dom], 5)}
+    else:
+        tf = fwd_tf if dom == 'noise_fwd' else bwd_tf
+        achieved = tf / (kernels[dom] / 1e3)
+        roofline = {'kernel': dom, 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
+                    'algorithmic_per_launch': round(tf, 6), 'avg_launch_ms': round(kernels[dom], 5)}
+    roofline.update({
+        'launch_structure': 'dccf_train_step with X_next: the launches the timed region runs, bracketed by HIP events inside the '
+                            'library on the launch stream; event boundary %.4f ms subtracted' % ev_ms,
+        'hosted_in_backward_launch': {'item_rows': hosted_rows, 'GB': round(24.0 * hosted_params / 1e9, 4)},
+        # the whole pass as ONE launch (split calls): same kernel, nothing hosted
+        'whole_pass': {'avg_launch_ms': round(whole_pass_ms, 5), 'algorithmic_GB': round(24.0 * n_params / 1e9, 4),
+                       'achieved': round(24.0 * n_params / 1e9 / (whole_pass_ms / 1e3), 1),
+                       'frac': round(24.0 * n_params / 1e9 / (whole_pass_ms / 1e3) / HBM_PEAK_GBS, 4)},
+        # p + m + v of this model (197 MB) fit the 256 MiB Infinity Cache: the figures above are cache-assisted.  The same
+        # kernel on 3.2 GB of state:
+        'frac_beyond_llc': round(big_gb / (big_ms / 1e3) / HBM_PEAK_GBS, 4),
+        'beyond_llc': {'params': big_rows * 64, 'algorithmic_GB': round(big_gb, 3), 'avg_launch_ms': round(big_ms, 4),
+                       'achieved': round(big_gb / (big_ms / 1e3), 1)},
+        'event_boundary_ms': round(ev_ms, 5)})
+    roofline_mfma = {
+        'peak_TFLOPs': MFMA_F32_PEAK_TFLOPS,
+        'noise_fwd': {'flops': fwd_tf * 1e12, 'avg_us': round(kernels['noise_fwd'] * 1e3, 2),
+                      'TFLOPs': round(fwd_tf / (kernels['noise_fwd'] / 1e3), 2),
+                      'frac': round(fwd_tf / (kernels['noise_fwd'] / 1e3) / MFMA_F32_PEAK_TFLOPS, 4)},
+        'k_bwd': {'flops': bwd_tf * 1e12, 'avg_us': round(kernels['k_bwd'] * 1e3, 2),
+                  'TFLOPs': round(bwd_tf / (kernels['k_bwd'] / 1e3), 2),
+                  'frac': round(bwd_tf / (kernels['k_bwd'] / 1e3) / MFMA_F32_PEAK_TFLOPS, 4),
+                  'note': 'the launch also hosts %.1f MB of the optimizer pass (item rows this step does not touch)'
+                          % (24.0 * hosted_params / 1e6)},
+        'k_bwd_alone': {'avg_us': round(split['noise_bwd_eps'] * 1e3, 2),
+                        'frac': round(bwd_tf / (split['noise_bwd_eps'] / 1e3) / MFMA_F32_PEAK_TFLOPS, 4),
+                        'note': 'split calls: the backward launch with nothing hosted'}}
+    kernels['dense_adam_whole_pass (split calls)'] = whole_pass_ms
     value = args.steps * B / dt
     out = {
         'metric': 'train pairs/sec at rank=64 Electronics', 'value': round(value, 1), 'unit': 'pairs/s', 'n_gpus': 1,
@@ -295,10 +379,11 @@ def main():
                    'batch_size': B, 'optimizer': 'Adam lr=1e-3 l2=1e-4 dropout=0.2', 'params': n_params,
                    'step_launch': 'hipGraph replay' if args.graph else 'eager launches'},
         'roofline': roofline,
+        'roofline_mfma': roofline_mfma,
         'kernel_ms': {k: round(v, 5) for k, v in sorted(kernels.items())},
         'embedding_fwd_bwd': {   # 4D(3+6(S+1)) + 8F + 8(S+1) + 32 algorithmic bytes per pair
             'bytes_per_pair': 4 * D * (3 + 6 * (S + 1)) + 8 * F + 8 * (S + 1) + 32,
-            'kernel_ms': round(sum(v for k, v in kernels.items() if k != 'dense_adam'), 5)},
+            'kernel_ms': round(split['noise_fwd'] + split['noise_bwd_eps'] + split.get('pair_epilogue', 0.0), 5)},
     }
     ebp = out['embedding_fwd_bwd']
     ebp['achieved_GBps'] = round(B * ebp['bytes_per_pair'] / (ebp['kernel_ms'] / 1e3) / 1e9, 2)

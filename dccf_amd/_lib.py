@@ -17,7 +17,7 @@ EXPORTS = ['dccf_ctx_create', 'dccf_ctx_destroy', 'dccf_ctx_reserve', 'dccf_last
            'shard_pack_rows', 'shard_unpack_rows', 'shard_scatter_add', 'dccf_dense_opt_step_rows', 'dccf_dense_opt_step_dev', 'dccf_advance', 'rank_eval_topk', 'dccf_train_step', 'dp_buffer_words',
            'dp_export_touched', 'dp_import_touched', 'dp_mark_global', 'dccf_dense_opt_phase', 'dccf_ctx_side_stream', 'dp_import_apply',
            'dccf_sample_eval_negatives', 'dccf_eval_prepare', 'dccf_predict_projected', 'dccf_dp_local', 'dccf_dp_overlap',
-           'dccf_dp_finish', 'dccf_ctx_prepared_steps']
+           'dccf_dp_finish', 'dccf_ctx_prepared_steps', 'dccf_ctx_hosted_rows', 'shard_pack_multi', 'shard_unpack_multi', 'dccf_build_epoch_batches']
 
 ABI_VERSION = 2
 OPT_KIND = {'gd': 0, 'adagrad': 1, 'adam': 2}
@@ -63,6 +63,11 @@ class DpT(C.Structure):
 class DpNextT(C.Structure):
     _fields_ = [('ctx', _f), ('model', C.POINTER(ModelT)), ('X_next', _f), ('X_all_next', _f), ('N', C.c_int64),
                 ('step0_next', C.c_uint64)]
+
+
+class ShardJobT(C.Structure):
+    _fields_ = [('idx', _f), ('dst', _f), ('n', C.c_int64), ('tables', _f * 4), ('widths', C.c_int32 * 4),
+                ('ntables', C.c_int32), ('ld', C.c_int32), ('buf', _f)]
 
 
 class MFModelT(C.Structure):
@@ -131,6 +136,7 @@ def load():
         'mf_predict_full': [C.POINTER(MFModelT), vp, vp],
         'dccf_sample_train_negatives': [vp, vp, vp, vp, i64, i64, u64, u64, vp, vp],
         'dccf_ctx_prepared_steps': [vp, C.POINTER(C.c_int64)],
+        'dccf_ctx_hosted_rows': [vp, C.POINTER(C.c_int64)],
         'dccf_debug_candidates': [i64, i32, i64, u64, u64, vp, vp],
         'dccf_debug_noise': [i64, i32, f32, u64, u64, vp, vp],
         'dccf_debug_keep': [i64, i32, f32, u64, u64, vp, vp],
@@ -139,6 +145,9 @@ def load():
         'shard_pack_rows': [vp, vp, i64, C.POINTER(vp), C.POINTER(i32), i32, vp, i32, vp],
         'shard_unpack_rows': [vp, i32, i64, vp, C.POINTER(vp), C.POINTER(i32), i32, vp],
         'shard_scatter_add': [vp, i64, vp, i32, vp, vp, vp],
+        'dccf_build_epoch_batches': [vp, vp, vp, vp, i64, i64, vp, vp, vp, vp],
+        'shard_pack_multi': [vp, i32, vp],
+        'shard_unpack_multi': [vp, i32, vp, i64, vp],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)
@@ -186,13 +195,19 @@ class Context(object):
         check(load().dccf_ctx_prepared_steps(self.h, C.byref(n)))
         return n.value
 
+    def hosted_rows(self):
+        """Item rows whose untouched-row optimizer pass rode in the backward launch of the last training call."""
+        n = C.c_int64()
+        check(load().dccf_ctx_hosted_rows(self.h, C.byref(n)))
+        return n.value
+
     def side_stream(self):
         """The context's low-priority (or CU-masked, DCCF_SIDE_CUS) stream as a torch stream."""
         h = C.c_void_p()
         check(load().dccf_ctx_side_stream(self.h, C.byref(h)))
         return torch.cuda.ExternalStream(h.value)
 
-    KERNELS = ['prep', 'base', 'noise_fwd', 'pair_epilogue', 'bwd_small', 'noise_bwd_eps', 'noise_bwd_feat', 'unused']
+    KERNELS = ['prep', 'mlp_fwd', 'noise_fwd', 'pair_epilogue', 'mlp_bwd', 'noise_bwd_eps', 'opt_launch', 'unused']
 
     def profile(self, enable=True):
         check(load().dccf_profile(self.h, 1 if enable else 0))
@@ -452,6 +467,43 @@ def shard_unpack_rows(payload, n, dst, tables):
     ptrs, widths, k = _table_args(tables)
     check(load().shard_unpack_rows(ptr(payload, torch.float32), int(payload.shape[1]), int(n), ptr(dst, torch.int32), ptrs,
                                    widths, k, stream()))
+
+
+def build_epoch_batches(uid, iid, neg, perm, batch_size, bad):
+    """(full [n // B, 2B, 2], tail [2 (n % B), 2] or None) int64 from the epoch's permutation — one launch."""
+    n = uid.numel()
+    nb, r = n // batch_size, n % batch_size
+    full = torch.empty((nb, 2 * batch_size, 2), dtype=torch.int64, device=uid.device)
+    tail = torch.empty((2 * r, 2), dtype=torch.int64, device=uid.device) if r else None
+    check(load().dccf_build_epoch_batches(ptr(uid, torch.int64), ptr(iid, torch.int64), ptr(neg, torch.int64), ptr(perm, torch.int64),
+                                          n, int(batch_size), ptr(full, torch.int64), ptr(tail, torch.int64), ptr(bad, torch.int32),
+                                          stream()))
+    return full, tail
+
+
+def shard_jobs(jobs):
+    """A HOST array of shard_job_t from [(idx, dst, n, tables, payload)] (idx / dst int32 tensors or None); keeps the tensors
+    alive.  `n`, `idx` and `dst` may be rewritten per step through the returned array (a[q].n = ..., a[q].idx = ptr)."""
+    a = (ShardJobT * len(jobs))()
+    keep = []
+    for q, (idx, dst, n, tables, payload) in enumerate(jobs):
+        a[q].idx, a[q].dst, a[q].n = ptr(idx, torch.int32), ptr(dst, torch.int32), int(n)
+        for t, tb in enumerate(tables):
+            a[q].tables[t] = ptr(tb, torch.float32)
+            a[q].widths[t] = int(tb.shape[1]) if tb.dim() > 1 else 1
+        a[q].ntables, a[q].ld, a[q].buf = len(tables), int(payload.shape[1]), ptr(payload, torch.float32)
+        keep.append((idx, dst, tables, payload))
+    a._keep = keep
+    return a
+
+
+def shard_pack_multi(jobs):
+    check(load().shard_pack_multi(C.cast(jobs, C.c_void_p), len(jobs), stream()))
+
+
+def shard_unpack_multi(jobs, zero=None):
+    check(load().shard_unpack_multi(C.cast(jobs, C.c_void_p), len(jobs), ptr(zero, torch.float32), zero.numel() if zero is not None else 0,
+                                    stream()))
 
 
 def shard_scatter_add(idx, n, rows, g, flags=None):

@@ -30,7 +30,7 @@ static inline int dccf_fail(int code, const char* msg) {
   } while (0)
 
 // ---------------------------------------------------------------------------------------------- context
-#define DCCF_PROF_SLOTS 8     // 0 prep 1 base 2 noise_fwd 3 pair_epilogue 4 bwd_small 5 noise_bwd(eps) 6 noise_bwd(feat)
+#define DCCF_PROF_SLOTS 8     // 0 prep 1 mlp_fwd 2 noise_fwd 3 pair_epilogue 4 mlp_bwd 5 bwd 6 opt_launch (dccf_train_step)
 #define DCCF_PROF_EVENTS 16384
 struct dccf_ctx {
   int device;
@@ -69,6 +69,7 @@ struct dccf_ctx {
   uint8_t* hv_flags[2];
   int64_t hv_items;
   int hv_parity, hv_prepared;
+  int64_t last_hosted_rows;  // item rows whose untouched-row pass the last training call hosted in its backward launch
   const void* prep_Xall;
   int64_t prep_N;
   uint64_t prep_step, prep_seed;

@@ -1277,6 +1277,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     hv_rows = min(M->item_num, (int64_t)(frac * (double)M->item_num) / unit * unit);
     if (frac >= 1.0) hv_rows = M->item_num * M->D % 256 == 0 ? M->item_num : M->item_num / unit * unit;
   }
+  ctx->last_hosted_rows = hv_rows;
   ctx->prep_valid = 0;       // consumed — or overwritten by the k_prep below
   if (prepared) ++ctx->prep_hits;
   if (!prepared) {
@@ -1342,6 +1343,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     }                                                                                                                \
   }
   if (NX > 0) {
+    prof_begin(ctx, st);
     ma.U = M->U; ma.X = X; ma.m = m; ma.dmns = dmns; ma.L = y.L; ma.rpn = S1 * A; ma.A = A; ma.Dr = D; ma.DP = y.DP;
     ma.fused = fused ? 1 : 0; ma.drop_thr = thr; ma.kscale = kscale; ma.dkey = dkey; ma.sr = sr;
     for (int k = 1; k <= NX; ++k) {
@@ -1354,6 +1356,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
       BY_D(D, LAUNCH_MF)
 #undef LAUNCH_MF
     }
+    prof_end(ctx, 1, st);
   }
   // training with at most 16 candidates per row: the pair epilogue is folded into the backward (wave_dm)
   const bool fold = train && NX == 0 && D == y.DT && S1 <= 16 && A <= 4 && N <= knobs().fold_max_n;
@@ -1398,6 +1401,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     BwdArgs ba;
     ba.dh = nullptr;
     if (NX > 0) {
+      prof_begin(ctx, st);
       // the extra layers, last to first: gW_k, gb_k and dh_{k-1}; then the user gradient from the last layer's output
       float* dhA = (float*)(ws + y.dh);
       float* dhB = (float*)(ws + y.dh + hstride);
@@ -1418,6 +1422,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
       hipLaunchKernelGGL(k_gu_last, dim3((unsigned)min((int64_t)1024, (N + 3) / 4)), dim3(256), 0, st,
                          (const float*)(ws + y.hx + (size_t)(NX - 1) * hstride), (const float*)dmns, X, G->gU, G->touchedU, N, S1, A,
                          D, y.DP, ctx->slot_where, ctx->slot_rows, ctx->slot_offU, ctx->slot_cap, sr);
+      prof_end(ctx, 4, st);
     }
     ba.W = M->W; ba.U = M->U; ba.V = M->V; ba.feat = M->feat; ba.X = X; ba.cand = cand; ba.dmns = dmns; ba.hbuf = hbuf;
     ba.noise = rnd->noise; ba.gU = G->gU; ba.gV = G->gV; ba.gW = G->gW; ba.gb = G->gb;
@@ -1823,6 +1828,14 @@ extern "C" int dccf_train_fwdbwd(dccf_ctx* ctx, const dccf_model_t* model, const
                                  const float* Y, int64_t N, int32_t rank, float dropout, const dccf_grads_t* grads,
                                  float* prediction, float* loss, void* stream) {
   return run_dccf(ctx, model, rnd, X, Y, N, rank, dropout, grads, prediction, loss, true, (hipStream_t)stream);
+}
+
+// Diagnostics (bench.py prices the launches by the bytes they move): item rows whose untouched-row optimizer pass rode in the
+// backward launch of the LAST training call on this context (0: the optimizer launch did the whole pass).
+extern "C" int dccf_ctx_hosted_rows(const dccf_ctx* ctx, int64_t* out) {
+  ARG_CHECK(ctx && out, "NULL argument");
+  *out = ctx->last_hosted_rows;
+  return 0;
 }
 
 extern "C" int dccf_ctx_reserve(dccf_ctx* ctx, int64_t max_rows, int32_t D, int32_t F, int32_t S, int32_t A) {

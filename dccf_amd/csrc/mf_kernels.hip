@@ -702,6 +702,44 @@ extern "C" int dccf_sample_train_negatives(const int64_t* rows_indptr, const int
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ epoch batches
+// The feed dicts of an epoch (src/data_processor/DataProcessor.py:160-207,227-250) as ONE tensor: with the epoch's
+// permutation `perm` (the in-unison shuffle, src/utils/utils.py:82-92) batch k is X = [pos rows ; neg rows],
+// pos row j = (uid, iid)[perm[k*B + j]], neg row j = (uid, neg)[perm[k*B + j]] — rows j and B + j carry the same uid.  The
+// n % B rows left over form the shorter last batch `tail` [2r, 2].  A negative of -1 (a user with nothing left to draw,
+// dccf_sample_train_negatives) is replaced by 0 and reported through *bad: no id below 0 ever reaches a kernel as a row index.
+__global__ __launch_bounds__(256) void k_epoch_batches(const int64_t* __restrict__ uid, const int64_t* __restrict__ iid,
+                                                       const int64_t* __restrict__ neg, const int64_t* __restrict__ perm, int64_t n,
+                                                       int64_t B, int64_t* __restrict__ full, int64_t* __restrict__ tail,
+                                                       int32_t* __restrict__ bad) {
+  const int64_t nb = n / B, r = n - nb * B;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t s = perm[i];
+    const int64_t u = uid[s], ip = iid[s];
+    int64_t ng = neg[s];
+    if (ng < 0) {
+      *bad = 1;
+      ng = 0;
+    }
+    const int64_t k = i / B, j = i - k * B;
+    int64_t* pos_row = k < nb ? full + (k * 2 * B + j) * 2 : tail + j * 2;
+    int64_t* neg_row = k < nb ? full + (k * 2 * B + B + j) * 2 : tail + (r + j) * 2;
+    pos_row[0] = u; pos_row[1] = ip;
+    neg_row[0] = u; neg_row[1] = ng;
+  }
+}
+
+extern "C" int dccf_build_epoch_batches(const int64_t* uid, const int64_t* iid, const int64_t* neg, const int64_t* perm, int64_t n,
+                                        int64_t batch_size, int64_t* full, int64_t* tail, int32_t* bad, void* stream) {
+  ARG_CHECK(n >= 0 && batch_size > 0 && bad, "bad arguments");
+  if (n == 0) return 0;
+  ARG_CHECK(uid && iid && neg && perm && (n < batch_size || full) && (n % batch_size == 0 || tail), "NULL argument");
+  const int grid = (int)min((int64_t)2048, (n + 255) / 256);
+  hipLaunchKernelGGL(k_epoch_batches, dim3(grid), dim3(256), 0, (hipStream_t)stream, uid, iid, neg, perm, n, batch_size, full, tail, bad);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ eval negatives
 // neg_n negatives per DISTINCT user of an eval split (src/data_processor/DataProcessor.py:408-444, first-occurrence rule
 // :420-426): uniform over the items, outside the user's train + validation/test history (sorted CSR -> binary search) and

@@ -306,25 +306,23 @@ class DeviceTrainSet(object):
         self.rows, self.rows_indptr = t(order.astype(np.int64)), t(rows_indptr)
         self.hist_indptr, self.hist_items = t(hist_indptr), t(ki.astype(np.int64))
         self.neg = torch.empty(self.n, dtype=torch.int64, device=self.uid.device)
+        self._bad = torch.zeros(1, dtype=torch.int32, device=self.uid.device)
 
     def sample_negatives(self, epoch):
         return _lib.sample_train_negatives(self.rows_indptr, self.rows, self.hist_indptr, self.hist_items, self.user_num,
                                            self.item_num, self.seed, epoch, out=self.neg)
 
+    def check_negatives(self):
+        """Raises if an epoch_batches() since the last check met a user without an admissible negative (the reference asserts,
+        DataProcessor.py:495).  Called at the end of an epoch: no host synchronisation inside the step loop."""
+        assert self.n == 0 or int(self._bad) == 0, 'no admissible training negative left for some user'
+
     def epoch_batches(self, epoch, batch_size):
+        """Three launches per epoch: the sampler, the permutation, the batch tensor."""
         neg = self.sample_negatives(epoch)
-        # a user whose history leaves nothing to draw: the reference asserts (DataProcessor.py:495); an id of -1 must never
-        # reach the kernels as a row index
-        assert self.n == 0 or int(neg.min()) >= 0, 'no admissible training negative left for some user'
         g = torch.Generator(device=self.uid.device)
         g.manual_seed((self.seed * 1000003 + int(epoch)) & 0x7FFFFFFFFFFFFFFF)
         perm = torch.randperm(self.n, generator=g, device=self.uid.device)
-        u = self.uid[perm]
-        pos = torch.stack([u, self.iid[perm]], 1)
-        ngx = torch.stack([u, neg[perm]], 1)
-        nb = self.n // batch_size
-        full = torch.cat([pos[:nb * batch_size].view(nb, batch_size, 2), ngx[:nb * batch_size].view(nb, batch_size, 2)], 1).contiguous()
-        tail = None
-        if self.n % batch_size:
-            tail = torch.cat([pos[nb * batch_size:], ngx[nb * batch_size:]], 0).contiguous()
-        return full, tail
+        # a user whose history leaves nothing to draw gets -1 from the sampler; the batch kernel stores 0 instead (an id of -1
+        # must never reach a kernel as a row index) and raises the device flag check_negatives() reads
+        return _lib.build_epoch_batches(self.uid, self.iid, neg, perm, batch_size, self._bad)

@@ -298,8 +298,10 @@ def bench_main(args, rank, world, dev):
                'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
                'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                'config': {'workload': 'DCCF train step (fwd + BPR + bwd + dense l2/clip/Adam), Electronics-shaped synthetic: '
-                                      'user_num=%d item_num=%d D=%d F=%d S=%d A=%d, exposure=%s, full replica per GPU, fused '
-                                      'on-device negatives' % (U, I, D, F, S, A, expo_mode),
+                                      'user_num=%d item_num=%d D=%d F=%d S=%d A=%d, exposure=%s, layout=replicated (full replica per '
+                                      'GPU, one all-gather of the touched gradient rows per step; --mp sharded runs the row-sharded '
+                                      'all-to-all layout), fused on-device negatives' % (U, I, D, F, S, A, expo_mode),
+                          'layout': 'replicated',
                           'batch_size_per_gpu': B, 'global_batch': B * world, 'optimizer': 'Adam lr=1e-3 l2=1e-4 dropout=0.2',
                           'collectives_per_step': 'all_gather x1 (touched gradient rows + [dW|db], %.2f MB per rank)'
                                                   % (tr.words * 4 / 1e6),

@@ -121,6 +121,7 @@ class BaseRunner(object):
                 if tail is not None:
                     pred = sg.tail(tail)
                     out = {'prediction': pred, 'check': [('prediction', pred)], 'loss': model._loss[0]}
+                data_processor._dev.check_negatives()
                 model.eval()
                 return out
             y = torch.cat([torch.ones(B, device=full.device), torch.zeros(B, device=full.device)])
@@ -135,6 +136,7 @@ class BaseRunner(object):
                 batch = {'X': tail, 'Y': torch.cat([y[:r], y[B:B + r]]), 'rank': 1, 'train': True, 'dropout': self.dropout,
                          utils.REAL_BATCH_SIZE: r}
                 out = self._step(model, batch)
+            data_processor._dev.check_negatives()
         else:
             batches = self.batches_add_control(data_processor.prepare_batches(data, self.batch_size, train=True), train=True)
             for batch in batches:

@@ -37,19 +37,33 @@ class HipBackend(object):
     def candidates(self, n_rows, S, item_num, seed, step):
         return self.L.debug_candidates(n_rows, S, item_num, seed, step, self.device)
 
-    def pack_rows(self, idx, dst, n, tables, out):
-        self.L.shard_pack_rows(idx, dst, n, tables, out)
+    # Row movers: several pack (unpack) jobs are ONE launch.  `make_jobs` builds the argument block once per epoch plan from
+    # [(idx, dst, n, tables, payload)]; a step only rewrites (idx, dst, n) of each job.
+    def make_jobs(self, jobs):
+        return self.L.shard_jobs(jobs)
 
-    def unpack_rows(self, payload, n, dst, tables):
-        self.L.shard_unpack_rows(payload, n, dst, tables)
+    def set_job(self, jobs, q, idx, dst, n):
+        jobs[q].idx, jobs[q].dst, jobs[q].n = self.L.ptr(idx, torch.int32), self.L.ptr(dst, torch.int32), int(n)
+
+    def pack_multi(self, jobs):
+        self.L.shard_pack_multi(jobs)
+
+    def unpack_multi(self, jobs, zero=None):
+        self.L.shard_unpack_multi(jobs, zero)
 
     def scatter_add(self, idx, n, rows, g, flags=None):
         self.L.shard_scatter_add(idx, n, rows, g, flags)
 
-    def local_step(self, Uc, Vc, W, b, featc, ips, Xc, cand_c, Y, S, A, std, dropout, seed, step, gU, gV, gW, gb):
-        m = self.L.model_struct(Uc, Vc, W, b, featc, None, S, A, std, ips=ips)
-        r = self.L.rand_struct(sample_item=cand_c, seed=seed, step=step)
-        return self.L.dccf_train_fwdbwd(self.ctx, m, r, Xc, Y, 1, dropout, gU, gV, gW, gb)
+    def local_step(self, Uc, Vc, W, b, featc, ips, Xc, cand_c, Y, S, A, std, dropout, seed, step, gU, gV, gW, gb, pred=None,
+                   loss=None):
+        # the compact tables of an epoch plan keep their addresses: the argument blocks are built once per plan
+        key = (Uc.data_ptr(), featc.data_ptr(), W.data_ptr(), gU.data_ptr(), gW.data_ptr())
+        if getattr(self, '_key', None) != key:
+            self._m = self.L.model_struct(Uc, Vc, W, b, featc, None, S, A, std, ips=ips)
+            self._r = self.L.rand_struct(sample_item=cand_c, seed=seed, step=step)
+            self._key = key
+        self._r.sample_item, self._r.step = self.L.ptr(cand_c, torch.int64), int(step)
+        return self.L.dccf_train_fwdbwd(self.ctx, self._m, self._r, Xc, Y, 1, dropout, gU, gV, gW, gb, pred=pred, loss=loss)
 
     def opt_step(self, p, g, s1, s2, lr, l2, t, segments=None):
         if segments:       # rows no peer sent a gradient for: g neither read nor re-zeroed (24 instead of 32 B/param)
@@ -180,42 +194,63 @@ class ShardedDCCF(object):
             send_e=e(re.send_max, we), recv_e=e(T, we), send_f=e(rf.send_max, self.F), recv_f=e(N, self.F),
             E=e(T, D), PQ=e(T, Dq), bb=e(T, 1), prop=e(T, 1), featc=torch.zeros((T, self.F), dtype=f32, device=dev),
             gc=torch.zeros((T, D), dtype=f32, device=dev), gback=e(re.send_max, D),
-            Y=torch.cat([torch.ones(B, device=dev), torch.zeros(B, device=dev)]))
+            Y=torch.cat([torch.ones(B, device=dev), torch.zeros(B, device=dev)]),
+            pred=e(N), loss=e(1))
+        p = self.plan
         self.tables_u = [self.U, self.ips['P'], self.ips['bu'].view(-1, 1), self.user_pad]
         self.tables_i = [self.V, self.ips['Q'], self.ips['bi'].view(-1, 1), self.ips['prop'].view(-1, 1)]
+        # the three outgoing payload kinds are ONE launch, the two incoming ones (+ zeroing the compact gradient table) another
+        p['pack'] = self.be.make_jobs([(re.a_src[0], re.a_dst[0], 0, self.tables_u, p['send_e']),
+                                       (re.b_src[0], re.b_dst[0], 0, self.tables_i, p['send_e']),
+                                       (rf.a_src[0], rf.a_dst[0], 0, [self.feat], p['send_f'])])
+        p['unpack'] = self.be.make_jobs([(None, None, T, [p['E'], p['PQ'], p['bb'], p['prop']], p['recv_e']),
+                                         (None, p['feat_dst'][0], N, [p['featc']], p['recv_f'])])
+        p['ipsc'] = dict(P=p['PQ'], bu=p['bb'].view(-1), Q=p['PQ'], bi=p['bb'].view(-1), prop=p['prop'].view(-1),
+                         b0=self.ips['b0'], M=self.ips['M'])
 
     # ------------------------------------------------------------------------------------------------ one step
     def _a2a(self, out, inp, out_splits, in_splits):
         dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)
 
-    def train_step(self, k):
+    def train_step(self, k, marks=None):
         """Step k of the epoch prepared by begin_epoch.  Returns (prediction [2B], loss [1]) of THIS rank's pairs.
-        4 collectives: rows (users + candidate items in one payload), feature rows, gradient rows, [dW | db]."""
+        4 collectives: rows (users + candidate items in one payload), feature rows, gradient rows, [dW | db].
+        marks: optional callable(name) invoked between the phases (bench: per-phase HIP events)."""
+        mark = marks or (lambda name: None)
         p, be = self.plan, self.be
         re, rf = p['re'], p['rf']
         N, T = p['N'], p['T']
         ne, nf = re.send_n[k], rf.send_n[k]
-        # rows out: users and items share one payload (both are [embedding | IPS factor | bias | prop] rows)
-        be.pack_rows(re.a_src[k], re.a_dst[k], re.na[k], self.tables_u, p['send_e'])
-        be.pack_rows(re.b_src[k], re.b_dst[k], re.nb_[k], self.tables_i, p['send_e'])
-        be.pack_rows(rf.a_src[k], rf.a_dst[k], nf, [self.feat], p['send_f'])
+        # rows out: users and items share one payload (both are [embedding | IPS factor | bias | prop] rows); one launch
+        pk = p['pack']
+        be.set_job(pk, 0, re.a_src[k], re.a_dst[k], re.na[k])
+        be.set_job(pk, 1, re.b_src[k], re.b_dst[k], re.nb_[k])
+        be.set_job(pk, 2, rf.a_src[k], rf.a_dst[k], nf)
+        be.pack_multi(pk)
+        mark('pack')
         self._a2a(p['recv_e'], p['send_e'][:ne], re.recv_splits[k], re.send_splits[k])
         self._a2a(p['recv_f'], p['send_f'][:nf], rf.recv_splits[k], rf.send_splits[k])
-        # compact tables in receive order: ONE table serves users and items (compact id = receive position)
-        be.unpack_rows(p['recv_e'], T, None, [p['E'], p['PQ'], p['bb'], p['prop']])
-        be.unpack_rows(p['recv_f'], N, p['feat_dst'][k], [p['featc']])
-        ipsc = dict(P=p['PQ'], bu=p['bb'].view(-1), Q=p['PQ'], bi=p['bb'].view(-1), prop=p['prop'].view(-1),
-                    b0=self.ips['b0'], M=self.ips['M'])
-        p['gc'].zero_()
-        pred, loss = be.local_step(p['E'], p['E'], self.W, self.b, p['featc'], ipsc, p['Xc'][k], p['cand_c'][k], p['Y'],
+        mark('a2a_rows')
+        # compact tables in receive order: ONE table serves users and items (compact id = receive position); the same launch
+        # zeroes the step's compact gradient table
+        up = p['unpack']
+        be.set_job(up, 1, None, p['feat_dst'][k], N)
+        be.unpack_multi(up, p['gc'])
+        mark('unpack')
+        pred, loss = be.local_step(p['E'], p['E'], self.W, self.b, p['featc'], p['ipsc'], p['Xc'][k], p['cand_c'][k], p['Y'],
                                    self.S, self.A, self.std, self.dropout, self.seed, self.t * self.G + self.rank,
-                                   p['gc'], p['gc'], self.gW, self.gb)
-        # gradient rows back (compact order == receive order: nothing to permute), summed at the owner
+                                   p['gc'], p['gc'], self.gW, self.gb, pred=p['pred'], loss=p['loss'])
+        # [dW | db] is complete after the backward: its all-reduce travels while the gradient rows go back to their owners
+        # (compact order == receive order: nothing to permute) and are summed there
+        mark('fwd_bwd')
+        work = dist.all_reduce(self.g_dense, group=self.group, async_op=True)
         self._a2a(p['gback'][:ne], p['gc'], re.send_splits[k], re.recv_splits[k])
         be.scatter_add(re.g_row[k], ne, p['gback'], self.g_rows, self.touched if self.segments else None)
-        dist.all_reduce(self.g_dense, group=self.group)
+        work.wait()
+        mark('a2a_grads+all_reduce+scatter')
         self.t += 1
         be.opt_step(self.flat_p, self.flat_g, self.s1, self.s2, self.lr, self.l2, self.t, self.segments)
+        mark('adam')
         return pred, loss
 
 
@@ -263,17 +298,50 @@ def bench_main(args, rank, world, dev):
     dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt)
+    # ---- outside the timed region: per-phase GPU time of a step (HIP events between the phases, queue kept full) and its host
+    # cost, and the roofline of the layout's HBM-bound kernel — the dense regularised Adam pass over THIS rank's shard
+    n_prof = min(args.steps, 50)
+    names, evs = [], []
+    blocker = torch.zeros(64 << 20, device=dev)
+    for _ in range(32):
+        blocker.add_(1.0)
+    h0 = time.perf_counter()
+    for k in range(n_prof):
+        row = [torch.cuda.Event(enable_timing=True)]
+        row[0].record()
+
+        def mk(name, row=row):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            row.append(e)
+            if k == 0:
+                names.append(name)
+        tr.train_step(k, marks=mk)
+        evs.append(row)
+    host_us = (time.perf_counter() - h0) / n_prof * 1e6
+    torch.cuda.synchronize()
+    del blocker
+    phase_us = {nm: round(sum(r[i].elapsed_time(r[i + 1]) for r in evs) / n_prof * 1e3, 2) for i, nm in enumerate(names)}
+    adam_ms = max(phase_us['adam'] / 1e3, 1e-6)
+    n_local = tr.flat_p.numel()
+    roofline = {'kernel': 'k_dense_opt_rows<Adam> over the local shard (rows mod G)', 'bound': 'hbm',
+                'achieved': round(24.0 * n_local / 1e9 / (adam_ms / 1e3), 1), 'peak': 8000.0, 'unit': 'GB/s',
+                'frac': round(24.0 * n_local / 1e9 / (adam_ms / 1e3) / 8000.0, 4), 'traffic': None,
+                'algorithmic_per_launch': round(24.0 * n_local / 1e9, 4), 'avg_launch_ms': round(adam_ms, 5),
+                'note': 'includes one event boundary (~4 us); p + m + v of a shard below 256 MiB sit in the Infinity Cache'}
     if rank == 0:
         out = {'metric': 'train pairs/sec at rank=64 Electronics', 'value': round(args.steps * B * world / dt, 1),
                'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
                'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                'config': {'workload': 'DCCF train step (fwd + BPR + bwd + dense l2/clip/Adam), Electronics-shaped synthetic: '
-                                      'user_num=%d item_num=%d D=%d F=%d S=%d A=%d, rows sharded mod %d, exposure from IPS '
-                                      'factors, fused on-device negatives' % (U, I, D, F, S, A, world),
+                                      'user_num=%d item_num=%d D=%d F=%d S=%d A=%d, layout=sharded (embedding rows mod %d, all-to-all '
+                                      'row exchange, all-reduce of [dW|db]), exposure from IPS factors, fused on-device negatives'
+                                      % (U, I, D, F, S, A, world),
+                          'layout': 'sharded',
                           'batch_size_per_gpu': B, 'global_batch': B * world, 'optimizer': 'Adam lr=1e-3 l2=1e-4 dropout=0.2',
                           'collectives_per_step': 'all_to_all x3 (rows, feature rows, grad rows) + all_reduce([dW|db])'},
-               'roofline': None, 'cpu_baseline': None}
+               'roofline': roofline, 'phase_us': phase_us, 'host_us_per_step': round(host_us, 1), 'cpu_baseline': None}
         import bench
         bench.emit(out)
     dist.destroy_process_group()

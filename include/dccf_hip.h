@@ -36,7 +36,8 @@ const char* dccf_last_error(void);
 int dccf_abi_version(void);
 /* Optional per-kernel timing: HIP events on the launch stream around every kernel of dccf_predict / dccf_train_fwdbwd.
  * dccf_profile_read adds elapsed ms / launch counts since the last read into HOST arrays of 8 slots:
- * 0 prep, 1 base, 2 noise_fwd, 3 pair_epilogue, 4 bwd_small, 5 noise_bwd(eps), 6 noise_bwd(feat). */
+ * 0 prep, 1 mlp_fwd (extra layers), 2 noise_fwd, 3 pair_epilogue, 4 mlp_bwd (extra layers + user gradient), 5 bwd,
+ * 6 opt_launch (the optimizer launch of dccf_train_step). */
 int dccf_profile(dccf_ctx* ctx, int enable);
 int dccf_profile_read(dccf_ctx* ctx, double* ms, int64_t* counts);
 
@@ -188,6 +189,9 @@ int dccf_ctx_side_stream(dccf_ctx* ctx, void** out);
 /* Diagnostics: *out = how many dccf_train_step calls on this context started from a step prepared by the previous call
  * (X_next matched) instead of launching k_prep. */
 int dccf_ctx_prepared_steps(const dccf_ctx* ctx, int64_t* out);
+/* Diagnostics: *out = item rows whose untouched-row optimizer pass rode in the backward launch of the last training call on
+ * this context (dccf_train_step at 2B <= 2048; 0 otherwise) — what bench.py needs to price the two launches by their bytes. */
+int dccf_ctx_hosted_rows(const dccf_ctx* ctx, int64_t* out);
 int dccf_train_step(dccf_ctx* ctx, const dccf_model_t* model, const dccf_rand_t* rnd, const int64_t* X, const float* Y,
                     int64_t N, int32_t rank, float dropout, const dccf_grads_t* grads, const dccf_opt_t* opt,
                     float* prediction, float* loss, const int64_t* X_next, uint64_t step_next, void* stream);
@@ -234,6 +238,12 @@ int mf_predict_full(const mf_model_t* model, float* out, void* stream);
 int dccf_sample_train_negatives(const int64_t* rows_indptr, const int64_t* rows, const int64_t* hist_indptr,
                                 const int64_t* hist_items, int64_t user_num, int64_t item_num, uint64_t seed,
                                 uint64_t epoch, int64_t* neg_out, void* stream);
+/* The epoch's feed dicts (src/data_processor/DataProcessor.py:160-207,227-250) as one tensor: with the epoch's permutation
+ * perm [n] (shuffle_in_unison_scary, src/utils/utils.py:82-92) batch k of full [n / B, 2B, 2] is X = [pos ; neg] with
+ * pos row j = (uid, iid)[perm[kB + j]] and neg row j = (uid, neg)[perm[kB + j]]; the n % B rows left over are the shorter last
+ * batch tail [2 (n % B), 2].  A negative of -1 is stored as 0 and *bad (device int32, zeroed by the caller) set to 1. */
+int dccf_build_epoch_batches(const int64_t* uid, const int64_t* iid, const int64_t* neg, const int64_t* perm, int64_t n,
+                             int64_t batch_size, int64_t* full, int64_t* tail, int32_t* bad, void* stream);
 /* Eval negatives (src/data_processor/DataProcessor.py:408-444,446-524 with train=False): neg_n items per DISTINCT user of a
  * split (users [n_users], first-occurrence order), uniform over the items, outside the user's train + validation/test
  * history (hist CSR by user id, items sorted) and distinct.  Draw j of user u = word j%4 of Philox(c0=u, c1=j/4, c2=tag)
@@ -354,6 +364,23 @@ int shard_unpack_rows(const float* in, int32_t ld, int64_t n, const int32_t* dst
 /* g[idx[j], :] += rows[j, :]  — received gradient rows into the owner's gradient shard (float atomics) */
 int shard_scatter_add(const int32_t* idx, int64_t n, const float* rows, int32_t width, float* g, uint8_t* flags,
                       void* stream);   /* flags: optional "touched" byte per row of g (dccf_dense_opt_step_rows) */
+
+/* Several pack / unpack jobs in ONE launch (a step of the sharded path sends user rows, item rows and feature rows and
+ * receives two payload kinds; at batch 128 every launch counts).  HOST array of up to 4 jobs, each as the arguments of
+ * shard_pack_rows / shard_unpack_rows: `buf` is the payload (written by pack, read by unpack), rows `ld` floats apart.
+ * shard_unpack_multi also zeroes zero[0 : zero_n] (the compact per-step gradient table) in the same launch. */
+typedef struct {
+  const int32_t* idx;        /* pack: source row of payload row j; unpack: unused                 */
+  const int32_t* dst;        /* payload row (pack) / table row (unpack) of entry j; NULL = j      */
+  int64_t n;
+  float* tables[4];
+  int32_t widths[4];
+  int32_t ntables;
+  int32_t ld;
+  float* buf;
+} shard_job_t;
+int shard_pack_multi(const shard_job_t* jobs, int32_t njobs, void* stream);
+int shard_unpack_multi(const shard_job_t* jobs, int32_t njobs, float* zero, int64_t zero_n, void* stream);
 
 /* ---- the fused-mode random streams written out (for parity tests: fused == injected on the same draws) ---------- */
 int dccf_debug_candidates(int64_t N, int32_t S, int64_t item_num, uint64_t seed, uint64_t step, int64_t* out, void* stream);

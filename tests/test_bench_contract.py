@@ -48,3 +48,30 @@ def test_replicated_pipeline_line():
         assert k in d, k
     assert d['n_gpus'] == 1 and d['config']['replicas_bit_identical'] is True
     assert d['roofline']['bound'] == 'hbm' and 0 < d['roofline']['frac'] < 1
+
+
+def test_single_gpu_line_is_honest_about_caches_and_mfma():
+    """the HBM figure beyond the Infinity Cache, the MFMA fractions of forward / backward computed in the run,
+    the launch structure that was timed, and `traffic` labelled as coming from the committed PMC passes."""
+    d = run('--cpu_baseline', '0')
+    r = d['roofline']
+    assert 0 < r['frac_beyond_llc'] < 1 and r['beyond_llc']['params'] * 12 > 1 << 30          # p + m + v > 1 GiB
+    assert 'dccf_train_step' in r['launch_structure'] and r['whole_pass']['avg_launch_ms'] > 0
+    assert r['traffic'] is None or 'NOT measured in this run' in r['traffic_unit']
+    m = d['roofline_mfma']
+    for k in ('noise_fwd', 'k_bwd'):
+        assert 0 < m[k]['frac'] < 1 and m[k]['flops'] > 0 and m[k]['avg_us'] > 0
+    assert 'layout' not in d['config'] or d['config']['layout'] == 'single'
+
+
+def test_sharded_pipeline_line():
+    """--mp sharded (the all-to-all layout BASELINE.json's north_star names) at N = 1: the line names the layout, carries a
+    roofline object (the dense Adam pass over the local shard) and the per-phase timings of a step."""
+    d = run('--cpu_baseline', '0', '--mp', 'sharded')
+    for k in KEYS:
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['config']['layout'] == 'sharded' and 'layout=sharded' in d['config']['workload']
+    assert d['roofline']['bound'] == 'hbm' and 0 < d['roofline']['frac'] < 1
+    assert set(d['phase_us']) >= {'pack', 'a2a_rows', 'unpack', 'fwd_bwd', 'adam'} and d['host_us_per_step'] > 0
+    r = run('--cpu_baseline', '0', '--mp', 'replicated')
+    assert r['config']['layout'] == 'replicated' and 'layout=replicated' in r['config']['workload']

@@ -171,3 +171,21 @@ def test_device_train_set_epoch_batches_layout():
     hist_indptr = np.searchsorted(key // I_, np.arange(U_ + 1)).astype(np.int64)
     ref = PH.train_negatives(2019, 1, uid, I_, hist_indptr, (key % I_).astype(np.int64))
     assert np.array_equal(ds.sample_negatives(1).cpu().numpy(), ref)
+
+
+def test_device_train_set_flags_a_user_without_admissible_negative():
+    """A user whose train history leaves no item to draw: the reference asserts (DataProcessor.py:495).  The device path stores
+    item 0 instead of the sampler's -1 (never a negative row index in a kernel) and check_negatives() raises."""
+    from dccf_amd.data_processor import DeviceTrainSet
+    I_ = 12
+    uid = np.concatenate([np.zeros(I_, dtype=np.int64), np.array([1, 1, 2], dtype=np.int64)])       # user 0 interacted with every item
+    iid = np.concatenate([np.arange(I_, dtype=np.int64), np.array([3, 5, 7], dtype=np.int64)])
+    ds = DeviceTrainSet(uid, iid, 3, I_, seed=5)
+    full, tail = ds.epoch_batches(0, 4)
+    X = np.concatenate([full.cpu().numpy().reshape(-1, 2), tail.cpu().numpy()])
+    assert X.min() >= 0 and X[:, 1].max() < I_
+    with pytest.raises(AssertionError, match='no admissible'):
+        ds.check_negatives()
+    ok = DeviceTrainSet(uid[I_:], iid[I_:], 3, I_, seed=5)
+    ok.epoch_batches(0, 4)
+    ok.check_negatives()

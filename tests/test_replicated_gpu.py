@@ -249,3 +249,83 @@ def test_two_ranks_hip_backend_replicas_bit_identical(tmp_path, overlap, world):
         L.dense_opt_step('adam', tr.flat_p, tr.flat_g, s1, s2, 1e-2, 1e-4, 1e-4, 50.0, t + 1)
     d = np.abs(tr.flat_p.cpu().numpy() - r0['p'])
     assert d.max() <= c['steps'] * 1e-2 and (d > c['steps'] * 5e-3 * 1e-2).sum() <= 4 * c['D'] + 8
+
+
+# ------------------------------------------------------------------------------------------------ row-sharded layout, 2 ranks
+def _sharded_rank_main(rank, world, port, out):
+    """One rank of the row-sharded trainer with the HIP backend; both ranks share this box's one GPU, gloo moves the bytes."""
+    import torch.distributed as dist
+    import test_sharded_gloo as TS
+    from dccf_amd import sharded
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    c = TS.CFG
+    P, feat, ips, X = TS.make_world(c)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    ips_loc = dict(P=T(ips['P'][rank::world]), bu=T(ips['bu'][rank::world]), Q=T(ips['Q'][rank::world]),
+                   bi=T(ips['bi'][rank::world]), prop=T(ips['prop'][rank::world]), b0=0.1, M=0.1)
+    tr = sharded.ShardedDCCF(rank, world, c['U'], c['I'], c['D'], c['S'], c['A'], c['std'], c['dropout'], c['lr'], c['l2'],
+                             c['seed'], sharded.HipBackend(dev), dev, T(feat[rank::world]), ips_loc)
+    K = TS.KEYS
+    tr.set_global_params(T(P[K[0]]), T(P[K[1]]), T(P[K[2]]), T(P[K[3]]))
+    preds, losses = [], []
+    tr.begin_epoch(T(np.stack(X)), 3)
+    for step in range(c['steps']):
+        pred, loss = tr.train_step(step)
+        preds.append(pred.cpu().numpy().copy())
+        losses.append(float(loss))
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out, 'sh%d.npz' % rank), U=tr.U.cpu().numpy(), V=tr.V.cpu().numpy(), W=tr.W.cpu().numpy(),
+             b=tr.b.cpu().numpy(), preds=np.stack(preds), losses=np.array(losses), gmax=float(tr.flat_g.abs().max()),
+             touched=int(tr.touched.sum()))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_hip_backend_row_sharded_equals_union_batch(tmp_path):
+    """World size 2 of the ROW-SHARDED layout with the HIP backend (pack / all-to-all / unpack / the single-GPU kernels on
+    compact tables / all-to-all / scatter-add / all-reduce / row-aware Adam): every rank's predictions equal the oracle's on
+    the same counter-based draws, the shards partition the tables (rank r holds rows r, r + G, ...), W and b stay
+    replicated, and the parameters equal ONE oracle step on the union of the ranks' batches to the float-atomic tolerance."""
+    import torch.multiprocessing as mp
+    import test_sharded_gloo as TS
+    from oracle import dccf_oracle as O
+    from oracle import philox as PH
+    world = 2
+    port = 36000 + os.getpid() % 2000
+    mp.spawn(_sharded_rank_main, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    c = TS.CFG
+    K = TS.KEYS
+    P, feat, ips, X = TS.make_world(c)
+    expo = TS.expo_from_ips(ips)
+    opt = O.DenseOptimizer('adam', c['lr'], c['l2'])
+    N, Ld = 2 * c['B'], 2 * c['B'] * (c['S'] + 1) * c['A']
+    Y = np.concatenate([np.ones(c['B'], np.float32), np.zeros(c['B'], np.float32)])
+    res = [dict(np.load(os.path.join(str(tmp_path), 'sh%d.npz' % r))) for r in range(world)]
+    cand_all = PH.candidates(c['seed'], 3, c['steps'] * world * N, c['S'], c['I']).reshape(c['steps'], world, N, c['S'])
+    for step in range(c['steps']):
+        total = {k: np.zeros_like(v) for k, v in P.items()}
+        for r in range(world):
+            noise = PH.noise(c['seed'], step * world + r, Ld, c['F'], c['std'])
+            keep = PH.dropout_keep(c['seed'], step * world + r, Ld, c['D'], float(np.float32(c['dropout'])))
+            fw = O.dccf_forward(P, feat, expo, X[step][r], cand_all[step][r], noise, keep, c['dropout'], c['A'])
+            if step == 0:      # later steps start from parameters that differ by the float-atomic noise of the step before
+                np.testing.assert_allclose(res[r]['preds'][step], fw['prediction'], rtol=1e-4, atol=2e-6)
+            loss, dpred = O.loss_and_dpred(fw['prediction'], Y, 1)
+            assert float(loss) == pytest.approx(float(res[r]['losses'][step]), rel=2e-3)
+            g = O.dccf_backward(P, fw, dpred, c['A'])
+            for k in total:
+                total[k] += g[k]
+        P, _ = O.train_step(P, opt, c['l2'], total)
+    lr, steps = c['lr'], c['steps']
+    for r in range(world):
+        assert res[r]['gmax'] == 0.0 and res[r]['touched'] == 0            # nothing left behind
+        assert res[r]['U'].shape[0] == len(range(r, c['U'], world)) and res[r]['V'].shape[0] == len(range(r, c['I'], world))
+        for mine, ref in ((res[r]['U'], P[K[0]][r::world]), (res[r]['V'], P[K[1]][r::world]), (res[r]['W'], P[K[2]]),
+                          (res[r]['b'], P[K[3]])):
+            d = np.abs(mine - ref)
+            # Adam turns the last-bit differences of float-atomic sums into fractions of lr on a few elements
+            assert d.max() <= steps * lr and (d > steps * 5e-3 * lr).mean() <= 0.02, (d.max(), (d > steps * 5e-3 * lr).mean())
+    assert np.array_equal(res[0]['W'], res[1]['W']) and np.array_equal(res[0]['b'], res[1]['b'])     # replicas stay identical

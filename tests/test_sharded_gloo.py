@@ -28,23 +28,36 @@ class OracleBackend(object):
     def candidates(self, n_rows, S, item_num, seed, step):
         return torch.from_numpy(PH.candidates(seed, step, n_rows, S, item_num))
 
-    def pack_rows(self, idx, dst, n, tables, out):
-        if n:
-            rows = torch.cat([t[idx[:n].long()].view(n, -1) for t in tables], 1)
-            out[(torch.arange(n) if dst is None else dst[:n].long()), :rows.shape[1]] = rows
+    def make_jobs(self, jobs):
+        return [dict(idx=i, dst=d, n=n, tables=t, payload=pl) for (i, d, n, t, pl) in jobs]
 
-    def unpack_rows(self, payload, n, dst, tables):
-        rows = torch.arange(n) if dst is None else dst[:n].long()
-        o = 0
-        for t in tables:
-            t[rows] = payload[:n, o:o + t.shape[1]]
-            o += t.shape[1]
+    def set_job(self, jobs, q, idx, dst, n):
+        jobs[q].update(idx=idx, dst=dst, n=n)
+
+    def pack_multi(self, jobs):
+        for j in jobs:
+            n, idx, dst, tables, out = j['n'], j['idx'], j['dst'], j['tables'], j['payload']
+            if n:
+                rows = torch.cat([t[idx[:n].long()].view(n, -1) for t in tables], 1)
+                out[(torch.arange(n) if dst is None else dst[:n].long()), :rows.shape[1]] = rows
+
+    def unpack_multi(self, jobs, zero=None):
+        for j in jobs:
+            n, dst, payload = j['n'], j['dst'], j['payload']
+            rows = torch.arange(n) if dst is None else dst[:n].long()
+            o = 0
+            for t in j['tables']:
+                t[rows] = payload[:n, o:o + t.shape[1]]
+                o += t.shape[1]
+        if zero is not None:
+            zero.zero_()
 
     def scatter_add(self, idx, n, rows, g, flags=None):
         if n:
             g.index_add_(0, idx[:n].long(), rows[:n])
 
-    def local_step(self, Uc, Vc, W, b, featc, ips, Xc, cand_c, Y, S, A, std, dropout, seed, step, gU, gV, gW, gb):
+    def local_step(self, Uc, Vc, W, b, featc, ips, Xc, cand_c, Y, S, A, std, dropout, seed, step, gU, gV, gW, gb, pred=None,
+                   loss=None):
         P = {KEYS[0]: Uc.numpy(), KEYS[1]: Vc.numpy(), KEYS[2]: W.numpy(), KEYS[3]: b.numpy()}
         ipn = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in ips.items()}
         expo = expo_from_ips(ipn)
