@@ -490,7 +490,8 @@ static int launch_full_band(const mf_model_t* M, float* out, hipStream_t st) {
   constexpr int LD = D + 1;
   const size_t smem = (size_t)(FU * LD + FI * LD + FU * FI + FU) * 4;
   const int64_t bands = (M->user_num + FU - 1) / FU, gi = (M->item_num + FI - 1) / FI;
-  const int splits = (int)max((int64_t)1, min(gi, (4096 + bands - 1) / bands));
+  int splits = (int)max((int64_t)1, min(gi, (4096 + bands - 1) / bands));
+  if (getenv("DCCF_FULL_SPLITS")) splits = (int)max((int64_t)1, min(gi, (int64_t)atoi(getenv("DCCF_FULL_SPLITS"))));
   ARG_CHECK(bands * splits < 2147483647LL, "matrix too large for one launch");
   HIP_TRY(hipFuncSetAttribute((const void*)k_mf_full_band<D, FU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipLaunchKernelGGL((k_mf_full_band<D, FU>), dim3((unsigned)(bands * splits)), dim3(FU * 4), smem, st, *M, out, splits);
@@ -498,11 +499,16 @@ static int launch_full_band(const mf_model_t* M, float* out, hipStream_t st) {
   return 0;
 }
 
-// Q [I][D] -> Q^T [D][Ipad] (zero padded): the B operand of the row-band kernel reads 128-B runs of it
-__global__ __launch_bounds__(256) void k_transpose_q(const float* __restrict__ Q, int64_t I, int D, int64_t Ipad,
+// Q [I][D] -> Q^T in TILE-MAJOR order [Ipad / TW][D][TW] (zero padded): the B operand of a tile of TW items is one contiguous
+// D x TW block (a wave reads 128-B runs of it).  A plain [D][Ipad] layout puts the D rows of a tile 4 * Ipad bytes apart — a
+// stride with its low address bits all zero, so the 2 x D/2 runs a wave fetches per tile fell on the same L2 channels
+// (measured at D = 64: 7.4 ms for the loads alone, with neither MFMA nor stores in the loop).
+__global__ __launch_bounds__(256) void k_transpose_q(const float* __restrict__ Q, int64_t I, int D, int64_t Ipad, int TW,
                                                      float* __restrict__ QT) {
   for (int64_t x = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; x < Ipad * D; x += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t k = x / Ipad, i = x % Ipad;
+    const int64_t T = x / ((int64_t)D * TW);
+    const int k = (int)((x / TW) % D), c = (int)(x % TW);
+    const int64_t i = T * TW + c;
     QT[x] = i < I ? Q[i * D + k] : 0.f;
   }
 }
@@ -515,18 +521,22 @@ __global__ __launch_bounds__(256) void k_transpose_q(const float* __restrict__ Q
 // pure-write microbenchmark of this matrix (75 k x 64 k, rows 4-byte aligned) reaches 4.7 TB/s with fill, 3.8-4.1 TB/s
 // when a workgroup marches along 32 rows with >= 256-B segments per store, 2.5 TB/s with 128-row bands and 1.9 TB/s with
 // the 128-B segments MFMA accumulators give directly.
-template <int D, int RB>
-__global__ __launch_bounds__(512) void k_mf_full_rows(mf_model_t M, float* __restrict__ out, int splits,
-                                                      const float* __restrict__ QT, int64_t Ipad) {
-  __shared__ float Cs[2][32][256 + 4];
+template <int D, int RB, int NW>
+__global__ __launch_bounds__(64 * NW) void k_mf_full_rows(mf_model_t M, float* __restrict__ out, int splits,
+                                                         const float* __restrict__ QT, int64_t Ipad) {
+  constexpr int TW = NW * 32;                 // items per tile: one 32 x 32 block per wave
+  __shared__ float Cs[2][32][TW + 4];
+  __shared__ float Bu[RB * 32];
   constexpr int KS = D / 2, Q4 = D / 4;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (the wave index as a scalar: row pointers and tile bases then live in SGPRs and their arithmetic leaves the vector pipe,
+  // which the fp32 MFMA shares)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = lane >> 5, c31 = lane & 31;
-  const int64_t gt = (M.item_num + 255) / 256;
+  const int64_t gt = (M.item_num + TW - 1) / TW;
   const int64_t band = blockIdx.x / splits, sp = blockIdx.x % splits;
   const int64_t T0 = gt * sp / splits, T1 = gt * (sp + 1) / splits;
   const int64_t u0 = band * (32 * RB);
-  float pa[RB][KS], bur[RB][16];
+  float pa[RB][KS];
 #pragma unroll
   for (int b = 0; b < RB; ++b) {
     const float4* prow = reinterpret_cast<const float4*>(M.P + min(u0 + b * 32 + c31, M.user_num - 1) * D);
@@ -536,57 +546,80 @@ __global__ __launch_bounds__(512) void k_mf_full_rows(mf_model_t M, float* __res
       pa[b][2 * j] = h ? v.y : v.x;
       pa[b][2 * j + 1] = h ? v.w : v.z;
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      bur[b][r] = M.kind >= 1 ? M.bu[min(u0 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, M.user_num - 1)] : 0.f;
   }
+  if (threadIdx.x < RB * 32) Bu[threadIdx.x] = M.kind >= 1 ? M.bu[min(u0 + threadIdx.x, M.user_num - 1)] : 0.f;
+  __syncthreads();
   const float b0 = M.kind >= 1 ? M.b0[0] : 0.f;
-  float qn[KS], bin = 0.f, prn = 1.f;
+  // ONE register copy of the B operand: the next tile's columns are fetched right after the k-loop consumed the current
+  // ones (the epilogue, the barrier and the other resident workgroups cover the round trip) — at D = 64 the second copy cost
+  // the registers that decide between two and three waves per SIMD
+  float qb[KS], bin = 0.f, prn = 1.f;
   auto prefetch = [&](int64_t T) {
-    const int64_t ic = T * 256 + wave * 32 + c31;               // < Ipad (Q^T is padded to whole 256-item tiles)
+    const int64_t ic = T * TW + wave * 32 + c31;                // < Ipad (Q^T is padded to whole tiles)
     const int64_t i = min(ic, M.item_num - 1);
-    const float* qc = QT + ic + (int64_t)h * Ipad;
+    const float* qc = QT + T * (int64_t)(D * TW) + h * TW + wave * 32 + c31;      // tile-major Q^T: [T][k][TW]
 #pragma unroll
-    for (int k = 0; k < KS; ++k) qn[k] = qc[(int64_t)(2 * k) * Ipad];
+    for (int k = 0; k < KS; ++k) qb[k] = qc[2 * k * TW];
     bin = M.kind >= 1 ? M.bi[i] : 0.f;
     prn = M.kind == 2 ? fmaxf(M.prop[i], M.M) : 1.f;
   };
   if (T0 < T1) prefetch(T0);
   int buf = 0;
   for (int64_t T = T0; T < T1; ++T) {
-    float qb[KS];
-#pragma unroll
-    for (int k = 0; k < KS; ++k) qb[k] = qn[k];
     const float bic = bin + b0, prc = prn;
+    // v / prc for 16 values with one divisor: one division for r = 1 / prc, then q = v r refined by one residual step
+    // (q + (v - q prc) r: the correction step of the division expansion itself) — 3 instructions per value instead of ~10 on
+    // the pipe the fp32 MFMA shares with the vector ALU
+    const float rinv = 1.0f / prc;
+    const int64_t c0 = T * TW;
+    // the RB sub-bands of 32 users share the B operand (Q traffic / RB) and are RB independent accumulator chains
+    f32x16 accs[RB];
+#pragma unroll
+    for (int b = 0; b < RB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accs[b][r] = 0.f;
+#pragma unroll
+    for (int k = 0; k < KS; ++k)
+#pragma unroll
+      for (int b = 0; b < RB; ++b) accs[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[b][k], qb[k], accs[b], 0, 0, 0);
     if (T + 1 < T1) prefetch(T + 1);
-    const int64_t c0 = T * 256;
 #pragma unroll
-    for (int b = 0; b < RB; ++b) {          // the sub-bands of 32 users share the B operand: Q traffic / RB
-      f32x16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-      for (int k = 0; k < KS; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[b][k], qb[k], acc, 0, 0, 0);
-      float (*C)[256 + 4] = Cs[buf];
+    for (int b = 0; b < RB; ++b) {
+      const f32x16 acc = accs[b];
+      float (*C)[TW + 4] = Cs[buf];
       buf ^= 1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
         float v = acc[r];
-        if (M.kind >= 1) v = v + bur[b][r] + bic;
-        if (M.kind == 2) v = v / prc;
-        C[(r & 3) + 8 * (r >> 2) + 4 * h][wave * 32 + c31] = v;
+        if (M.kind >= 1) v = v + Bu[b * 32 + row] + bic;
+        if (M.kind == 2) {
+          const float q = v * rinv;
+          v = fmaf(fmaf(-q, prc, v), rinv, q);
+        }
+        C[row][wave * 32 + c31] = v;
       }
       __syncthreads();     // the tile is complete (the other buffer is free again: every wave stored it before arriving)
+      if (c0 + TW <= M.item_num && u0 + b * 32 + 32 <= M.user_num) {      // whole tile inside the matrix: no per-store tests
+        float* orow = out + (u0 + b * 32 + wave) * M.item_num + c0 + lane;
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int row = wave + 8 * rr;
-        const int64_t u = u0 + b * 32 + row;
-        if (u < M.user_num) {
-          float* orow = out + u * M.item_num + c0;
+        for (int rr = 0; rr < 32 / NW; ++rr) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int c = q * 64 + lane;
-            if (c0 + c < M.item_num) orow[c] = C[row][c];
+          for (int q = 0; q < TW / 64; ++q) orow[q * 64] = C[wave + NW * rr][q * 64 + lane];
+          orow += (int64_t)NW * M.item_num;
+        }
+      } else {
+#pragma unroll
+        for (int rr = 0; rr < 32 / NW; ++rr) {
+          const int row = wave + NW * rr;
+          const int64_t u = u0 + b * 32 + row;
+          if (u < M.user_num) {
+            float* orow = out + u * M.item_num + c0;
+#pragma unroll
+            for (int q = 0; q < TW / 64; ++q) {
+              const int c = q * 64 + lane;
+              if (c0 + c < M.item_num) orow[c] = C[row][c];
+            }
           }
         }
       }
@@ -594,18 +627,22 @@ __global__ __launch_bounds__(512) void k_mf_full_rows(mf_model_t M, float* __res
   }
 }
 
-template <int D, int RB>
+template <int D, int RB, int NW = 8>
 static int launch_full_rows(const mf_model_t* M, float* out, hipStream_t st) {
-  const int64_t bands = (M->user_num + 32 * RB - 1) / (32 * RB), gt = (M->item_num + 255) / 256;
-  const int splits = (int)max((int64_t)1, min(gt, (2048 + bands - 1) / bands));
+  const int64_t bands = (M->user_num + 32 * RB - 1) / (32 * RB), gt = (M->item_num + NW * 32 - 1) / (NW * 32);
+  // item range in a multiple of 8 pieces, workgroup = (band, piece) with the piece index fastest: workgroups go round-robin
+  // over the 8 XCDs, so XCD x only ever reads the pieces = x (mod 8) of Q^T — 1/8 of it (2 MB at D = 64) stays in that
+  // XCD's 4 MB L2 while every band streams past it (measured: 10.5 -> 9.8 ms at D = 64 against one piece per band)
+  int splits = gt >= 64 ? 32 : (gt >= 16 ? 8 : 1);
+  if (getenv("DCCF_FULL_SPLITS")) splits = (int)max((int64_t)1, min(gt, (int64_t)atoi(getenv("DCCF_FULL_SPLITS"))));
   ARG_CHECK(bands * splits < 2147483647LL, "matrix too large for one launch");
   ARG_CHECK((uintptr_t)M->P % 16 == 0, "P must be 16-byte aligned");
-  const int64_t Ipad = gt * 256;
+  const int64_t Ipad = gt * NW * 32;
   float* QT = nullptr;
   HIP_TRY(hipMallocAsync((void**)&QT, (size_t)Ipad * D * sizeof(float), st));
   hipLaunchKernelGGL(k_transpose_q, dim3((unsigned)min((int64_t)4096, (Ipad * D + 255) / 256)), dim3(256), 0, st, M->Q, M->item_num, D,
-                     Ipad, QT);
-  hipLaunchKernelGGL((k_mf_full_rows<D, RB>), dim3((unsigned)(bands * splits)), dim3(512), 0, st, *M, out, splits, QT, Ipad);
+                     Ipad, NW * 32, QT);
+  hipLaunchKernelGGL((k_mf_full_rows<D, RB, NW>), dim3((unsigned)(bands * splits)), dim3(64 * NW), 0, st, *M, out, splits, QT, Ipad);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipFreeAsync(QT, st));
   return 0;
@@ -618,12 +655,13 @@ extern "C" int mf_predict_full(const mf_model_t* M, float* out, void* stream) {
   ARG_CHECK(M->kind != 2 || M->prop, "propensity missing");
   ARG_CHECK(M->user_num > 0 && M->item_num > 0, "empty matrix");
   switch (M->D) {
-    // band height per D as measured (CDs-shaped 75k x 64k): D=64 wants 3 workgroups per CU (50 KB of LDS each)
-    // D=16 is bound by the write pattern alone: 32-row bands with 1-KB row segments (6.1 ms vs 8.3 ms for the LDS-band
-    // form; at D >= 32 the re-read of Q by 2,352 narrow bands costs more than the pattern gains: 10.9 / 13.7 ms vs 8.5 / 12.8)
+    // forms per D as measured (CDs-shaped 75k x 64k, profiles/r02_full_matrix_bench.json): the row-band form (32 or 64 users
+    // per workgroup, A operand in registers, tile-major Q^T, 1-KB row segments) for D <= 64: 5.1 / 6.0 / 9.1 ms at D = 16 /
+    // 32 / 64 (round 1: 6.1 / 8.7 / 12.8 with the LDS-band form at D >= 32; rocBLAS sgemm without the epilogue: 7.1 / 9.3 ms
+    // at D = 32 / 64); D = 128 keeps the LDS-band form (the A operand alone would be 64 registers)
     case 16: return launch_full_rows<16, 1>(M, out, (hipStream_t)stream);
-    case 32: return launch_full_band<32, 128>(M, out, (hipStream_t)stream);
-    case 64: return launch_full_band<64, 64>(M, out, (hipStream_t)stream);
+    case 32: return launch_full_rows<32, 2>(M, out, (hipStream_t)stream);
+    case 64: return launch_full_rows<64, 1>(M, out, (hipStream_t)stream);
     case 128: return launch_full_band<128, 128>(M, out, (hipStream_t)stream);
     default: break;                            // other even D: the one-tile-per-workgroup form below
   }

@@ -174,6 +174,7 @@ class BaseRunner(object):
         init_train = self.evaluate(model, train_data, data_processor, metrics=['rmse', 'mae']) if train_data is not None else nm
         init_valid = self.evaluate(model, validation_data, data_processor) if validation_data is not None else nm
         init_test = self.evaluate(model, test_data, data_processor) if test_data is not None else nm
+        self.init_results = (init_train, init_valid, init_test)
         logging.info('Init: \t train= %s validation= %s test= %s [%.1f s] ' % (
             utils.format_metric(init_train), utils.format_metric(init_valid), utils.format_metric(init_test),
             self._check_time()) + ','.join(self.metrics))

@@ -78,7 +78,13 @@ def main():
                 runner = M.main(argv)
                 valid.append(runner.valid_results)
                 test.append(runner.test_results)
-            res[arm] = {'valid': stats(valid), 'test': stats(test), 'seconds': time.time() - t0, 'flags': ARMS[arm]}
+                init.append(runner.init_results[1])
+            res[arm] = {'valid': stats(valid), 'test': stats(test), 'init_valid': stats(init), 'seconds': time.time() - t0,
+                        'flags': ARMS[arm]}
+            di = np.array(res[arm]['init_valid']['mean'])[0] - np.array(res['reference']['init_valid']['mean'])[0]
+            sei = np.sqrt(np.array(res[arm]['init_valid']['se'])[0] ** 2 + np.array(res['reference']['init_valid']['se'])[0] ** 2)
+            print(arm, 'init valid ndcg@5: mine %.4f ref %.4f delta/se %.2f' % (res[arm]['init_valid']['mean'][0],
+                                                                                  res['reference']['init_valid']['mean'][0], di / sei))
             d = np.array(res[arm]['valid']['mean'])[:, 0] - np.array(res['reference']['valid']['mean'])[:, 0]
             se = np.sqrt(np.array(res[arm]['valid']['se'])[:, 0] ** 2 + np.array(res['reference']['valid']['se'])[:, 0] ** 2)
             res[arm]['valid_ndcg5_delta'] = d.tolist()
