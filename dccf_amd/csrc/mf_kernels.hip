@@ -658,11 +658,15 @@ extern "C" int mf_predict_full(const mf_model_t* M, float* out, void* stream) {
     // forms per D as measured (CDs-shaped 75k x 64k, profiles/r02_full_matrix_bench.json): the row-band form (32 or 64 users
     // per workgroup, A operand in registers, tile-major Q^T, 1-KB row segments) for D <= 64: 5.1 / 6.0 / 9.1 ms at D = 16 /
     // 32 / 64 (round 1: 6.1 / 8.7 / 12.8 with the LDS-band form at D >= 32; rocBLAS sgemm without the epilogue: 7.1 / 9.3 ms
-    // at D = 32 / 64); D = 128 keeps the LDS-band form (the A operand alone would be 64 registers)
+    // at D = 32 / 64); D = 128: 4 waves per workgroup (204 VGPRs), 14.9 ms against 22.0 with the LDS-band form
     case 16: return launch_full_rows<16, 1>(M, out, (hipStream_t)stream);
     case 32: return launch_full_rows<32, 2>(M, out, (hipStream_t)stream);
     case 64: return launch_full_rows<64, 1>(M, out, (hipStream_t)stream);
-    case 128: return launch_full_band<128, 128>(M, out, (hipStream_t)stream);
+    case 128: {
+      const char* f = getenv("DCCF_FULL_FORM");
+      if (f && !strcmp(f, "band")) return launch_full_band<128, 128>(M, out, (hipStream_t)stream);      // 22.0 ms
+      return launch_full_rows<128, 1, 4>(M, out, (hipStream_t)stream);      // 14.9 ms (8 waves: 17.9; rocBLAS product only: 12.5)
+    }
     default: break;                            // other even D: the one-tile-per-workgroup form below
   }
   const int64_t nblk = ((M->item_num + FT - 1) / FT) * ((M->user_num + FT - 1) / FT);

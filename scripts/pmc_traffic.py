@@ -3,7 +3,7 @@
 WRITE_SIZE in SEPARATE --pmc passes (no trace domains beside them), FETCH_SIZE doubled for wide coalesced streaming reads on
 gfx950.  Run on the GPU box from the repo root:
 
-    python scripts/pmc_traffic.py            # -> profiles/r01_pmc_traffic.{md,json}
+    python scripts/pmc_traffic.py [r02]      # -> profiles/<round>_pmc_traffic.{md,json}
 
 The profiled command is `python3 bench.py --steps 100 --warmup 10 --cpu_baseline 0` (the program itself after `--`)."""
 import csv
@@ -16,7 +16,13 @@ import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NAMES = {'k_prep': 'prep', 'k_noise_fwd': 'noise_fwd', 'k_pair_epilogue': 'pair_epilogue', 'k_bwd': 'noise_bwd_eps',
-         'k_dense_opt_rows': 'dense_adam'}
+         'k_dense_opt_rows': 'dense_adam', 'k_dense_opt_rows_beyond_llc': 'dense_adam_beyond_llc (268 M parameters)'}
+
+
+N_PARAMS = None
+ROUND = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+# (gpurun merges only gpurun_out/ back: write there on the GPU box, then copy the two files into profiles/)
+OUTDIR = os.path.join(REPO, os.environ.get('PMC_OUT', 'profiles'))
 
 
 def collect(counter, outdir):
@@ -24,13 +30,21 @@ def collect(counter, outdir):
     env = dict(os.environ, TMPDIR='/tmp', DCCF_NO_HOSTV='1')
     cmd = ['rocprofv3', '--pmc', counter, '--output-format', 'csv', '-d', outdir, '--', 'python3', os.path.join(REPO, 'bench.py'),
            '--steps', '100', '--warmup', '10', '--cpu_baseline', '0']
-    subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+    r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True)
+    global N_PARAMS
+    for line in r.stdout.decode().splitlines():
+        if line.startswith('{') and '"params"' in line:
+            N_PARAMS = json.loads(line)['config']['params']
     f = glob.glob(os.path.join(outdir, '**', '*counter_collection.csv'), recursive=True)[0]
     acc = {}
     for r in csv.DictReader(open(f)):
         if r['Counter_Name'] != counter:
             continue
-        name = re.match(r'(?:void )?([\w:]+)', re.sub(r'\(anonymous namespace\)::', '', r['Kernel_Name'])).group(1)
+        full = re.sub(r'\(anonymous namespace\)::', '', r['Kernel_Name'])
+        name = re.match(r'(?:void )?([\w:]+)', full).group(1)
+        # bench.py also runs the optimizer kernel on a 3.2 GB buffer (roofline.frac_beyond_llc): a one-segment instance, kept apart
+        if name == 'k_dense_opt_rows' and re.search(r'k_dense_opt_rows<\d+, 2,', full):
+            name = 'k_dense_opt_rows_beyond_llc'
         a = acc.setdefault(name, [0.0, 0])
         a[0] += float(r['Counter_Value'])
         a[1] += 1
@@ -50,16 +64,12 @@ def main():
         rd, wr = 2.0 * fk * 1024 / 1e6, wk * 1024 / 1e6
         res[short] = {'fetch_kb': fk, 'write_kb': wk, 'read_mb_corrected': rd, 'write_mb': wr, 'total_mb': rd + wr}
         lines.append('| `%s` | %d | %.1f | %.2f | %.1f | %.2f | %.2f |' % (k, n, fk, rd, wk, wr, rd + wr))
-    n_params = None
-    try:
-        n_params = json.loads(open(os.path.join(REPO, 'profiles', 'r01_bench_b128.json')).read().strip().splitlines()[-1])['config']['params']
-    except Exception:
-        pass
+    n_params = N_PARAMS
     if n_params and 'dense_adam' in res:
         res['_meta'] = {'params': n_params, 'dense_adam_bytes_per_param': res['dense_adam']['total_mb'] * 1e6 / n_params}
-    with open(os.path.join(REPO, 'profiles', 'r01_pmc_traffic.json'), 'w') as f:
+    with open(os.path.join(OUTDIR, ROUND + '_pmc_traffic.json'), 'w') as f:
         json.dump(res, f, indent=1)
-    md = ['# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), `python3 bench.py --steps 100 --warmup 10 --cpu_baseline 0`',
+    md = ['# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), `DCCF_NO_HOSTV=1 python3 bench.py --steps 100 --warmup 10 --cpu_baseline 0` (every optimizer launch is then the whole pass)',
           '', 'FETCH_SIZE is in KB and on gfx950 reports exactly half of a wide coalesced streaming read (MI355X_MICROARCH.md §HBM) — the',
           '`read MB` column doubles it; that correction is calibrated for 16-B-per-lane streams (the dense optimizer); the gather',
           "kernels' reads are uncalibrated.  Regenerate with `python scripts/pmc_traffic.py` on the GPU box.", '',
@@ -71,7 +81,7 @@ def main():
                'gradient is read and re-zeroed only for the ~3 k rows a step touches).'
                % (n_params, d['read_mb_corrected'], d['read_mb_corrected'] * 1e6 / n_params, d['write_mb'], d['write_mb'] * 1e6 / n_params,
                   d['total_mb'], 24.0 * n_params / 1e6)]
-    open(os.path.join(REPO, 'profiles', 'r01_pmc_traffic.md'), 'w').write('\n'.join(md) + '\n')
+    open(os.path.join(OUTDIR, ROUND + '_pmc_traffic.md'), 'w').write('\n'.join(md) + '\n')
     print('\n'.join(md))
 
 
