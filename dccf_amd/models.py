@@ -406,6 +406,18 @@ class DCCF(DMF):
         inj = feed_dict.get('inject')
         if inj is not None:   # parity tests: the reference's captured draws
             return _lib.rand_struct(sample_item=inj['sample_item'], noise=inj['noise'], keep=inj.get('keep'))
+        if os.environ.get('DCCF_TORCH_DRAWS') == '1':
+            # A/B diagnostic (scripts/e2e_ab.py, arm torch_draws): the draws of DCCF.predict (src/models/DCCF.py:72,87,94) come from
+            # torch's generator through the INJECTED kernel path instead of the Philox streams — same distributions, another RNG
+            X = feed_dict['X']
+            N, S, A, D = X.shape[0], self.sample_num, self.attribute_num, self.ui_vector_size
+            Ld, F, p = N * (S + 1) * A, self.feature_embedding.shape[1], float(feed_dict['dropout'])
+            keep = None
+            if p > 0:
+                keep = (torch.rand((self.n_layers, Ld, D), device=X.device) >= p).to(torch.uint8)
+            self._call += 1
+            return _lib.rand_struct(sample_item=torch.randint(self.item_num, (N, S), device=X.device),
+                                    noise=torch.randn((Ld, F), device=X.device) * self.std, keep=keep)
         self._struct()
         self._rs.step = self._next_step()
         return self._rs

@@ -32,6 +32,8 @@ ARMS = {
     'host_eval': ['--device_eval', '0'],
     'host_all': ['--fused_sampling', '0', '--device_eval', '0'],
     'projected': ['--eval_noise', 'projected'],
+    # diagnostic: candidates / noise / dropout masks from torch's generator through the injected kernel path (no Philox)
+    'torch_draws': ['--fused_sampling', '0', '--device_eval', '0'],
 }
 
 
@@ -75,12 +77,26 @@ def main():
                         '--u_vector_size', str(int(g['D'])), '--i_vector_size', str(int(g['D'])),
                         '--random_seed', str(seed), '--batch_size', str(int(g['batch_size'])), '--check_epoch', '0',
                         '--verbose', str(logging.WARNING)] + ARMS[arm]
-                runner = M.main(argv)
+                if arm == 'torch_draws':
+                    os.environ['DCCF_TORCH_DRAWS'] = '1'
+                try:
+                    runner = M.main(argv)
+                finally:
+                    os.environ.pop('DCCF_TORCH_DRAWS', None)
                 valid.append(runner.valid_results)
                 test.append(runner.test_results)
                 init.append(runner.init_results[1])
             res[arm] = {'valid': stats(valid), 'test': stats(test), 'init_valid': stats(init), 'seconds': time.time() - t0,
-                        'flags': ARMS[arm]}
+                        'flags': ARMS[arm], 'valid_ndcg5_per_seed': np.asarray(valid)[:, :, 0].tolist()}
+            # the seeds both sides ran: with --fused_sampling 0 the batches and evaluation negatives of a seed are the reference's own,
+            # so the per-seed differences are paired
+            common = [k for k in range(a.seeds) if 2019 + k in ref_seeds]
+            if common:
+                dv = np.array([np.asarray(valid[k])[:, 0] - g['seed%d/valid' % (2019 + k)][:, 0] for k in common])
+                res[arm]['paired'] = {'n': len(common), 'mean_diff': dv.mean(0).tolist(),
+                                      'se_diff': (dv.std(0, ddof=1) / np.sqrt(len(common))).tolist()}
+                print(arm, 'paired over', len(common), 'common seeds: mean diff', np.round(dv.mean(0), 4), 'se',
+                      np.round(dv.std(0, ddof=1) / np.sqrt(len(common)), 4))
             di = np.array(res[arm]['init_valid']['mean'])[0] - np.array(res['reference']['init_valid']['mean'])[0]
             sei = np.sqrt(np.array(res[arm]['init_valid']['se'])[0] ** 2 + np.array(res['reference']['init_valid']['se'])[0] ** 2)
             print(arm, 'init valid ndcg@5: mine %.4f ref %.4f delta/se %.2f' % (res[arm]['init_valid']['mean'][0],
