@@ -261,21 +261,36 @@ def main():
         for _ in range(64):
             blocker.add_(1.0)
 
-    # [event, event] with nothing between: what one event boundary costs on this stream — every bracket contains it once
-    empties = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(2)) for _ in range(n_prof)]
+    def profile_structure(full):
+        """n_prof steps of the timed launch structure with the library's per-launch event brackets; returns (ms per launch by
+        kernel with the event-boundary cost subtracted, launch counts, that cost, item rows hosted in the backward launch)."""
+        # [event, event] with nothing between: what one event boundary costs on this stream — every bracket contains it once
+        empties = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(2)) for _ in range(n_prof)]
+        model.ctx.profile(True)
+        fill_queue()
+        for k in range(n_prof):
+            batch['X'] = full[k]
+            model.train_step(batch, overlap=args.overlap, X_next=full[k + 1] if args.prep_next and k + 1 < n_prof else None)
+            empties[k][0].record()
+            empties[k][1].record()
+        torch.cuda.synchronize()
+        prof = model.ctx.profile_read()
+        model.ctx.profile(False)
+        ev = sum(a.elapsed_time(b) for a, b in empties) / n_prof
+        return ({k: max(v[0] / max(v[1], 1) - ev, 1e-6) for k, v in prof.items()}, {k: int(v[1]) for k, v in prof.items()}, ev,
+                model.ctx.hosted_rows())
+
+    timed, timed_counts, ev_ms, hosted_rows = profile_structure(full)
+    lazy = opt.lazy
+    lazy_rows = int((lazy.list[:2 * B * (S + 2)] >= 0).sum()) if lazy is not None else 0       # distinct rows of the last step
+    dense_timed = None
+    if lazy is not None:
+        # the same steps with the dense pass every launch (lazy_K = 0): the HBM-bound form of the optimizer launch, for the record
+        model.lazy_K = 0
+        model._opt_struct_key = None          # (the next train_step flushes the lazy rows and rebuilds its argument block)
+        dense_timed, _, _, dense_hosted = profile_structure(epoch_tensor(4))
+        model.lazy_K, model._opt_struct_key = lazy.K, None
     model.ctx.profile(True)
-    fill_queue()
-    for k in range(n_prof):
-        batch['X'] = full[k]
-        model.train_step(batch, overlap=args.overlap, X_next=full[k + 1] if args.prep_next and k + 1 < n_prof else None)
-        empties[k][0].record()
-        empties[k][1].record()
-    torch.cuda.synchronize()
-    hosted_rows = model.ctx.hosted_rows()
-    prof_a = model.ctx.profile_read()
-    ev_ms = sum(a.elapsed_time(b) for a, b in empties) / n_prof
-    timed = {k: max(v[0] / max(v[1], 1) - ev_ms, 1e-6) for k, v in prof_a.items()}         # ms per launch
-    timed_counts = {k: int(v[1]) for k, v in prof_a.items()}
     events = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(2)) for _ in range(n_prof)]
     full = epoch_tensor(3)
     fill_queue()
@@ -311,29 +326,49 @@ def main():
     del bp, bg, b1, b2, bfl
     # ---- algorithmic work per launch.  Dense Adam: p, m, v read + written = 24 B per parameter
     # (the gradient is touched only for the rows the step reached; SURVEY.md section 8d prices a gradient-streaming Adam at 28).
-    hosted_params = hosted_rows * D
-    opt_gb = 24.0 * (n_params - hosted_params) / 1e9
     fwd_tf = 2.0 * L_rows * (D + F) * D / 1e12
     bwd_tf = (2.0 * L_rows * (D + F) * D + 2.0 * L_rows * D * D) / 1e12
     kernels = {'opt_launch': timed.get('opt_launch', whole_pass_ms), 'noise_fwd': timed['noise_fwd'], 'k_bwd': timed['noise_bwd_eps']}
+    if 'lazy_catchup' in timed:
+        kernels['k_lazy_catchup'] = timed['lazy_catchup']
     if 'prep' in timed:
         kernels['k_prep (unprepared steps only: %d of %d)' % (timed_counts['prep'], n_prof)] = timed['prep']
-    dom = max(('opt_launch', 'noise_fwd', 'k_bwd'), key=lambda k: kernels[k])
     pmc = None
     try:
         pmc = json.load(open(os.path.join(REPO, 'profiles', 'r02_pmc_traffic.json')))['_meta']
     except Exception:
         pass
-    if dom == 'opt_launch':
-        achieved = opt_gb / (kernels[dom] / 1e3)
-        roofline = {'kernel': 'k_dense_opt_rows<Adam> as launched by dccf_train_step (U, W, b, the marked rows of V and the rows '
-                              'of V not hosted in the backward launch; + the next step\'s preparation)',
-                    'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(achieved / HBM_PEAK_GBS, 4),
-                    'traffic': round(pmc['dense_adam_bytes_per_param'] * (n_params - hosted_params) / 1e9, 4) if pmc else None,
-                    'traffic_unit': 'GB per launch; NOT measured in this run: bytes/param of the separate rocprofv3 --pmc '
-                                    'FETCH_SIZE / WRITE_SIZE passes committed as profiles/r02_pmc_traffic.json',
-                    'algorithmic_per_launch': round(opt_gb, 4), 'avg_launch_ms': round(kernels[dom], 5)}
+
+    def dense_launch(ms, hosted):
+        """The HBM-bound form of the optimizer launch: 24 B per parameter it streams."""
+        gb = 24.0 * (n_params - hosted * D) / 1e9
+        return {'kernel': 'k_dense_opt_rows<Adam> as launched by dccf_train_step (U, W, b, the marked rows of V and the rows of V '
+                          'not hosted in the backward launch; + the next step\'s preparation)',
+                'bound': 'hbm', 'achieved': round(gb / (ms / 1e3), 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': round(gb / (ms / 1e3) / HBM_PEAK_GBS, 4),
+                'traffic': round(pmc['dense_adam_bytes_per_param'] * (n_params - hosted * D) / 1e9, 4) if pmc else None,
+                'traffic_unit': 'GB per launch; NOT measured in this run: bytes/param of the separate rocprofv3 --pmc FETCH_SIZE / '
+                                'WRITE_SIZE passes committed as profiles/r02_pmc_traffic.json',
+                'algorithmic_per_launch': round(gb, 4), 'avg_launch_ms': round(ms, 5),
+                'hosted_in_backward_launch': {'item_rows': hosted, 'GB': round(24.0 * hosted * D / 1e9, 4)}}
+
+    dom = max(('opt_launch', 'noise_fwd', 'k_bwd'), key=lambda k: kernels[k])
+    if dom == 'opt_launch' and lazy is None:
+        roofline = dense_launch(kernels[dom], hosted_rows)
+    elif dom == 'opt_launch':
+        # windowed lazy regularisation: the launch streams 1 / K of the row-structured parameters (24 B each), the rows the step
+        # touched (32 B: + gradient read and re-zeroed) and the dense tail W, b (32 B) — and replays up to K steps per element
+        n_rowp = (U + I) * D
+        gb = (24.0 * n_rowp / lazy.K + 32.0 * lazy_rows * D + 32.0 * (n_params - n_rowp)) / 1e9
+        roofline = {'kernel': 'k_lazy_opt<Adam> (windowed lazy regularisation, K = %d: the rows the step touched, W, b and one K-th of '
+                              'the other rows, advanced K steps in registers; + the next step\'s preparation)' % lazy.K,
+                    'bound': 'hbm', 'achieved': round(gb / (kernels[dom] / 1e3), 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(gb / (kernels[dom] / 1e3) / HBM_PEAK_GBS, 4), 'traffic': None,
+                    'algorithmic_per_launch': round(gb, 4), 'avg_launch_ms': round(kernels[dom], 5),
+                    'note': 'NOT an HBM-bound launch any more: the replay (2 IEEE divisions + 1 square root per element and step, the '
+                            'dense pass\'s exact operation order) is bound by the vector ALU — 16.4 M element-steps cost >= 21 us '
+                            'whatever K is (profiles/r02_lazy_replay_bench.md); the same step with the dense pass is in dense_mode',
+                    'element_steps_per_launch': n_rowp}
     else:
         tf = fwd_tf if dom == 'noise_fwd' else bwd_tf
         achieved = tf / (kernels[dom] / 1e3)
@@ -343,17 +378,23 @@ def main():
     roofline.update({
         'launch_structure': 'dccf_train_step with X_next: the launches the timed region runs, bracketed by HIP events inside the '
                             'library on the launch stream; event boundary %.4f ms subtracted' % ev_ms,
-        'hosted_in_backward_launch': {'item_rows': hosted_rows, 'GB': round(24.0 * hosted_params / 1e9, 4)},
-        # the whole pass as ONE launch (split calls): same kernel, nothing hosted
+        # the whole dense pass as ONE launch (split calls): same kernel, nothing hosted
         'whole_pass': {'avg_launch_ms': round(whole_pass_ms, 5), 'algorithmic_GB': round(24.0 * n_params / 1e9, 4),
                        'achieved': round(24.0 * n_params / 1e9 / (whole_pass_ms / 1e3), 1),
                        'frac': round(24.0 * n_params / 1e9 / (whole_pass_ms / 1e3) / HBM_PEAK_GBS, 4)},
-        # p + m + v of this model (197 MB) fit the 256 MiB Infinity Cache: the figures above are cache-assisted.  The same
+        # p + m + v of this model (197 MB) fit the 256 MiB Infinity Cache: the dense figures are cache-assisted.  The same
         # kernel on 3.2 GB of state:
         'frac_beyond_llc': round(big_gb / (big_ms / 1e3) / HBM_PEAK_GBS, 4),
         'beyond_llc': {'params': big_rows * 64, 'algorithmic_GB': round(big_gb, 3), 'avg_launch_ms': round(big_ms, 4),
                        'achieved': round(big_gb / (big_ms / 1e3), 1)},
         'event_boundary_ms': round(ev_ms, 5)})
+    if dense_timed is not None:
+        d_ms = sum(dense_timed.get(k, 0.0) for k in ('noise_fwd', 'noise_bwd_eps', 'opt_launch'))
+        roofline['dense_mode'] = dict(dense_launch(dense_timed['opt_launch'], dense_hosted),
+                                      step_kernel_ms={'noise_fwd': round(dense_timed['noise_fwd'], 5),
+                                                      'k_bwd': round(dense_timed['noise_bwd_eps'], 5),
+                                                      'opt_launch': round(dense_timed['opt_launch'], 5), 'sum': round(d_ms, 5)},
+                                      how='DCCF_LAZY_K=0 (or model.lazy_K = 0): every optimizer launch streams every parameter')
     roofline_mfma = {
         'peak_TFLOPs': MFMA_F32_PEAK_TFLOPS,
         'noise_fwd': {'flops': fwd_tf * 1e12, 'avg_us': round(kernels['noise_fwd'] * 1e3, 2),
@@ -362,11 +403,8 @@ def main():
         'k_bwd': {'flops': bwd_tf * 1e12, 'avg_us': round(kernels['k_bwd'] * 1e3, 2),
                   'TFLOPs': round(bwd_tf / (kernels['k_bwd'] / 1e3), 2),
                   'frac': round(bwd_tf / (kernels['k_bwd'] / 1e3) / MFMA_F32_PEAK_TFLOPS, 4),
-                  'note': 'the launch also hosts %.1f MB of the optimizer pass (item rows this step does not touch)'
-                          % (24.0 * hosted_params / 1e6)},
-        'k_bwd_alone': {'avg_us': round(split['noise_bwd_eps'] * 1e3, 2),
-                        'frac': round(bwd_tf / (split['noise_bwd_eps'] / 1e3) / MFMA_F32_PEAK_TFLOPS, 4),
-                        'note': 'split calls: the backward launch with nothing hosted'}}
+                  'note': 'the launch also hosts %.1f MB of the optimizer pass' % (24.0 * hosted_rows * D / 1e6) if hosted_rows else
+                          'nothing hosted'}}
     kernels['dense_adam_whole_pass (split calls)'] = whole_pass_ms
     value = args.steps * B / dt
     out = {
@@ -377,6 +415,8 @@ def main():
                                'user_num=%d item_num=%d D=%d F=%d S=%d A=%d, exposure=%s, fused on-device negatives'
                                % (U, I, D, F, S, A, expo_mode),
                    'batch_size': B, 'optimizer': 'Adam lr=1e-3 l2=1e-4 dropout=0.2', 'params': n_params,
+                   'regularisation': ('windowed lazy (K = %d): untouched rows are advanced K steps at a time, bit-identical to the '
+                                      'dense pass' % lazy.K) if lazy is not None else 'dense pass every step',
                    'step_launch': 'hipGraph replay' if args.graph else 'eager launches'},
         'roofline': roofline,
         'roofline_mfma': roofline_mfma,

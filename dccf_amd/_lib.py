@@ -17,9 +17,9 @@ EXPORTS = ['dccf_ctx_create', 'dccf_ctx_destroy', 'dccf_ctx_reserve', 'dccf_last
            'shard_pack_rows', 'shard_unpack_rows', 'shard_scatter_add', 'dccf_dense_opt_step_rows', 'dccf_dense_opt_step_dev', 'dccf_advance', 'rank_eval_topk', 'dccf_train_step', 'dp_buffer_words',
            'dp_export_touched', 'dp_import_touched', 'dp_mark_global', 'dccf_dense_opt_phase', 'dccf_ctx_side_stream', 'dp_import_apply',
            'dccf_sample_eval_negatives', 'dccf_eval_prepare', 'dccf_predict_projected', 'dccf_dp_local', 'dccf_dp_overlap',
-           'dccf_dp_finish', 'dccf_ctx_prepared_steps', 'dccf_ctx_hosted_rows', 'shard_pack_multi', 'shard_unpack_multi', 'dccf_build_epoch_batches']
+           'dccf_dp_finish', 'dccf_ctx_prepared_steps', 'dccf_ctx_hosted_rows', 'shard_pack_multi', 'shard_unpack_multi', 'dccf_build_epoch_batches', 'dccf_lazy_scalars', 'dccf_lazy_flush']
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 OPT_KIND = {'gd': 0, 'adagrad': 1, 'adam': 2}
 MF_KIND = {'RecModel': 0, 'BiasedMF': 1, 'IPSBiasedMF': 2}
 
@@ -49,7 +49,10 @@ class OptT(C.Structure):
     _fields_ = [('kind', C.c_int32), ('overlap', C.c_int32), ('p', _f), ('g', _f), ('s1', _f), ('s2', _f), ('n', C.c_int64),
                 ('lr', C.c_float), ('wd', C.c_float), ('l2', C.c_float), ('clip', C.c_float), ('step', C.c_int64),
                 ('nseg', C.c_int32), ('reserved', C.c_int32), ('seg_begin', _f), ('seg_rows', _f), ('seg_width', _f),
-                ('seg_flags', _f)]
+                ('seg_flags', _f),
+                # windowed lazy regularisation (include/dccf_hip.h: dccf_opt_t.lazy_*)
+                ('lazy_K', C.c_int32), ('lazy_nscal', C.c_int32), ('lazy_last', _f), ('lazy_claim', _f), ('lazy_list', _f),
+                ('lazy_cnt', _f), ('lazy_scal', _f), ('lazy_t0', C.c_int64)]
 
 
 class DpT(C.Structure):
@@ -147,6 +150,8 @@ def load():
         'shard_scatter_add': [vp, i64, vp, i32, vp, vp, vp],
         'dccf_build_epoch_batches': [vp, vp, vp, vp, i64, i64, vp, vp, vp, vp],
         'shard_pack_multi': [vp, i32, vp],
+        'dccf_lazy_scalars': [f32, i64, i32, vp],
+        'dccf_lazy_flush': [C.POINTER(OptT), vp],
         'shard_unpack_multi': [vp, i32, vp, i64, vp],
     }
     for name, args in sig.items():
@@ -207,7 +212,7 @@ class Context(object):
         check(load().dccf_ctx_side_stream(self.h, C.byref(h)))
         return torch.cuda.ExternalStream(h.value)
 
-    KERNELS = ['prep', 'mlp_fwd', 'noise_fwd', 'pair_epilogue', 'mlp_bwd', 'noise_bwd_eps', 'opt_launch', 'unused']
+    KERNELS = ['prep', 'mlp_fwd', 'noise_fwd', 'pair_epilogue', 'mlp_bwd', 'noise_bwd_eps', 'opt_launch', 'lazy_catchup']
 
     def profile(self, enable=True):
         check(load().dccf_profile(self.h, 1 if enable else 0))
@@ -318,6 +323,50 @@ def opt_struct(kind, p, g, s1, s2, lr, wd, l2, clip, segments, overlap):
     o.lr, o.wd, o.l2, o.clip, o.nseg = float(lr), float(wd), float(l2), float(clip), n
     o.seg_begin, o.seg_rows, o.seg_width, o.seg_flags = [C.cast(a, C.c_void_p) for a in o._refs[:4]]
     return o
+
+
+class LazyState(object):
+    """The arrays of the windowed lazy regularisation of a dccf_opt_t (include/dccf_hip.h), owned here as torch tensors: per-row
+    step counters, claims, the step's row list, and the table of Adam step scalars (refilled when the step runs off its end)."""
+    NSCAL = 1 << 15
+
+    def __init__(self, opt, K, n_rows, list_cap, lr, device):
+        self.opt, self.K, self.lr = opt, int(K), float(lr)
+        self.last = torch.zeros(n_rows, dtype=torch.int32, device=device)
+        self.claim = torch.zeros(n_rows, dtype=torch.int32, device=device)
+        self.list = torch.zeros(list_cap, dtype=torch.int32, device=device)
+        self.cnt = torch.zeros(1, dtype=torch.int32, device=device)
+        self.scal = torch.zeros(2 * self.NSCAL, dtype=torch.float32, device=device)
+        self.t0 = -1
+        self.dirty = False          # True while some row may be behind opt.step
+        opt.lazy_K, opt.lazy_nscal = self.K, self.NSCAL
+        opt.lazy_last, opt.lazy_claim = ptr(self.last, torch.int32), ptr(self.claim, torch.int32)
+        opt.lazy_list, opt.lazy_cnt = ptr(self.list, torch.int32), ptr(self.cnt, torch.int32)
+        opt.lazy_scal = ptr(self.scal, torch.float32)
+
+    def cover(self, step):
+        """Makes the scalar table cover [step - K + 1, step] (and a long stretch beyond)."""
+        lo = max(1, step - self.K + 1)
+        if self.t0 < 0 or lo < self.t0 or step >= self.t0 + self.NSCAL:
+            self.t0 = max(0, lo - 1)
+            host = (C.c_float * (2 * self.NSCAL))()
+            check(load().dccf_lazy_scalars(self.lr, self.t0, self.NSCAL, host))
+            self.scal.copy_(torch.frombuffer(host, dtype=torch.float32).clone().to(self.scal.device))
+            self.opt.lazy_t0 = self.t0
+
+    def sync_all(self, step):
+        """Every row IS at `step` (dense steps ran, or nothing ran yet): reset the counters."""
+        self.last.fill_(int(step))
+        self.dirty = False
+
+    def flush(self, step):
+        """Brings every row up to `step` (dccf_lazy_flush); no-op when nothing is behind."""
+        if not self.dirty:
+            return
+        self.opt.step = int(step)
+        self.cover(step)
+        check(load().dccf_lazy_flush(C.byref(self.opt), stream()))
+        self.dirty = False
 
 
 def dccf_train_step(ctx, m, r, X, Y, rank, dropout, gU, gV, gW, gb, opt, step, pred=None, loss=None, touchedU=None,

@@ -1195,6 +1195,7 @@ struct StepPlan {
   int64_t max_rows;
   const int64_t* X_next;     // same N, Philox step `step_next`: prepared inside the optimizer launch (NULL = not known)
   uint64_t step_next;
+  int lazy_segU, lazy_segV;  // >= 0: windowed lazy regularisation (dccf_opt_t.lazy_K > 0); the segments of U and V
 };
 
 static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd, const int64_t* X, const float* Y,
@@ -1218,6 +1219,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
   }
   if (N == 0) {
     if (train) HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), st));
+    if (plan && plan->lazy_segU >= 0) return dccf_lazy_step(plan->opt, nullptr, 0, 0, st);
     if (plan) return dccf_opt_phase(plan->opt, OPT_PHASE_ALL, nullptr, nullptr, 0, st);
     return 0;
   }
@@ -1250,7 +1252,9 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
   // Did the previous dccf_train_step prepare exactly this step (same batch pointer, size, Philox step, seed, tables)?
   const bool prepared = train && !(plan && plan->overlap) && dccf_prep_matches(ctx, M, rnd, X, N);
   // hosted item table (dccf_train_step, no other overlap mode): two sets of "item row touched" bytes owned by the context
-  const bool hostv = plan && !plan->overlap && plan->hostv_seg >= 0 && train;
+  const bool lazy = plan && train && plan->lazy_segU >= 0;
+  ctx->lazy_hosted = 0;
+  const bool hostv = plan && !plan->overlap && plan->hostv_seg >= 0 && train && !lazy;
   if (hostv) {
     const int64_t nb = (M->item_num + 3) / 4 * 4;
     if (ctx->hv_items != nb) {
@@ -1291,6 +1295,12 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
                        M->S, M->item_num, fused_cand ? 1 : 0, ckey, m, y.GY > 1 ? y.L : (int64_t)0, train ? loss : nullptr, sr,
                        mark, hostv ? ctx->hv_flags[ctx->hv_parity] : (uint8_t*)nullptr);
     prof_end(ctx, 0, st);
+  }
+  if (lazy) {
+    // the rows this step reads (its users and candidates, known now) are brought up to the previous step before anything reads them
+    prof_begin(ctx, st);
+    if (int e = dccf_lazy_catchup(plan->opt, X, cand, N, S1, plan->lazy_segU, plan->lazy_segV, st)) return e;
+    prof_end(ctx, 7, st);
   }
   if (plan && plan->overlap && !plan->hosted) {
     // fork: rows NOT on this batch's list see only the l2 term -> their optimizer pass needs nothing from this step
@@ -1379,6 +1389,8 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     // small batches: ~1 workgroup per CU; large ones: ~4 per CU (4 waves per SIMD fill the shared VALU / fp32-MFMA pipe)
     const int64_t gx = max((int64_t)1, min((N + BWD_NW - 1) / BWD_NW, (int64_t)max(1, (N >= 2048 ? 1024 : 256) / roles)));
     // hosted optimizer pass: as many extra workgroups as CUs (one beside each role workgroup)
+    // (hosting the lazy window here as well was measured and lost: its replay is vector-ALU work with long dependent chains, and
+    // the hosted waves — one per SIMD beside the 256-VGPR role waves — cannot issue it fast enough: backward 25 -> 68 us)
     const int opt_rows_y = ((plan && plan->overlap && plan->hosted) || hostv) ? (int)((knobs().hosted_wgs + gx - 1) / gx) : 0;
     const dim3 grid((unsigned)gx, (unsigned)(roles + opt_rows_y));
     const size_t smem = (size_t)4 * 32 * 64 * 4;
@@ -1460,7 +1472,22 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
   HIP_TRY(hipGetLastError());
   if (plan) {
     prof_begin(ctx, st);
-    if (plan->overlap) {
+    if (lazy) {
+      // touched rows + W, b + this step's window of the untouched rows (+ the next step's preparation)
+      const bool prep_ok = plan->X_next && fused_cand && rnd->k_dev == nullptr && plan->opt->p <= M->W &&
+                           M->W + (int64_t)D * (D + F) <= plan->opt->p + plan->opt->n;
+      if (prep_ok) {
+        PrepNext pn;
+        if (int e = dccf_prep_next_fill(ctx, M, N, plan->X_next, rnd->seed, plan->step_next, &pn)) return e;
+        pn.w_begin = M->W - plan->opt->p;
+        pn.w_end = pn.w_begin + (int64_t)D * (D + F);
+        pn.blocks = (int)min((int64_t)64, (y.NS + pn.Lm + 255) / 256);
+        if (int e = dccf_lazy_step(plan->opt, &pn, N * (int64_t)(S1 + 1), ctx->lazy_hosted, st)) return e;
+        dccf_prep_next_commit(ctx, M, N, plan->X_next, rnd->seed, plan->step_next);
+      } else {
+        if (int e = dccf_lazy_step(plan->opt, nullptr, N * (int64_t)(S1 + 1), ctx->lazy_hosted, st)) return e;
+      }
+    } else if (plan->overlap) {
       if (!plan->hosted) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));
       if (int e = dccf_opt_phase(plan->opt, OPT_PHASE_TOUCHED, plan->mark.list, plan->mark.cnt, plan->max_rows, st)) return e;
     } else if (plan->X_next && fused_cand && rnd->k_dev == nullptr && plan->opt->p <= M->W &&
@@ -1512,6 +1539,19 @@ extern "C" int dccf_train_step(dccf_ctx* ctx, const dccf_model_t* M, const dccf_
   }
   plan.X_next = (N > 0 && rank == 1) ? X_next : nullptr;
   plan.step_next = step_next;
+  plan.lazy_segU = plan.lazy_segV = -1;
+  if (opt->lazy_K > 0) {
+    ARG_CHECK(!plan.overlap, "the lazy optimizer (lazy_K > 0) excludes the overlap modes");
+    ARG_CHECK(opt->nseg >= 2 && opt->seg_begin && opt->seg_rows && opt->seg_width && opt->seg_flags, "lazy optimizer needs the U and V row segments");
+    for (int q = 0; q < opt->nseg; ++q) {
+      if (opt->p + opt->seg_begin[q] == M->U && opt->seg_rows[q] == M->user_num && opt->seg_width[q] == M->D) plan.lazy_segU = q;
+      if (opt->p + opt->seg_begin[q] == M->V && opt->seg_rows[q] == M->item_num && opt->seg_width[q] == M->D) plan.lazy_segV = q;
+    }
+    ARG_CHECK(plan.lazy_segU >= 0 && plan.lazy_segV >= 0 && G->touchedU == opt->seg_flags[plan.lazy_segU] &&
+                  G->touchedV == opt->seg_flags[plan.lazy_segV],
+              "lazy optimizer: model->U / model->V must be row segments of opt->p whose flags are grads->touchedU / touchedV");
+    plan.hostv_seg = -1;
+  }
   if (plan.overlap) {
     // the segments that hold U and V, by address
     int qU = -1, qV = -1;

@@ -119,7 +119,84 @@ __device__ __forceinline__ void opt_untouched_pass(const OptJob& j, int64_t bid,
 #undef OPT_UP_LOAD
 }
 
+// ---- windowed lazy regularisation: see dccf_opt_t.lazy_* (include/dccf_hip.h).  Rows are numbered globally: segment q's row r is grow = row_off[q] + r.
+struct LazyArgs {
+  int K, nscal;
+  int64_t t0, step;          // scal[2 (s - t0)], scal[2 (s - t0) + 1] are the scalars of step s
+  int* last;
+  int* claim;
+  int* list;
+  int* cnt;
+  const float* scal;
+  int64_t row_off[4];        // first global row of segment q
+  int64_t rows[4];
+};
+
+// `steps` optimizer steps with a zero loss gradient on one element, starting after step `from`: exactly what the dense pass
+// would have done to it launch by launch
+template <int KIND>
+__device__ __forceinline__ void lazy_replay(float& p, float& s1, float& s2, OptArgs a, const LazyArgs& z, int from, int to) {
+  for (int s = from + 1; s <= to; ++s) {
+    if (KIND == DCCF_OPT_ADAM) {
+      a.step_size_neg = z.scal[2 * (s - z.t0)];
+      a.bc2_sqrt = z.scal[2 * (s - z.t0) + 1];
+    }
+    float g0 = 0.f;
+    opt_elem<KIND>(p, g0, s1, s2, a);
+  }
+}
+template <int KIND>
+__device__ __forceinline__ void lazy_replay4(float4& p, float4& s1, float4& s2, OptArgs a, const LazyArgs& z, int from, int to) {
+  for (int s = from + 1; s <= to; ++s) {
+    if (KIND == DCCF_OPT_ADAM) {
+      a.step_size_neg = z.scal[2 * (s - z.t0)];
+      a.bc2_sqrt = z.scal[2 * (s - z.t0) + 1];
+    }
+    float4 g0 = make_float4(0, 0, 0, 0);
+    opt_elem<KIND>(p.x, g0.x, s1.x, s2.x, a);
+    opt_elem<KIND>(p.y, g0.y, s1.y, s2.y, a);
+    opt_elem<KIND>(p.z, g0.z, s1.z, s2.z, a);
+    opt_elem<KIND>(p.w, g0.w, s1.w, s2.w, a);
+  }
+}
+
+
+// The window of step t: the float4 slots of the rows [win0, win1) of the global row space are advanced to step t (rows this
+// step uses — claim == t — excepted: the step's list updates them with their gradient).  All lanes busy: rows are contiguous.
+// Runs as workgroups bid of nblk — of the optimizer launch, or hosted in the backward launch, whose role waves leave most of
+// the vector ALU's issue slots empty at small batches.
+template <int KIND>
+__device__ __forceinline__ void lazy_window_pass(float* __restrict__ p, float* __restrict__ s1, float* __restrict__ s2,
+                                                 const OptArgs& a, const RowSegs& sg, const LazyArgs& z, int64_t win0, int64_t win1,
+                                                 int flush, int64_t bid, int64_t nblk, int nthreads) {
+  const int t = (int)z.step;
+  for (int q = 0; q < sg.n; ++q) {
+    const int64_t r0 = max(win0, z.row_off[q]) - z.row_off[q], r1 = min(win1, z.row_off[q] + z.rows[q]) - z.row_off[q];
+    if (r1 <= r0) continue;
+    const int w4 = sg.width[q] >> 2;
+    const int64_t nslot = (r1 - r0) * w4;
+    for (int64_t x = bid * nthreads + threadIdx.x; x < nslot; x += nblk * nthreads) {
+      const int64_t row = r0 + x / w4;
+      const int64_t grow = z.row_off[q] + row;
+      const int from = z.last[grow];
+      // a row this step touched is the list's business (its last is t - 1 until that wave has updated it: never replay it here)
+      if (from >= t || (!flush && z.claim[grow] == t)) continue;
+      const int64_t i = (sg.begin[q] >> 2) + row * w4 + x % w4;
+      float4 pv = reinterpret_cast<float4*>(p)[i];
+      float4 av = make_float4(0, 0, 0, 0), bv = make_float4(0, 0, 0, 0);
+      if (KIND != DCCF_OPT_GD) av = reinterpret_cast<float4*>(s1)[i];
+      if (KIND == DCCF_OPT_ADAM) bv = reinterpret_cast<float4*>(s2)[i];
+      lazy_replay4<KIND>(pv, av, bv, a, z, from, t);
+      reinterpret_cast<float4*>(p)[i] = pv;
+      if (KIND != DCCF_OPT_GD) reinterpret_cast<float4*>(s1)[i] = av;
+      if (KIND == DCCF_OPT_ADAM) reinterpret_cast<float4*>(s2)[i] = bv;
+    }
+  }
+}
+
 // opt_kernels.hip: validation + bias corrections (host side) of one optimizer step
 int opt_make_job(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t n, float lr, float wd, float l2, float clip,
                  int64_t step, const int64_t* k_dev, int32_t nseg, const int64_t* seg_begin, const int64_t* seg_rows,
                  const int32_t* seg_width, uint8_t* const* seg_flags, OptJob* out);
+
+int dccf_lazy_window_job(const void* ov, OptJob* j, LazyArgs* z, int64_t* win0, int64_t* win1);

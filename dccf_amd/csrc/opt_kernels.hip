@@ -558,6 +558,224 @@ extern "C" int dccf_dense_opt_step_dev(int32_t kind, float* p, float* g, float* 
                        stream);
 }
 
+// ---------------------------------------------------------------------------------------------- windowed lazy regularisation
+// (LazyArgs, lazy_replay and the window pass: opt_device.hpp — the backward launch can host the window)
+// Before the forward of step t: every distinct row the step reads (the batch's users, its candidates) is claimed by ONE wave
+// (atomicMax on claim), appended to the step's list and brought up to step t - 1.
+template <int KIND>
+__global__ __launch_bounds__(256) void k_lazy_catchup(float* __restrict__ p, float* __restrict__ s1, float* __restrict__ s2,
+                                                      OptArgs a, RowSegs sg, LazyArgs z, const int64_t* __restrict__ X,
+                                                      const int* __restrict__ cand, int64_t N, int S1, int segU, int segV) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int64_t slots = N * S1 + N;
+  const int t = (int)z.step;
+  for (int64_t j = wave; j < slots; j += nw) {
+    int q;
+    int64_t row;
+    if (j < N * S1) { q = segV; row = cand[j]; } else { q = segU; row = X[2 * (j - N * S1)]; }
+    const int64_t grow = z.row_off[q] + row;
+    int won = 0;
+    if (lane == 0) {
+      won = atomicMax(&z.claim[grow], t) < t ? 1 : 0;
+      z.list[j] = won ? (int)grow : -1;        // the step's rows, one entry per slot (-1: another slot owns the row): no shared
+    }                                          // counter — 3,000 appends to one address took 40 us
+    won = __shfl(won, 0, 64);
+    if (!won) continue;
+    const int from = __builtin_amdgcn_readfirstlane(z.last[grow]);      // (uniform: the scalar table is then read by scalar loads)
+    if (from >= t - 1) continue;
+    const int w = sg.width[q];
+    float* pr = p + sg.begin[q] + row * w;
+    float* ar = s1 ? s1 + sg.begin[q] + row * w : nullptr;
+    float* br = s2 ? s2 + sg.begin[q] + row * w : nullptr;
+    for (int c = lane; c < w; c += 64) {
+      float pv = pr[c], av = KIND != DCCF_OPT_GD ? ar[c] : 0.f, bv = KIND == DCCF_OPT_ADAM ? br[c] : 0.f;
+      lazy_replay<KIND>(pv, av, bv, a, z, from, t - 1);
+      pr[c] = pv;
+      if (KIND != DCCF_OPT_GD) ar[c] = av;
+      if (KIND == DCCF_OPT_ADAM) br[c] = bv;
+    }
+    if (lane == 0) z.last[grow] = t - 1;
+  }
+}
+
+// The optimizer launch of step t.  Workgroups by role: [0, pn.blocks) the next step's preparation; then `lb` workgroups walk the
+// step's list (one wave per row: gradient read, step t applied, gradient zeroed, byte cleared); `db` workgroups take the dense
+// tail (W, b, ...: everything outside the row segments); the rest advance this step's window — the rows
+// [R w / K, R (w + 1) / K) of the global row space, w = t mod K — to step t (rows the step touched excepted).
+template <int KIND>
+__global__ __launch_bounds__(256) void k_lazy_opt(float* __restrict__ p, float* __restrict__ g, float* __restrict__ s1,
+                                                  float* __restrict__ s2, OptArgs a, RowSegs sg, DenseSegs ds, LazyArgs z,
+                                                  int lb, int db, int mb, int64_t win0, int64_t win1, int flush, int nslots,
+                                                  PrepNext pn) {
+  if ((int)blockIdx.x < pn.blocks) {
+    prep_next_slots(pn, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)pn.blocks * blockDim.x);
+    return;
+  }
+  const int t = (int)z.step;
+  int bid = (int)blockIdx.x - pn.blocks;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (bid < lb) {                              // ---- the rows this step touched
+    for (int e = bid * 4 + wv; e < nslots; e += lb * 4) {
+      const int64_t grow = z.list[e];
+      if (grow < 0) continue;
+      int q = 0;
+#pragma unroll
+      for (int k = 1; k < 4; ++k)
+        if (k < sg.n && grow >= z.row_off[k]) q = k;
+      const int64_t row = grow - z.row_off[q];
+      const int w = sg.width[q];
+      const int64_t base = sg.begin[q] + row * w;
+      for (int c = lane; c < w; c += 64) {
+        float pv = p[base + c], gv = g[base + c], av = KIND != DCCF_OPT_GD ? s1[base + c] : 0.f,
+              bv = KIND == DCCF_OPT_ADAM ? s2[base + c] : 0.f;
+        opt_elem<KIND>(pv, gv, av, bv, a);
+        p[base + c] = pv;
+        g[base + c] = 0.f;
+        if (KIND != DCCF_OPT_GD) s1[base + c] = av;
+        if (KIND == DCCF_OPT_ADAM) s2[base + c] = bv;
+      }
+      if (lane == 0) {
+        z.last[grow] = t;
+        sg.flags[q][row] = 0;
+      }
+    }
+    return;
+  }
+  bid -= lb;
+  if (bid < db) {                              // ---- everything outside the row segments: dense, with its gradient
+    const int64_t tid = (int64_t)bid * blockDim.x + threadIdx.x, stride = (int64_t)db * blockDim.x;
+    for (int d = 0; d < ds.n; ++d)
+      for (int64_t i = ds.begin[d] + tid; i < ds.end[d]; i += stride) {
+        float pv = p[i], gv = g[i], av = 0.f, bv = 0.f;
+        if (KIND != DCCF_OPT_GD) av = s1[i];
+        if (KIND == DCCF_OPT_ADAM) bv = s2[i];
+        opt_elem<KIND>(pv, gv, av, bv, a);
+        p[i] = pv;
+        g[i] = 0.f;
+        if (KIND != DCCF_OPT_GD) s1[i] = av;
+        if (KIND == DCCF_OPT_ADAM) s2[i] = bv;
+        if (pn.blocks && i >= pn.w_begin && i < pn.w_end) prep_next_wt(pn, i, pv);      // W^T for the next step's forward
+      }
+    return;
+  }
+  bid -= db;
+  const int wb = (int)gridDim.x - pn.blocks - lb - db - mb;
+  if (bid < wb) {                              // ---- the window (unless the backward launch hosted it)
+    lazy_window_pass<KIND>(p, s1, s2, a, sg, z, win0, win1, flush, bid, wb, blockDim.x);
+    return;
+  }
+  bid -= wb;
+  // ---- hosted window: it ran inside the backward launch, which has completed — its rows are at step t now
+  for (int64_t r = win0 + (int64_t)bid * blockDim.x + threadIdx.x; r < win1; r += (int64_t)mb * blockDim.x)
+    if (z.last[r] < t && z.claim[r] != t) z.last[r] = t;
+}
+
+// last[row] = t for the rows of the window, after k_lazy_opt (every lane of a row must have read the old value first)
+__global__ __launch_bounds__(256) void k_lazy_mark(LazyArgs z, int64_t win0, int64_t win1, int flush) {
+  const int t = (int)z.step;
+  for (int64_t r = win0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < win1; r += (int64_t)gridDim.x * blockDim.x)
+    if (z.last[r] < t && (flush || z.claim[r] != t)) z.last[r] = t;
+}
+
+static int lazy_args(const dccf_opt_t* o, const OptJob& j, LazyArgs* z) {
+  ARG_CHECK(o->lazy_K > 0 && o->lazy_last && o->lazy_claim && o->lazy_list, "lazy optimizer: missing arrays");
+  ARG_CHECK(j.sg.n >= 1, "lazy optimizer needs row segments");
+  ARG_CHECK(o->kind != DCCF_OPT_ADAM || (o->lazy_scal && o->lazy_t0 <= max((int64_t)1, o->step - o->lazy_K + 1) &&
+                                         o->step < o->lazy_t0 + o->lazy_nscal),
+            "lazy optimizer: the step-scalar table does not cover [step - K + 1, step]");
+  z->K = o->lazy_K; z->nscal = o->lazy_nscal; z->t0 = o->lazy_t0; z->step = o->step;
+  z->last = o->lazy_last; z->claim = o->lazy_claim; z->list = o->lazy_list; z->cnt = o->lazy_cnt; z->scal = o->lazy_scal;
+  int64_t off = 0;
+  for (int q = 0; q < 4; ++q) {
+    z->row_off[q] = off;
+    z->rows[q] = q < j.sg.n ? (j.sg.end[q] - j.sg.begin[q]) / j.sg.width[q] : 0;
+    off += z->rows[q];
+  }
+  return 0;
+}
+
+extern "C" int dccf_lazy_scalars(float lr, int64_t t0, int32_t n, float* out_host) {
+  ARG_CHECK(out_host && n >= 0 && t0 >= 0, "bad arguments");
+  for (int i = 0; i < n; ++i) {
+    const double s = (double)(t0 + i);
+    // (step 0 is never applied; its slot keeps the table aligned)
+    const double bc1 = 1.0 - pow(0.9, s), bc2 = 1.0 - pow(0.999, s);
+    out_host[2 * i] = s >= 1.0 ? (float)(-((double)lr / bc1)) : 0.f;
+    out_host[2 * i + 1] = s >= 1.0 ? (float)sqrt(bc2) : 1.f;
+  }
+  return 0;
+}
+
+int dccf_lazy_catchup(const void* ov, const int64_t* X, const int* cand, int64_t N, int S1, int segU, int segV, hipStream_t st) {
+  const dccf_opt_t* o = (const dccf_opt_t*)ov;
+  OptJob j;
+  if (int e = opt_job(ov, &j)) return e;
+  LazyArgs z;
+  if (int e = lazy_args(o, j, &z)) return e;
+  ARG_CHECK(segU >= 0 && segU < j.sg.n && segV >= 0 && segV < j.sg.n, "bad segment index");
+  const int64_t slots = N * S1 + N;
+  if (slots == 0) return 0;
+  const int grid = (int)min((int64_t)2048, (slots + 3) / 4);
+  BY_KIND(j.kind, k_lazy_catchup, dim3(grid), dim3(256), 0, st, j.p, j.s1, j.s2, j.a, j.sg, z, X, cand, N, S1, segU, segV);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// hosted: the window pass of this step already ran as extra workgroups of the backward launch (dccf_lazy_window_job): this
+// launch then only marks its rows
+static int lazy_launch(const dccf_opt_t* o, int flush, const PrepNext* pnp, int64_t nslots, hipStream_t st, bool hosted = false) {
+  OptJob j;
+  if (int e = opt_job(o, &j)) return e;
+  LazyArgs z;
+  if (int e = lazy_args(o, j, &z)) return e;
+  DenseSegs ds;
+  int64_t dense_total = 0;
+  if (int e = dense_complement(j.sg, j.n, &ds, &dense_total)) return e;
+  const int64_t R = z.row_off[3] + z.rows[3];
+  const int64_t w = o->step % o->lazy_K;
+  const int64_t win0 = flush ? 0 : R * w / o->lazy_K, win1 = flush ? R : R * (w + 1) / o->lazy_K;
+  PrepNext pn;
+  memset(&pn, 0, sizeof(pn));
+  if (pnp) pn = *pnp;
+  int maxw4 = 4;
+  for (int q = 0; q < j.sg.n; ++q) maxw4 = max(maxw4, j.sg.width[q] >> 2);
+  const int lb = (flush || nslots == 0) ? 0 : (int)min((int64_t)256, (nslots + 3) / 4);
+  const int db = flush ? 0 : (int)min((int64_t)256, (dense_total + 255) / 256);
+  const int wb = hosted ? 0 : (int)max((int64_t)1, min((int64_t)8192, ((win1 - win0) * maxw4 + 255) / 256));
+  const int mb = hosted ? (int)max((int64_t)1, min((int64_t)64, (win1 - win0 + 255) / 256)) : 0;
+  const int grid = pn.blocks + lb + db + wb + mb;
+  BY_KIND(j.kind, k_lazy_opt, dim3(grid), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.a, j.sg, ds, z, lb, db, mb, win0, win1, flush,
+          (int)nslots, pn);
+  if (!hosted)
+    hipLaunchKernelGGL(k_lazy_mark, dim3((unsigned)max((int64_t)1, min((int64_t)1024, (win1 - win0 + 255) / 256))), dim3(256), 0, st, z,
+                       win0, win1, flush);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// What a kernel needs to host this step's window pass (k_bwd): the job, the lazy arrays and the window
+int dccf_lazy_window_job(const void* ov, OptJob* j, LazyArgs* z, int64_t* win0, int64_t* win1) {
+  const dccf_opt_t* o = (const dccf_opt_t*)ov;
+  if (int e = opt_job(ov, j)) return e;
+  if (int e = lazy_args(o, *j, z)) return e;
+  const int64_t R = z->row_off[3] + z->rows[3];
+  const int64_t w = o->step % o->lazy_K;
+  *win0 = R * w / o->lazy_K;
+  *win1 = R * (w + 1) / o->lazy_K;
+  return 0;
+}
+
+int dccf_lazy_step(const void* ov, const PrepNext* pn, int64_t nslots, int hosted, hipStream_t st) {
+  return lazy_launch((const dccf_opt_t*)ov, 0, pn, nslots, st, hosted != 0);
+}
+
+extern "C" int dccf_lazy_flush(const dccf_opt_t* opt, void* stream) {
+  ARG_CHECK(opt != nullptr && opt->lazy_K > 0, "dccf_lazy_flush needs a lazy optimizer (lazy_K > 0)");
+  ARG_CHECK(opt->kind != DCCF_OPT_ADAM || opt->step < opt->lazy_t0 + opt->lazy_nscal, "step-scalar table too short");
+  return lazy_launch(opt, 1, nullptr, 0, (hipStream_t)stream);
+}
+
 __global__ void k_advance(int64_t* k) { *k += 1; }
 extern "C" int dccf_advance(int64_t* k_dev, void* stream) {
   ARG_CHECK(k_dev != nullptr, "k_dev is NULL");

@@ -43,8 +43,18 @@ class FusedOptimizer(object):
         """Grads are zeroed by the fused step itself (src/runners/BaseRunner.py:178 becomes a no-op)."""
         return
 
+    lazy = None       # _lib.LazyState of the windowed lazy regularisation (DCCF.train_step), when enabled
+
+    def flush(self):
+        """Every parameter row up to step t (no-op unless lazy rows are behind): before anything but train_step reads them."""
+        if self.lazy is not None:
+            self.lazy.flush(self.t)
+
     def step(self):
+        self.flush()
         self.t += 1
+        if self.lazy is not None:
+            self.lazy.last.fill_(self.t)       # the dense pass below brings every row to t
         m = self.model
         segs = getattr(m, 'row_segments', None)
         if segs:     # g of rows the backward did not touch is zero by construction: not read, not re-zeroed
@@ -432,6 +442,7 @@ class DCCF(DMF):
 
     def predict(self, feed_dict):
         """src/models/DCCF.py:66-107.  Fresh candidates and noise on every call, also in eval mode, as in the reference."""
+        self._flush()
         if (self.eval_noise == 'projected' and not self.training and feed_dict.get('inject') is None
                 and getattr(self, '_proj', None) is not None):
             pred = _lib.dccf_predict_projected(self.ctx, self._struct(), self._rand(feed_dict), feed_dict['X'].contiguous(),
@@ -445,6 +456,7 @@ class DCCF(DMF):
         """src/models/DCCF.py:109-127 (+ the backward of the loss term when training)."""
         if not self.training:
             return self.predict(feed_dict)
+        self._flush()
         g = self.grads
         ms = self._struct()
         pred, loss = _lib.dccf_train_fwdbwd(self.ctx, ms, self._rand(feed_dict), feed_dict['X'].contiguous(),
@@ -453,6 +465,32 @@ class DCCF(DMF):
                                             g['mlp.0.bias'], loss=self._loss, touchedU=self.touchedU, touchedV=self.touchedV,
                                             gextra=self._extra(g))
         return {'prediction': pred, 'check': [('prediction', pred)], 'loss': loss[0]}
+
+    lazy_K = int(os.environ.get('DCCF_LAZY_K', '8'))      # window count of the lazy regularisation; 0 = dense pass every step
+
+    def _flush(self):
+        if self.optimizer is not None and getattr(self.optimizer, 'flush', None):
+            self.optimizer.flush()
+
+    def eval(self):
+        self._flush()             # evaluation reads every row
+        return BaseModel.eval(self)
+
+    def state_dict(self):
+        self._flush()
+        return BaseModel.state_dict(self)
+
+    def parameters(self):
+        self._flush()
+        return BaseModel.parameters(self)
+
+    def named_parameters(self):
+        self._flush()
+        return BaseModel.named_parameters(self)
+
+    def l2(self):
+        self._flush()
+        return BaseModel.l2(self)
 
     def train_step(self, feed_dict, overlap=0, X_next=None):
         """zero_grad + forward + backward + `+ l2` + clip + optimizer.step() of src/runners/BaseRunner.py:172-188 as ONE
@@ -463,11 +501,23 @@ class DCCF(DMF):
         o = self.optimizer
         key = (o.name, o.lr, o.l2, o.clip, int(overlap))
         if getattr(self, '_opt_struct_key', None) != key:
+            o.flush()
             self._opt_struct = _lib.opt_struct(o.name, self.flat_p, self.flat_g, o.s1, o.s2, o.lr, o.l2, o.l2, o.clip,
                                                self.row_segments, overlap)
             self._opt_struct_key = key
+            o.lazy = None
+            if self.lazy_K > 0 and not overlap and self.row_segments and feed_dict.get('inject') is None:
+                # windowed lazy regularisation: only 1 / lazy_K of the untouched rows is streamed per step (dccf_opt_t.lazy_*)
+                rows = self.user_num + self.item_num
+                o.lazy = _lib.LazyState(self._opt_struct, self.lazy_K, rows, 16 + 4 * 16384 * (self.sample_num + 2), o.lr, self.device)
+                o.lazy.sync_all(o.t)
         g = self.grads
         o.t += 1
+        if o.lazy is not None:
+            if feed_dict['X'].shape[0] * (self.sample_num + 2) > o.lazy.list.numel():
+                raise RuntimeError('batch too large for the lazy optimizer row list')
+            o.lazy.cover(o.t)
+            o.lazy.dirty = True
         rs = self._rand(feed_dict)
         if X_next is not None and (overlap or feed_dict.get('inject') is not None or not X_next.is_contiguous()):
             X_next = None
@@ -490,6 +540,8 @@ class StepGraph(object):
 
     def __init__(self, model, opt, nb, rows, dropout):
         self.model, self.opt, self.nb, self.rows, self.dropout = model, opt, nb, rows, dropout
+        opt.flush()                      # (rows a lazy train_step left behind; the graph replays the dense pass)
+        opt.lazy, model._opt_struct_key = None, None
         dev = model.device
         self.k = torch.zeros(1, dtype=torch.int64, device=dev)
         self.k_host = 0

@@ -272,7 +272,7 @@ def bench_main(args, rank, world, dev):
     tr = ShardedDCCF(rank, world, U, I, D, S, A, 0.1, 0.2, 1e-3, 1e-4, args.seed, be, dev, feat, ips)
     tr.init_params()
     from bench import synthetic_interactions
-    n_steps = args.steps + args.warmup
+    n_steps = max(args.steps, args.warmup) + args.warmup
     n_pairs = (n_steps + 2) * B * world
     uid, iid = synthetic_interactions(int(n_pairs * 1.15) + 1000, U, I, args.seed)      # replicated train set
     ds = DeviceTrainSet(uid[:n_pairs], iid[:n_pairs], U, I, args.seed)
@@ -282,7 +282,8 @@ def bench_main(args, rank, world, dev):
         nb = full.shape[0] // world
         return full[:nb * world].view(nb, world, 2 * B, 2)     # step k: rank r trains full[k*world + r]
 
-    tr.begin_epoch(schedule(0)[:args.warmup], 0)
+    # (the warm-up epoch's plan has the timed epoch's size: the routing tables of the timed one then reuse its allocations)
+    tr.begin_epoch(schedule(0)[:max(args.warmup, args.steps)], 0)
     for k in range(args.warmup):
         tr.train_step(k)
     torch.cuda.synchronize()

@@ -181,7 +181,34 @@ typedef struct {
   const int64_t* seg_rows;
   const int32_t* seg_width;
   uint8_t* const* seg_flags;
+  /* ---- windowed lazy regularisation (dccf_train_step only; lazy_K == 0: every launch is the dense pass) ----------------
+   * A row the batch does not touch sees the l2 term alone: its update at step t is a function of its own (p, m, v) and of
+   * t.  With lazy_K = K > 0 the optimizer launch of step t therefore updates only (a) the rows the step touched, (b) W, b
+   * and (c) ONE K-th of the untouched rows, which it advances by all the steps they are behind (<= K, replayed in registers
+   * in the dense pass's exact operation order: bit-identical results) — 24 B/param/step of HBM traffic become 24/K, and the
+   * launch is bound by the arithmetic of the replay instead.  A row about to be used is first brought up to step t - 1
+   * (k_lazy_catchup, before the forward).  dccf_lazy_flush brings every row up to date (before evaluation, checkpoints, l2,
+   * or any dense call).  All arrays are the caller's, in HBM:
+   *   lazy_last  int32 [rows of all segments, segment after segment]: steps applied to the row so far
+   *   lazy_claim int32 [same]: the last step that used the row (0-initialised)
+   *   lazy_list  int32 [>= N (S + 2)]: the rows of the running step, one entry per (row of X, candidate) slot and per user slot,
+ *              -1 where another slot owns the row (lazy_cnt: reserved, may be NULL)
+   *   lazy_scal  float [2 * lazy_nscal]: (-(lr / (1 - 0.9^s)), sqrt(1 - 0.999^s)) for s = lazy_t0 .. lazy_t0 + lazy_nscal - 1,
+   *              as dccf_lazy_scalars writes them (the same double arithmetic as the dense launch); must cover
+   *              [step - lazy_K, step] */
+  int32_t lazy_K;
+  int32_t lazy_nscal;
+  int32_t* lazy_last;
+  int32_t* lazy_claim;
+  int32_t* lazy_list;
+  int32_t* lazy_cnt;
+  const float* lazy_scal;
+  int64_t lazy_t0;
 } dccf_opt_t;
+/* HOST: out[2 i], out[2 i + 1] = the Adam step scalars of step t0 + i (see lazy_scal), i < n. */
+int dccf_lazy_scalars(float lr, int64_t t0, int32_t n, float* out_host);
+/* Brings every row of the segments up to opt->step (rows already there are untouched).  Needs lazy_K > 0. */
+int dccf_lazy_flush(const dccf_opt_t* opt, void* stream);
 /* The context's side stream (hipStream_t): least priority, or confined to the first n CUs when the environment variable
  * DCCF_SIDE_CUS=n is set at its creation (the mask interleaves over the 8 XCDs).  For callers that run
  * dccf_dense_opt_phase(1) beside other work themselves (dccf_amd/replicated.py). */

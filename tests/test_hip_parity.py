@@ -559,8 +559,9 @@ def test_tables_beyond_2g_elements_equal_compact_tables(L):
         for k in range(2):
             out = m.train_step({'X': Xs[k], 'Y': y, 'rank': 1, 'train': True, 'dropout': 0.2}, X_next=Xs[k + 1] if k == 0 else None)
             preds.append(out['prediction'].clone())
+        m.optimizer.flush()       # the views in P were taken before training: bring the rows the lazy regularisation left behind
         torch.cuda.synchronize()
-        assert m.ctx.prepared_steps() == 1
+        assert m.ctx.prepared_steps() == 1 and m.optimizer.lazy is not None and not m.optimizer.lazy.dirty
         Uw = P['uid_embeddings.weight'].detach()
         res.append((Uw[uniq].clone() if mode == 'big' else Uw.clone(), P['iid_embeddings.weight'].detach().clone(),
                     P['mlp.0.weight'].detach().clone(), P['mlp.0.bias'].detach().clone(), preds))
@@ -700,6 +701,7 @@ def test_graph_replayed_steps_equal_eager_steps(L):
                 m({'X': T(tail_np), 'Y': torch.cat([y[:3], y[B:B + 3]]), 'rank': 1, 'train': True, 'dropout': 0.2})
                 opt.step()
         assert m._call == 2 * (nb + 1) and opt.t == 2 * (nb + 1)
+        m.optimizer.flush()       # (rows the lazy regularisation left behind)
         results.append(m.flat_p.cpu().numpy().copy())
     # float atomics reorder sums inside the backward; Adam turns that into <= a fraction of one step (see STEP_FRAC)
     close(results[1], results[0], PARAM_RTOL, PARAM_ATOL + STEP_FRAC * 1e-3, 'graph vs eager parameters')
@@ -757,13 +759,17 @@ def test_overlapped_train_step_equals_split_step(L, opt_name, B, l2, D, NL):
     full = torch.stack([torch.stack([torch.randint(0, U // 2 if k % 2 else 40, (2 * B,), generator=gen, device='cuda'),
                                      torch.randint(0, I, (2 * B,), generator=gen, device='cuda')], 1) for k in range(6)])
     tile = D in (16, 32, 64, 128)       # other widths have no row segments: the overlapped forms do not apply
-    for mode in ('split', 'step', 'overlap', 'prep', 'hosted') if tile else ('split', 'step', 'prep'):
+    # 'step' / 'prep' run with the windowed lazy regularisation (DCCF.lazy_K = 16 by default: 6 steps never complete a cycle of
+    # windows, so most rows are brought up to date by the flush); 'dense' / 'denseprep' are the same calls with lazy_K = 0;
+    # 'lazy3' cycles the windows twice
+    for mode in ('split', 'step', 'overlap', 'prep', 'hosted', 'dense', 'denseprep', 'lazy3') if tile else ('split', 'step', 'prep'):
         m = DCCF(path=None, dataset=None, sentence_model=None, sample_num=10, attribute_num=2, std=0.1, label_min=0, label_max=1,
                  feature_num=0, user_num=U, item_num=I, u_vector_size=D, i_vector_size=D, n_layers=NL, random_seed=11,
                  model_path='/tmp/x.pt', feature_embedding=feat, expo_prob=expo)
         torch.manual_seed(3)
         m.apply(m.init_paras)
         m.optimizer = FusedOptimizer(m, opt_name, 0.01, l2)
+        m.lazy_K = {'dense': 0, 'denseprep': 0, 'lazy3': 3}.get(mode, 16)
         m.train()
         y = torch.cat([torch.ones(B, device='cuda'), torch.zeros(B, device='cuda')])
         preds = []
@@ -775,13 +781,19 @@ def test_overlapped_train_step_equals_split_step(L, opt_name, B, l2, D, NL):
             if mode == 'split':
                 out = m(batch)
                 m.optimizer.step()
-            elif mode == 'prep':      # the optimizer launch of step k draws step k + 1's candidates and writes W^T
+            elif mode in ('prep', 'denseprep', 'lazy3'):      # the optimizer launch of step k draws step k + 1's candidates and writes W^T
                 out = m.train_step(batch, X_next=full[k + 1] if k < 5 else None)
             else:
-                out = m.train_step(batch, overlap={'step': 0, 'overlap': 1, 'hosted': 2}[mode])
+                out = m.train_step(batch, overlap={'overlap': 1, 'hosted': 2}.get(mode, 0))
             preds.append(out['prediction'].clone())
+        lazy_on = tile and mode in ('step', 'prep', 'lazy3')
+        assert (m.optimizer.lazy is not None) == lazy_on
+        if lazy_on:       # rows are behind until the flush (model.eval() / state_dict() / l2() / any dense call do it)
+            assert m.optimizer.lazy.dirty and int(m.optimizer.lazy.last.min()) < 6
+            m.eval()
+            assert not m.optimizer.lazy.dirty and int(m.optimizer.lazy.last.min()) == 6 and int(m.optimizer.lazy.cnt) == 0
         torch.cuda.synchronize()
-        assert m.ctx.prepared_steps() == (5 if mode == 'prep' else 0)
+        assert m.ctx.prepared_steps() == (5 if mode in ('prep', 'denseprep', 'lazy3') else 0)
         assert not tile or (int(m.touchedU.sum()) == 0 and int(m.touchedV.sum()) == 0)
         assert float(m.flat_g.abs().max()) == 0.0
         assert len(m.state_dict()) == 2 + 2 * NL
@@ -852,6 +864,7 @@ def test_prepared_state_survives_nothing_it_should_not(L):
             # 0->1 broken by the predict; 1->2 holds; 2->3 followed by the tail batch instead; 3->4 followed by batch 5
             # instead; 5->1 broken by the predict; 4->0 holds
             assert m.ctx.prepared_steps() == 2
+        m.optimizer.flush()       # (rows the lazy regularisation left behind)
         states.append((m.flat_p.clone(), preds))
     a, b = states
     close(b[0], a[0].cpu().numpy(), 0, 2e-7, 'parameters after the scripted sequence')
@@ -928,6 +941,7 @@ def test_mf_row_aware_optimizer_equals_dense(L, D):
         assert float(m.flat_g.abs().max()) == 0.0
         if m.touchedP is not None:
             assert int(m.touchedP.sum()) == 0 and int(m.touchedQ.sum()) == 0
+        m.optimizer.flush()
         runs.append(m.flat_p.clone())
     d = (runs[0] - runs[1]).abs()
     assert float(d.max()) <= 5 * 0.01 and int((d > 5 * STEP_FRAC * 0.01).sum()) <= 4 * D + 8
