@@ -335,7 +335,7 @@ class LazyState(object):
         self.last = torch.zeros(n_rows, dtype=torch.int32, device=device)
         self.claim = torch.zeros(n_rows, dtype=torch.int32, device=device)
         self.list = torch.zeros(list_cap, dtype=torch.int32, device=device)
-        self.cnt = torch.zeros(1, dtype=torch.int32, device=device)
+        self.cnt = torch.zeros(16, dtype=torch.int32, device=device)      # the pending-window records (include/dccf_hip.h)
         self.scal = torch.zeros(2 * self.NSCAL, dtype=torch.float32, device=device)
         self.t0 = -1
         self.dirty = False          # True while some row may be behind opt.step

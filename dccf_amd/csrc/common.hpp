@@ -69,7 +69,6 @@ struct dccf_ctx {
   uint8_t* hv_flags[2];
   int64_t hv_items;
   int hv_parity, hv_prepared;
-  int lazy_hosted;           // the running step's lazy window was hosted in the backward launch
   int64_t last_hosted_rows;  // item rows whose untouched-row pass the last training call hosted in its backward launch
   const void* prep_Xall;
   int64_t prep_N;
@@ -121,8 +120,7 @@ int dccf_opt_untouched_prep(const void* o, uint8_t* const* flags, const PrepNext
 // windowed lazy regularisation (dccf_opt_t.lazy_K > 0): the rows of the running step (X, cand, first global row of the user /
 // item segment) are claimed, listed and brought up to step - 1; then the step's optimizer launch
 int dccf_lazy_catchup(const void* o, const int64_t* X, const int* cand, int64_t N, int S1, int segU, int segV, hipStream_t st);
-int dccf_lazy_step(const void* o, const PrepNext* pn, int64_t nslots, int hosted, hipStream_t st);      // nslots = N (S + 2) of the catch-up;
-                                                                   // hosted: the window ran inside the backward launch
+int dccf_lazy_step(const void* o, const PrepNext* pn, int64_t nslots, hipStream_t st);      // nslots = N (S + 2) of the catch-up
 // dccf_kernels.hip: workspace pointers / key of the step (X_next, N, step_next) into pn (w_begin / w_end / blocks and the
 // dp fields are the caller's); and the record that makes the next matching call skip k_prep
 int dccf_prep_next_fill(dccf_ctx* ctx, const dccf_model_t* M, int64_t N, const int64_t* X_next, uint64_t seed, uint64_t step_next,

@@ -1219,7 +1219,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
   }
   if (N == 0) {
     if (train) HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), st));
-    if (plan && plan->lazy_segU >= 0) return dccf_lazy_step(plan->opt, nullptr, 0, 0, st);
+    if (plan && plan->lazy_segU >= 0) return dccf_lazy_step(plan->opt, nullptr, 0, st);
     if (plan) return dccf_opt_phase(plan->opt, OPT_PHASE_ALL, nullptr, nullptr, 0, st);
     return 0;
   }
@@ -1253,7 +1253,6 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
   const bool prepared = train && !(plan && plan->overlap) && dccf_prep_matches(ctx, M, rnd, X, N);
   // hosted item table (dccf_train_step, no other overlap mode): two sets of "item row touched" bytes owned by the context
   const bool lazy = plan && train && plan->lazy_segU >= 0;
-  ctx->lazy_hosted = 0;
   const bool hostv = plan && !plan->overlap && plan->hostv_seg >= 0 && train && !lazy;
   if (hostv) {
     const int64_t nb = (M->item_num + 3) / 4 * 4;
@@ -1482,10 +1481,10 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
         pn.w_begin = M->W - plan->opt->p;
         pn.w_end = pn.w_begin + (int64_t)D * (D + F);
         pn.blocks = (int)min((int64_t)64, (y.NS + pn.Lm + 255) / 256);
-        if (int e = dccf_lazy_step(plan->opt, &pn, N * (int64_t)(S1 + 1), ctx->lazy_hosted, st)) return e;
+        if (int e = dccf_lazy_step(plan->opt, &pn, N * (int64_t)(S1 + 1), st)) return e;
         dccf_prep_next_commit(ctx, M, N, plan->X_next, rnd->seed, plan->step_next);
       } else {
-        if (int e = dccf_lazy_step(plan->opt, nullptr, N * (int64_t)(S1 + 1), ctx->lazy_hosted, st)) return e;
+        if (int e = dccf_lazy_step(plan->opt, nullptr, N * (int64_t)(S1 + 1), st)) return e;
       }
     } else if (plan->overlap) {
       if (!plan->hosted) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));

@@ -127,10 +127,31 @@ struct LazyArgs {
   int* claim;
   int* list;
   int* cnt;
+  int pend_slot;             // which record of cnt this launch READS: (step - 1) & 1 for a step, step & 1 for a flush
   const float* scal;
   int64_t row_off[4];        // first global row of segment q
   int64_t rows[4];
 };
+
+// The window of the PREVIOUS lazy step is marked one launch late (its rows' `last` entries are written by the next optimizer
+// launch instead of a launch of their own): until then a row of that window that was behind counts as being at that step.
+// z.cnt holds two records {step, w0 lo, w0 hi, w1 lo, w1 hi} by step parity: launch t reads (t - 1) & 1 and writes t & 1.
+struct LazyPend {
+  int t;
+  int64_t w0, w1;
+};
+__device__ __forceinline__ LazyPend lazy_pend_read(const LazyArgs& z) {
+  const int* r = z.cnt + 5 * z.pend_slot;
+  LazyPend q;
+  q.t = r[0];
+  q.w0 = (int64_t)(uint32_t)r[1] | ((int64_t)r[2] << 32);
+  q.w1 = (int64_t)(uint32_t)r[3] | ((int64_t)r[4] << 32);
+  return q;
+}
+__device__ __forceinline__ int lazy_eff_last(const LazyArgs& z, const LazyPend& q, int64_t grow) {
+  const int f = z.last[grow];
+  return (grow >= q.w0 && grow < q.w1 && f < q.t) ? q.t : f;
+}
 
 // `steps` optimizer steps with a zero loss gradient on one element, starting after step `from`: exactly what the dense pass
 // would have done to it launch by launch
@@ -170,6 +191,7 @@ __device__ __forceinline__ void lazy_window_pass(float* __restrict__ p, float* _
                                                  const OptArgs& a, const RowSegs& sg, const LazyArgs& z, int64_t win0, int64_t win1,
                                                  int flush, int64_t bid, int64_t nblk, int nthreads) {
   const int t = (int)z.step;
+  const LazyPend pend = lazy_pend_read(z);
   for (int q = 0; q < sg.n; ++q) {
     const int64_t r0 = max(win0, z.row_off[q]) - z.row_off[q], r1 = min(win1, z.row_off[q] + z.rows[q]) - z.row_off[q];
     if (r1 <= r0) continue;
@@ -178,7 +200,7 @@ __device__ __forceinline__ void lazy_window_pass(float* __restrict__ p, float* _
     for (int64_t x = bid * nthreads + threadIdx.x; x < nslot; x += nblk * nthreads) {
       const int64_t row = r0 + x / w4;
       const int64_t grow = z.row_off[q] + row;
-      const int from = z.last[grow];
+      const int from = lazy_eff_last(z, pend, grow);
       // a row this step touched is the list's business (its last is t - 1 until that wave has updated it: never replay it here)
       if (from >= t || (!flush && z.claim[grow] == t)) continue;
       const int64_t i = (sg.begin[q] >> 2) + row * w4 + x % w4;
@@ -199,4 +221,3 @@ int opt_make_job(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t
                  int64_t step, const int64_t* k_dev, int32_t nseg, const int64_t* seg_begin, const int64_t* seg_rows,
                  const int32_t* seg_width, uint8_t* const* seg_flags, OptJob* out);
 
-int dccf_lazy_window_job(const void* ov, OptJob* j, LazyArgs* z, int64_t* win0, int64_t* win1);

@@ -582,7 +582,8 @@ __global__ __launch_bounds__(256) void k_lazy_catchup(float* __restrict__ p, flo
     }                                          // counter — 3,000 appends to one address took 40 us
     won = __shfl(won, 0, 64);
     if (!won) continue;
-    const int from = __builtin_amdgcn_readfirstlane(z.last[grow]);      // (uniform: the scalar table is then read by scalar loads)
+    const LazyPend pend = lazy_pend_read(z);
+    const int from = __builtin_amdgcn_readfirstlane(lazy_eff_last(z, pend, grow));      // (uniform: scalar loads of the table)
     if (from >= t - 1) continue;
     const int w = sg.width[q];
     float* pr = p + sg.begin[q] + row * w;
@@ -666,9 +667,16 @@ __global__ __launch_bounds__(256) void k_lazy_opt(float* __restrict__ p, float* 
     return;
   }
   bid -= wb;
-  // ---- hosted window: it ran inside the backward launch, which has completed — its rows are at step t now
-  for (int64_t r = win0 + (int64_t)bid * blockDim.x + threadIdx.x; r < win1; r += (int64_t)mb * blockDim.x)
-    if (z.last[r] < t && z.claim[r] != t) z.last[r] = t;
+  // ---- the PREVIOUS lazy step's window gets its marks now (that launch is complete), and this launch's window is recorded
+  const LazyPend pend = lazy_pend_read(z);
+  for (int64_t r = pend.w0 + (int64_t)bid * blockDim.x + threadIdx.x; r < pend.w1; r += (int64_t)mb * blockDim.x)
+    if (z.last[r] < pend.t && z.claim[r] != t) z.last[r] = pend.t;
+  if (bid == 0 && threadIdx.x == 0) {
+    int* w = z.cnt + 5 * (t & 1);
+    w[0] = t;
+    w[1] = (int)(uint32_t)win0; w[2] = (int)(win0 >> 32);
+    w[3] = (int)(uint32_t)win1; w[4] = (int)(win1 >> 32);
+  }
 }
 
 // last[row] = t for the rows of the window, after k_lazy_opt (every lane of a row must have read the old value first)
@@ -676,15 +684,17 @@ __global__ __launch_bounds__(256) void k_lazy_mark(LazyArgs z, int64_t win0, int
   const int t = (int)z.step;
   for (int64_t r = win0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < win1; r += (int64_t)gridDim.x * blockDim.x)
     if (z.last[r] < t && (flush || z.claim[r] != t)) z.last[r] = t;
+  if (blockIdx.x == 0 && threadIdx.x < 10) z.cnt[threadIdx.x] = threadIdx.x % 5 == 0 ? -1 : 0;      // nothing is pending after a flush
 }
 
 static int lazy_args(const dccf_opt_t* o, const OptJob& j, LazyArgs* z) {
-  ARG_CHECK(o->lazy_K > 0 && o->lazy_last && o->lazy_claim && o->lazy_list, "lazy optimizer: missing arrays");
+  ARG_CHECK(o->lazy_K >= 2 && o->lazy_last && o->lazy_claim && o->lazy_list && o->lazy_cnt, "lazy optimizer: lazy_K >= 2 and all arrays");
   ARG_CHECK(j.sg.n >= 1, "lazy optimizer needs row segments");
   ARG_CHECK(o->kind != DCCF_OPT_ADAM || (o->lazy_scal && o->lazy_t0 <= max((int64_t)1, o->step - o->lazy_K + 1) &&
                                          o->step < o->lazy_t0 + o->lazy_nscal),
             "lazy optimizer: the step-scalar table does not cover [step - K + 1, step]");
   z->K = o->lazy_K; z->nscal = o->lazy_nscal; z->t0 = o->lazy_t0; z->step = o->step;
+  z->pend_slot = (int)((o->step - 1) & 1);
   z->last = o->lazy_last; z->claim = o->lazy_claim; z->list = o->lazy_list; z->cnt = o->lazy_cnt; z->scal = o->lazy_scal;
   int64_t off = 0;
   for (int q = 0; q < 4; ++q) {
@@ -722,9 +732,7 @@ int dccf_lazy_catchup(const void* ov, const int64_t* X, const int* cand, int64_t
   return 0;
 }
 
-// hosted: the window pass of this step already ran as extra workgroups of the backward launch (dccf_lazy_window_job): this
-// launch then only marks its rows
-static int lazy_launch(const dccf_opt_t* o, int flush, const PrepNext* pnp, int64_t nslots, hipStream_t st, bool hosted = false) {
+static int lazy_launch(const dccf_opt_t* o, int flush, const PrepNext* pnp, int64_t nslots, hipStream_t st) {
   OptJob j;
   if (int e = opt_job(o, &j)) return e;
   LazyArgs z;
@@ -732,6 +740,7 @@ static int lazy_launch(const dccf_opt_t* o, int flush, const PrepNext* pnp, int6
   DenseSegs ds;
   int64_t dense_total = 0;
   if (int e = dense_complement(j.sg, j.n, &ds, &dense_total)) return e;
+  if (flush) z.pend_slot = (int)(o->step & 1);       // the window of the step just done
   const int64_t R = z.row_off[3] + z.rows[3];
   const int64_t w = o->step % o->lazy_K;
   const int64_t win0 = flush ? 0 : R * w / o->lazy_K, win1 = flush ? R : R * (w + 1) / o->lazy_K;
@@ -742,32 +751,20 @@ static int lazy_launch(const dccf_opt_t* o, int flush, const PrepNext* pnp, int6
   for (int q = 0; q < j.sg.n; ++q) maxw4 = max(maxw4, j.sg.width[q] >> 2);
   const int lb = (flush || nslots == 0) ? 0 : (int)min((int64_t)256, (nslots + 3) / 4);
   const int db = flush ? 0 : (int)min((int64_t)256, (dense_total + 255) / 256);
-  const int wb = hosted ? 0 : (int)max((int64_t)1, min((int64_t)8192, ((win1 - win0) * maxw4 + 255) / 256));
-  const int mb = hosted ? (int)max((int64_t)1, min((int64_t)64, (win1 - win0 + 255) / 256)) : 0;
+  const int wb = (int)max((int64_t)1, min((int64_t)8192, ((win1 - win0) * maxw4 + 255) / 256));
+  const int mb = flush ? 0 : 32;       // (a flush marks with a launch of its own: every row, and nothing stays pending)
   const int grid = pn.blocks + lb + db + wb + mb;
   BY_KIND(j.kind, k_lazy_opt, dim3(grid), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.a, j.sg, ds, z, lb, db, mb, win0, win1, flush,
           (int)nslots, pn);
-  if (!hosted)
+  if (flush)
     hipLaunchKernelGGL(k_lazy_mark, dim3((unsigned)max((int64_t)1, min((int64_t)1024, (win1 - win0 + 255) / 256))), dim3(256), 0, st, z,
                        win0, win1, flush);
   HIP_TRY(hipGetLastError());
   return 0;
 }
 
-// What a kernel needs to host this step's window pass (k_bwd): the job, the lazy arrays and the window
-int dccf_lazy_window_job(const void* ov, OptJob* j, LazyArgs* z, int64_t* win0, int64_t* win1) {
-  const dccf_opt_t* o = (const dccf_opt_t*)ov;
-  if (int e = opt_job(ov, j)) return e;
-  if (int e = lazy_args(o, *j, z)) return e;
-  const int64_t R = z->row_off[3] + z->rows[3];
-  const int64_t w = o->step % o->lazy_K;
-  *win0 = R * w / o->lazy_K;
-  *win1 = R * (w + 1) / o->lazy_K;
-  return 0;
-}
-
-int dccf_lazy_step(const void* ov, const PrepNext* pn, int64_t nslots, int hosted, hipStream_t st) {
-  return lazy_launch((const dccf_opt_t*)ov, 0, pn, nslots, st, hosted != 0);
+int dccf_lazy_step(const void* ov, const PrepNext* pn, int64_t nslots, hipStream_t st) {
+  return lazy_launch((const dccf_opt_t*)ov, 0, pn, nslots, st);
 }
 
 extern "C" int dccf_lazy_flush(const dccf_opt_t* opt, void* stream) {

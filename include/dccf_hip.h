@@ -192,7 +192,9 @@ typedef struct {
    *   lazy_last  int32 [rows of all segments, segment after segment]: steps applied to the row so far
    *   lazy_claim int32 [same]: the last step that used the row (0-initialised)
    *   lazy_list  int32 [>= N (S + 2)]: the rows of the running step, one entry per (row of X, candidate) slot and per user slot,
- *              -1 where another slot owns the row (lazy_cnt: reserved, may be NULL)
+ *              -1 where another slot owns the row
+ *   lazy_cnt   int32 [16], zero-initialised: the window whose marks are pending (a step's window is marked by the NEXT
+ *              optimizer launch instead of a launch of its own), two records by step parity
    *   lazy_scal  float [2 * lazy_nscal]: (-(lr / (1 - 0.9^s)), sqrt(1 - 0.999^s)) for s = lazy_t0 .. lazy_t0 + lazy_nscal - 1,
    *              as dccf_lazy_scalars writes them (the same double arithmetic as the dense launch); must cover
    *              [step - lazy_K, step] */

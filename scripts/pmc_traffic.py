@@ -16,7 +16,8 @@ import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NAMES = {'k_prep': 'prep', 'k_noise_fwd': 'noise_fwd', 'k_pair_epilogue': 'pair_epilogue', 'k_bwd': 'noise_bwd_eps',
-         'k_dense_opt_rows': 'dense_adam', 'k_dense_opt_rows_beyond_llc': 'dense_adam_beyond_llc (268 M parameters)'}
+         'k_dense_opt_rows': 'dense_adam', 'k_dense_opt_rows_beyond_llc': 'dense_adam_beyond_llc (268 M parameters)',
+         'k_lazy_opt': 'lazy_opt (K = 8)', 'k_lazy_catchup': 'lazy_catchup', 'k_lazy_mark': 'lazy_mark'}
 
 
 N_PARAMS = None

@@ -791,7 +791,7 @@ def test_overlapped_train_step_equals_split_step(L, opt_name, B, l2, D, NL):
         if lazy_on:       # rows are behind until the flush (model.eval() / state_dict() / l2() / any dense call do it)
             assert m.optimizer.lazy.dirty and int(m.optimizer.lazy.last.min()) < 6
             m.eval()
-            assert not m.optimizer.lazy.dirty and int(m.optimizer.lazy.last.min()) == 6 and int(m.optimizer.lazy.cnt) == 0
+            assert not m.optimizer.lazy.dirty and int(m.optimizer.lazy.last.min()) == 6 and int(m.optimizer.lazy.last.max()) == 6
         torch.cuda.synchronize()
         assert m.ctx.prepared_steps() == (5 if mode in ('prep', 'denseprep', 'lazy3') else 0)
         assert not tile or (int(m.touchedU.sum()) == 0 and int(m.touchedV.sum()) == 0)
@@ -1018,3 +1018,62 @@ def test_projected_eval_tables_and_distribution(L, ctx, D, F):
     # with dropout the projected path still runs and stays finite
     pd_ = L.dccf_predict_projected(ctx, m, L.rand_struct(seed=3, step=2), X[:257], 0.2, Pf, Lt)
     assert bool(torch.isfinite(pd_).all())
+
+
+@pytest.mark.parametrize('K,opt_name', [(2, 'adam'), (5, 'adam'), (7, 'adagrad'), (3, 'gd')])
+def test_lazy_regularisation_equals_dense_pass(L, K, opt_name):
+    """Windowed lazy regularisation (dccf_opt_t.lazy_*): 41 steps with the window cycling many times, a predict in the middle
+    (flush), a tail batch of another size and a step that is not announced — against the same calls with the dense pass
+    (lazy_K = 0).  Rows no batch ever touched must be BIT-IDENTICAL (their updates are the same operations in the same order,
+    applied K at a time); the rest agrees to the float-atomic tolerance of any two runs."""
+    from dccf_amd.models import DCCF, FusedOptimizer
+    U, I, D, F, B = 1501, 977, 64, 96, 48
+    g = torch.Generator(device='cuda').manual_seed(5)
+    feat = torch.randn(I, F, generator=g, device='cuda') * 0.05
+    expo = torch.randn(U, I, generator=g, device='cuda')
+    gen = torch.Generator(device='cuda').manual_seed(9)
+    nst = 41
+    # users from the first 300 only, so that most user rows are never touched; items from everywhere
+    full = torch.stack([torch.stack([torch.randint(0, 300, (2 * B,), generator=gen, device='cuda'),
+                                     torch.randint(0, I, (2 * B,), generator=gen, device='cuda')], 1) for _ in range(nst)])
+    tail = torch.stack([torch.randint(0, 300, (2 * 7,), generator=gen, device='cuda'),
+                        torch.randint(0, I, (2 * 7,), generator=gen, device='cuda')], 1)
+    y = torch.cat([torch.ones(B, device='cuda'), torch.zeros(B, device='cuda')])
+    res = []
+    for lazy_K in (0, K):
+        m = DCCF(path=None, dataset=None, sentence_model=None, sample_num=10, attribute_num=2, std=0.1, label_min=0, label_max=1,
+                 feature_num=0, user_num=U, item_num=I, u_vector_size=D, i_vector_size=D, n_layers=1, random_seed=11,
+                 model_path='/tmp/x.pt', feature_embedding=feat, expo_prob=expo)
+        torch.manual_seed(3)
+        m.apply(m.init_paras)
+        m.optimizer = FusedOptimizer(m, opt_name, 0.01, 1e-3)
+        m.lazy_K = lazy_K
+        m.train()
+        mid = None
+        for k in range(nst):
+            batch = {'X': full[k], 'Y': y, 'rank': 1, 'train': True, 'dropout': 0.2}
+            m.train_step(batch, X_next=full[k + 1] if k + 1 < nst and k % 9 != 4 else None)       # every 9th step unannounced
+            if k == 17:       # evaluation in the middle of an epoch: everything must be current for it
+                m.eval()
+                mid = m.predict({'X': full[0][:16].contiguous(), 'dropout': 0.0})['prediction'].clone()
+                m.train()
+            if k == 29:
+                m.train_step({'X': tail, 'Y': torch.cat([y[:7], y[B:B + 7]]), 'rank': 1, 'train': True, 'dropout': 0.2})
+        assert (m.optimizer.lazy is not None) == (lazy_K > 0)
+        sd = m.state_dict()             # flushes
+        assert m.optimizer.lazy is None or (not m.optimizer.lazy.dirty and int(m.optimizer.lazy.last.min()) == m.optimizer.t == nst + 1)
+        res.append((sd, m.optimizer.s1.clone() if m.optimizer.s1 is not None else None, mid, m))
+    (a, a1, amid, ma), (b, b1, bmid, mb) = res
+    never_u = torch.ones(U, dtype=torch.bool, device='cuda')
+    never_u[:300] = False
+    assert torch.equal(a['uid_embeddings.weight'][never_u], b['uid_embeddings.weight'][never_u])
+    if a1 is not None:
+        assert torch.equal(a1[:U * D].view(U, D)[never_u], b1[:U * D].view(U, D)[never_u])
+    lr, steps = 0.01, nst + 1
+    for k in a:
+        d = (a[k] - b[k]).abs()
+        if opt_name == 'gd':
+            assert float(d.max()) <= 2e-6, (k, float(d.max()))
+        else:       # Adam / Adagrad turn the last-bit differences of float-atomic sums into fractions of lr on a few elements
+            assert float(d.max()) <= steps * lr and float((d > steps * 5e-3 * lr).float().mean()) <= 0.02, (k, float(d.max()))
+    close(bmid, amid.cpu().numpy(), 2e-3 if opt_name != 'gd' else 1e-5, 1e-5, 'mid-epoch evaluation')
