@@ -243,6 +243,11 @@ def gen_dccf(outdir, cases=None):
             rec['eval/noise'] = t2n(CAP.noise[0])
             rec['eval/prediction'] = t2n(pe)
             np.savez_compressed(os.path.join(outdir, name + '.npz'), **rec)
+            if len(case) > 17 and case[17]:
+                # a checkpoint written by the reference's own save_model (src/models/BaseModel.py:224-236) after the steps above:
+                # the .pt interchange fixture (tests/test_hip_parity.py::test_reference_checkpoint_loads)
+                model.model_path = os.path.join(outdir, name + '.pt')
+                model.save_model()
             print('wrote', name, 'loss', [float(rec['s%d/loss' % s]) for s in range(steps)])
         finally:
             shutil.rmtree(tmp)
@@ -256,7 +261,7 @@ def gen_dccf_ext(outdir):
     gen_dccf(outdir, cases=[
         # name, U, I, D, F, pairs, S, A, std, dropout, optimizer, lr, l2, steps, rank, init_scale, n_layers
         ('dccf_d64_f768_l2_adam', 50, 40, 64, 768, 4, 10, 2, 0.1, 0.2, 'Adam', 0.001, 1e-4, 3, 1, 8.0, 2),
-        ('dccf_d24_f100_l3_adagrad', 40, 30, 24, 100, 5, 6, 2, 0.2, 0.3, 'Adagrad', 0.01, 1e-3, 2, 1, 25.0, 3),
+        ('dccf_d24_f100_l3_adagrad', 40, 30, 24, 100, 5, 6, 2, 0.2, 0.3, 'Adagrad', 0.01, 1e-3, 2, 1, 25.0, 3, True),
         ('dccf_d48_f1024_adam', 30, 35, 48, 1024, 3, 10, 2, 0.1, 0.2, 'Adam', 0.001, 1e-4, 2, 1, 10.0, 1),
         ('dccf_d100_f800_gd', 20, 25, 100, 800, 2, 10, 2, 0.1, 0.2, 'GD', 0.01, 1e-4, 2, 0, 10.0, 1),
         ('dccf_d128_f32_l2_mse', 20, 25, 128, 32, 3, 4, 3, 0.1, 0.2, 'Adam', 0.001, 1e-4, 2, 0, 20.0, 2),

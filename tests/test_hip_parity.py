@@ -1077,3 +1077,28 @@ def test_lazy_regularisation_equals_dense_pass(L, K, opt_name):
         else:       # Adam / Adagrad turn the last-bit differences of float-atomic sums into fractions of lr on a few elements
             assert float(d.max()) <= steps * lr and float((d > steps * 5e-3 * lr).float().mean()) <= 0.02, (k, float(d.max()))
     close(bmid, amid.cpu().numpy(), 2e-3 if opt_name != 'gd' else 1e-5, 1e-5, 'mid-epoch evaluation')
+
+
+def test_reference_checkpoint_loads(L):
+    """A .pt written by the REFERENCE's save_model (tests/golden/dccf_d24_f100_l3_adagrad.pt, src/models/BaseModel.py:224-236)
+    loads into this build's DCCF (same state_dict keys and shapes: 3 mlp layers, D = 24) and predicts the reference's own
+    evaluation output on the captured draws; and what this build saves, torch loads back with the same keys."""
+    import os
+    from conftest import GOLDEN
+    from dccf_amd.models import DCCF
+    g = load_golden('dccf_d24_f100_l3_adagrad')
+    m = DCCF(path=None, dataset=None, sentence_model=None, sample_num=int(g['S']), attribute_num=int(g['A']), std=float(g['std']),
+             label_min=0, label_max=1, feature_num=0, user_num=int(g['U']), item_num=int(g['I']), u_vector_size=int(g['D']),
+             i_vector_size=int(g['D']), n_layers=int(g['n_layers']), random_seed=1, model_path=os.path.join(GOLDEN, 'dccf_d24_f100_l3_adagrad.pt'),
+             feature_embedding=T(g['feat']), expo_prob=T(g['expo']))
+    m.load_model()
+    out = m.predict({'X': T(g['eval/X']), 'dropout': 0.0,
+                     'inject': {'sample_item': T(g['eval/sample_item']), 'noise': T(g['eval/noise'])}})['prediction']
+    close(out, g['eval/prediction'], FWD_RTOL, FWD_ATOL, 'prediction from the reference checkpoint')
+    path = '/tmp/dccf_mine_l3.pt'
+    m.save_model(path)
+    sd = torch.load(path, map_location='cpu')
+    assert list(sd.keys()) == pkeys(g)
+    last = 's%d/after/' % (int(g['steps']) - 1)
+    for k in sd:
+        assert np.array_equal(sd[k].numpy(), g[last + k])

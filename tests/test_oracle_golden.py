@@ -208,3 +208,19 @@ def test_eval_negatives_oracle_properties():
     cand = np.stack([PH.mulhi(x, I_) for x in xs], axis=1).reshape(-1)
     first = next(int(c) for c in cand if int(c) not in set(hist[0].tolist()))
     assert a[0][0] == first
+
+
+def test_reference_checkpoint_fixture_matches_golden_parameters():
+    """tests/golden/dccf_d24_f100_l3_adagrad.pt was written by the reference's own BaseModel.save_model (src/models/BaseModel.py:
+    224-236) after the golden's training steps: its keys, order, shapes and values are the golden's last `after/` parameters."""
+    import os
+    import torch
+    from conftest import GOLDEN
+    g = load_golden('dccf_d24_f100_l3_adagrad')
+    sd = torch.load(os.path.join(GOLDEN, 'dccf_d24_f100_l3_adagrad.pt'), map_location='cpu')
+    keys = pkeys(g)
+    assert list(sd.keys()) == keys == ['uid_embeddings.weight', 'iid_embeddings.weight', 'mlp.0.weight', 'mlp.0.bias',
+                                       'mlp.1.weight', 'mlp.1.bias', 'mlp.2.weight', 'mlp.2.bias']
+    last = 's%d/after/' % (int(g['steps']) - 1)
+    for k in keys:
+        assert np.array_equal(sd[k].numpy(), g[last + k])
