@@ -121,6 +121,11 @@ int dccf_opt_untouched_prep(const void* o, uint8_t* const* flags, const PrepNext
 // item segment) are claimed, listed and brought up to step - 1; then the step's optimizer launch
 int dccf_lazy_catchup(const void* o, const int64_t* X, const int* cand, int64_t N, int S1, int segU, int segV, hipStream_t st);
 int dccf_lazy_step(const void* o, const PrepNext* pn, int64_t nslots, hipStream_t st);      // nslots = N (S + 2) of the catch-up
+// replicated multi-GPU path (dp_kernels.hip): rows flagged in (flags0, flags1) of segments (seg0, seg1) claimed + caught up;
+// phase 1 = window + marks + next-step preparation; everything brought to step - 1
+int dccf_lazy_catchup_flags(const void* o, const uint8_t* flags0, const uint8_t* flags1, int seg0, int seg1, hipStream_t st);
+int dccf_lazy_phase1(const void* o, const PrepNext* pn, hipStream_t st);
+int dccf_lazy_flush_to_prev(const void* o, hipStream_t st);
 // dccf_kernels.hip: workspace pointers / key of the step (X_next, N, step_next) into pn (w_begin / w_end / blocks and the
 // dp fields are the caller's); and the record that makes the next matching call skip k_prep
 int dccf_prep_next_fill(dccf_ctx* ctx, const dccf_model_t* M, int64_t N, const int64_t* X_next, uint64_t seed, uint64_t step_next,

@@ -352,6 +352,9 @@ struct WMirror {
   // the local send buffer: its rows / dense tail are zeroed once summed (the next backward adds into them)
   float* local_buf;
   int self;
+  // lazy regularisation: the applied rows are at step lazy_t afterwards
+  int* lazy_last;
+  int lazy_t;
 };
 
 template <int APPLY>
@@ -480,6 +483,7 @@ __global__ __launch_bounds__(256) void k_dp_sum_rows(const float* __restrict__ b
     if (sub == 0) {
       sg.flags[q][row] = APPLY < 0 ? 1 : 0;
       mask[gid] = 0u;
+      if (APPLY >= 0 && wm.lazy_last) wm.lazy_last[gid] = wm.lazy_t;
     }
     DPT(5);
   }
@@ -619,6 +623,18 @@ extern "C" int dccf_dp_local(dccf_ctx* ctx, const dccf_model_t* model, const dcc
   if (!prepared) {
     if (int e = dp_discard_prepared(ctx, model, dp, st)) return e;
   }
+  const bool lazy = opt->lazy_K > 0;
+  if (lazy) {
+    ARG_CHECK(X_all != nullptr, "the lazy optimizer needs the replicated schedule (X_all) in every step");
+    // rows ANY rank touches this step: known as bytes when the previous step prepared this one -> claimed and brought up to
+    // step - 1 before the forward reads them; otherwise the whole table is brought up to date first, and the rows are claimed
+    // once the export launch below has marked them
+    if (prepared) {
+      if (int e = dccf_lazy_catchup_flags(opt, dp_gflags(dp, parity, 0), dp_gflags(dp, parity, 1), dp->segU, dp->segV, st)) return e;
+    } else {
+      if (int e = dccf_lazy_flush_to_prev(opt, st)) return e;
+    }
+  }
   ctx->prep_dp = 0;
   ctx->cur_tables = prepared && ctx->prep_tables && dp->ctx == ctx && dp_tables_usable(opt, dp, model);
   ctx->prep_tables = 0;
@@ -677,8 +693,11 @@ extern "C" int dccf_dp_local(dccf_ctx* ctx, const dccf_model_t* model, const dcc
                                  dp_gflags(dp, parity, 1), dp->segU, dp->segV, nullptr, nullptr, nullptr, &mg))
       return e;
   }
-  return dp_export_impl(opt->g, opt->n, opt->nseg, opt->seg_begin, opt->seg_rows, opt->seg_width, opt->seg_flags,
-                        dp->dense_begin, dp->loss, dp->buf, dp->cap, dp->D, 0, X_all ? &mg : nullptr, stream);
+  if (int e = dp_export_impl(opt->g, opt->n, opt->nseg, opt->seg_begin, opt->seg_rows, opt->seg_width, opt->seg_flags,
+                             dp->dense_begin, dp->loss, dp->buf, dp->cap, dp->D, 0, X_all ? &mg : nullptr, stream))
+    return e;
+  if (lazy) return dccf_lazy_catchup_flags(opt, dp_gflags(dp, parity, 0), dp_gflags(dp, parity, 1), dp->segU, dp->segV, st);
+  return 0;
 }
 
 static int dp_global_flags(const dccf_opt_t* opt, const dccf_dp_t* dp, int parity, uint8_t** out) {
@@ -705,6 +724,7 @@ extern "C" int dccf_dp_overlap(const dccf_opt_t* opt, const dccf_dp_t* dp, int32
   ARG_CHECK(opt && dp, "NULL opt / dp");
   uint8_t* gf[4];
   if (int e = dp_global_flags(opt, dp, parity, gf)) return e;
+  if (opt->lazy_K > 0 && !dp_next_usable(opt, dp, next)) return dccf_lazy_phase1(opt, nullptr, (hipStream_t)stream);
   if (!dp_next_usable(opt, dp, next))
     return dccf_dense_opt_phase(opt->kind, opt->p, opt->g, opt->s1, opt->s2, opt->n, opt->lr, opt->wd, opt->l2, opt->clip, opt->step,
                                 opt->nseg, opt->seg_begin, opt->seg_rows, opt->seg_width, gf, 1, nullptr, nullptr, 0, stream);
@@ -741,6 +761,7 @@ extern "C" int dccf_dp_overlap(const dccf_opt_t* opt, const dccf_dp_t* dp, int32
   ctx->prep_dp = 0;
   ctx->prep_pending = 1;             // committed by dccf_dp_finish (W^T is written there)
   ctx->prep_parity = 1 - parity;
+  if (opt->lazy_K > 0) return dccf_lazy_phase1(opt, &pn, (hipStream_t)stream);
   return dccf_opt_untouched_prep(opt, gf, &pn, (hipStream_t)stream);
 }
 
@@ -777,6 +798,10 @@ extern "C" int dccf_dp_finish(const dccf_opt_t* opt, const dccf_dp_t* dp, int32_
     bool scatter = true;
     wm.local_buf = dp->buf;          // rows and dense tail of the send buffer are zero again after every step
     wm.self = dp->rank;
+    if (opt->lazy_K > 0) {
+      wm.lazy_last = opt->lazy_last;
+      wm.lazy_t = (int)opt->step;
+    }
     if (dp->ctx && dp->ctx->cur_tables) {
       dccf_ctx* ctx = dp->ctx;
       const int64_t R = opt->seg_rows[0] + opt->seg_rows[1];
@@ -806,6 +831,7 @@ extern "C" int dccf_dp_finish(const dccf_opt_t* opt, const dccf_dp_t* dp, int32_
     }
     return 0;
   }
+  ARG_CHECK(opt->lazy_K == 0, "the lazy optimizer needs the overlapped form of the step (overlap != 0)");
   if (int e = dp_import_touched(dp->bufs, dp->G, opt->g, opt->n, opt->nseg, opt->seg_begin, opt->seg_rows, opt->seg_width,
                                 opt->seg_flags, dp->dense_begin, dp->loss_sum, dp->cap, dp->D, dp->mask, dp->where, dp->buf, stream))
     return e;

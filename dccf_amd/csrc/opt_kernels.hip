@@ -767,6 +767,96 @@ int dccf_lazy_step(const void* ov, const PrepNext* pn, int64_t nslots, hipStream
   return lazy_launch((const dccf_opt_t*)ov, 0, pn, nslots, st);
 }
 
+// Replicated multi-GPU path: the rows ANY rank touches at step t are known before the step as bytes (the replicated
+// schedule): each flagged row is claimed for step t and brought up to step t - 1.  A wave scans 64 rows' bytes, then all its
+// lanes serve the flagged rows one after the other.
+template <int KIND>
+__global__ __launch_bounds__(256) void k_lazy_catchup_flags(float* __restrict__ p, float* __restrict__ s1, float* __restrict__ s2,
+                                                            OptArgs a, RowSegs sg, LazyArgs z, const uint8_t* __restrict__ f0,
+                                                            const uint8_t* __restrict__ f1, int seg0, int seg1) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int t = (int)z.step;
+  const LazyPend pend = lazy_pend_read(z);
+  for (int k = 0; k < 2; ++k) {
+    const int q = k ? seg1 : seg0;
+    const uint8_t* fl = k ? f1 : f0;
+    const int64_t rows = z.rows[q];
+    const int w = sg.width[q];
+    for (int64_t r0 = wave * 64; r0 < rows; r0 += nw * 64) {
+      const int64_t r = r0 + lane;
+      uint64_t bits = __ballot(r < rows && fl[r < rows ? r : 0] != 0);
+      while (bits) {
+        const int b = __ffsll((unsigned long long)bits) - 1;
+        bits &= bits - 1;
+        const int64_t row = r0 + b, grow = z.row_off[q] + row;
+        const int from = __builtin_amdgcn_readfirstlane(lazy_eff_last(z, pend, grow));
+        if (lane == 0) z.claim[grow] = t;
+        if (from >= t - 1) continue;
+        float* pr = p + sg.begin[q] + row * w;
+        float* ar = s1 ? s1 + sg.begin[q] + row * w : nullptr;
+        float* br = s2 ? s2 + sg.begin[q] + row * w : nullptr;
+        for (int c = lane; c < w; c += 64) {
+          float pv = pr[c], av = KIND != DCCF_OPT_GD ? ar[c] : 0.f, bv = KIND == DCCF_OPT_ADAM ? br[c] : 0.f;
+          lazy_replay<KIND>(pv, av, bv, a, z, from, t - 1);
+          pr[c] = pv;
+          if (KIND != DCCF_OPT_GD) ar[c] = av;
+          if (KIND == DCCF_OPT_ADAM) br[c] = bv;
+        }
+        if (lane == 0) z.last[grow] = t - 1;
+      }
+    }
+  }
+}
+
+int dccf_lazy_catchup_flags(const void* ov, const uint8_t* flags0, const uint8_t* flags1, int seg0, int seg1, hipStream_t st) {
+  const dccf_opt_t* o = (const dccf_opt_t*)ov;
+  OptJob j;
+  if (int e = opt_job(ov, &j)) return e;
+  LazyArgs z;
+  if (int e = lazy_args(o, j, &z)) return e;
+  ARG_CHECK(flags0 && flags1 && seg0 >= 0 && seg0 < j.sg.n && seg1 >= 0 && seg1 < j.sg.n, "bad flags / segments");
+  const int64_t rows = max(z.rows[seg0], z.rows[seg1]);
+  const int grid = (int)max((int64_t)1, min((int64_t)2048, (rows + 255) / 256));
+  BY_KIND(j.kind, k_lazy_catchup_flags, dim3(grid), dim3(256), 0, st, j.p, j.s1, j.s2, j.a, j.sg, z, flags0, flags1, seg0, seg1);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// Phase 1 of a replicated step in lazy form: this step's window (claimed rows excepted), the previous window's marks and the
+// next step's preparation — no list, no dense tail (the import applies those with the rank-ordered sums)
+int dccf_lazy_phase1(const void* ov, const PrepNext* pnp, hipStream_t st) {
+  const dccf_opt_t* o = (const dccf_opt_t*)ov;
+  OptJob j;
+  if (int e = opt_job(o, &j)) return e;
+  LazyArgs z;
+  if (int e = lazy_args(o, j, &z)) return e;
+  DenseSegs ds;
+  memset(&ds, 0, sizeof(ds));
+  const int64_t R = z.row_off[3] + z.rows[3];
+  const int64_t w = o->step % o->lazy_K;
+  const int64_t win0 = R * w / o->lazy_K, win1 = R * (w + 1) / o->lazy_K;
+  PrepNext pn;
+  memset(&pn, 0, sizeof(pn));
+  if (pnp) pn = *pnp;
+  int maxw4 = 4;
+  for (int q = 0; q < j.sg.n; ++q) maxw4 = max(maxw4, j.sg.width[q] >> 2);
+  const int wb = (int)max((int64_t)1, min((int64_t)8192, ((win1 - win0) * maxw4 + 255) / 256));
+  const int mb = 32;
+  BY_KIND(j.kind, k_lazy_opt, dim3(pn.blocks + wb + mb), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.a, j.sg, ds, z, 0, 0, mb, win0, win1,
+          0, 0, pn);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// every row up to step - 1 (a step whose rows were not known in advance starts from a table that is current)
+int dccf_lazy_flush_to_prev(const void* ov, hipStream_t st) {
+  dccf_opt_t o = *(const dccf_opt_t*)ov;
+  if (o.step <= 1) return 0;
+  o.step -= 1;
+  return lazy_launch(&o, 1, nullptr, 0, st);
+}
+
 extern "C" int dccf_lazy_flush(const dccf_opt_t* opt, void* stream) {
   ARG_CHECK(opt != nullptr && opt->lazy_K > 0, "dccf_lazy_flush needs a lazy optimizer (lazy_K > 0)");
   ARG_CHECK(opt->kind != DCCF_OPT_ADAM || opt->step < opt->lazy_t0 + opt->lazy_nscal, "step-scalar table too short");

@@ -56,6 +56,12 @@ class HipBackend(object):
         self.r = L.rand_struct(seed=tr.seed, step=0)
         self.g = L.GradsT(L.ptr(tr.gU), L.ptr(tr.gV), L.ptr(tr.gW), L.ptr(tr.gb), L.ptr(tr.tU, u8), L.ptr(tr.tV, u8))
         self.opt = L.opt_struct('adam', tr.flat_p, tr.flat_g, tr.s1, tr.s2, tr.lr, tr.l2, tr.l2, 50.0, tr.segments, 0)
+        # windowed lazy regularisation in the overlapped form of the step: phase 1 advances one K-th of the
+        # rows no rank touches by K steps instead of streaming all of them every step
+        self.lazy = None
+        if tr.lazy_K >= 2 and tr.overlap and tr.D in (16, 32, 64, 128):
+            self.lazy = L.LazyState(self.opt, tr.lazy_K, tr.user_num + tr.item_num, 64, tr.lr, tr.flat_p.device)
+            self.lazy.sync_all(tr.t)
         self.scratch = L.DpScratch(tr.user_num + tr.item_num, tr.G, tr.flat_g.device)
         d = L.DpT()
         d.G, d.rank, d.D, d.S = int(tr.G), int(tr.rank), int(tr.D), int(tr.S)
@@ -84,6 +90,15 @@ class HipBackend(object):
             self.prepare(tr)
         if pred is None:
             pred = torch.empty(X.shape[0], dtype=torch.float32, device=X.device)
+        if self.lazy is not None:
+            if X_all is None:                  # a step without the schedule: bring everything up to date, dense pass for this one
+                self.flush(tr)
+                self.opt.lazy_K = 0
+            else:
+                self.opt.lazy_K = self.lazy.K
+                self.opt.step = tr.t + 1       # (the catch-up needs the step number before the forward)
+                self.lazy.cover(tr.t + 1)
+                self.lazy.dirty = True
         self.r.step = step
         self.L.check(self.f_local(self.ctx.h, self.mp, self.rp, self.L.ptr(X, torch.int64), self.L.ptr(Y, torch.float32),
                                   X.shape[0], tr.dropout, self.gp, self.op, self.dpp, self.L.ptr(X_all, torch.int64), int(step0),
@@ -106,14 +121,29 @@ class HipBackend(object):
         self.opt.step = t
         self.L.check(self.f_overlap(self.op, self.dpp, tr.parity, self._next(tr), self.L.stream()))
 
+    def flush(self, tr):
+        """Every row up to step tr.t (no-op unless lazy rows are behind): before anything but train_step reads the tables."""
+        if self.lazy is not None and self.ready is tr:
+            self.opt.lazy_K = self.lazy.K
+            self.lazy.flush(tr.t)
+
     def finish(self, tr, t, ov):
         """After the gathered buffers arrived: rank-ordered sums -> optimizer (ov: only the marked rows + W, b are left)."""
         self.opt.step = t
+        if self.lazy is not None and self.opt.lazy_K == 0:      # the dense step of a call without the schedule
+            self.lazy.last.fill_(int(t))
         self.L.check(self.f_finish(self.op, self.dpp, 1 if ov else 0, tr.parity, self._next(tr) if ov else None,
                                    self.L.stream()))
 
 
 class ReplicatedDCCF(object):
+    lazy_K = int(os.environ.get('DCCF_LAZY_K', '8'))       # 0: the dense pass in every phase 1
+
+    def flush(self):
+        """Brings every parameter row up to the current step (the lazy regularisation leaves rows behind between steps)."""
+        if hasattr(self.be, 'flush'):
+            self.be.flush(self)
+
     def __init__(self, rank, world, user_num, item_num, D, S, A, std, dropout, lr, l2, seed, backend, device, feat,
                  expo=None, ips=None, max_rows=256, group=None, overlap=True):
         """feat [item_num, F]; expo [user_num, item_num] or ips (dict of IPSBiasedMF factors) — full tables, identical on
@@ -272,6 +302,7 @@ def bench_main(args, rank, world, dev):
     dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt)
+    tr.flush()
     # replicas must be bit-identical: compare a checksum of the parameters across ranks (outside the timed region)
     chk = torch.stack([tr.flat_p.double().sum(), tr.flat_p.double().abs().sum()])
     lo, hi = chk.clone(), chk.clone()
@@ -302,6 +333,7 @@ def bench_main(args, rank, world, dev):
                                       'GPU, one all-gather of the touched gradient rows per step; --mp sharded runs the row-sharded '
                                       'all-to-all layout), fused on-device negatives' % (U, I, D, F, S, A, expo_mode),
                           'layout': 'replicated',
+                          'regularisation': ('windowed lazy (K = %d)' % be.lazy.K) if getattr(be, 'lazy', None) is not None else 'dense pass',
                           'batch_size_per_gpu': B, 'global_batch': B * world, 'optimizer': 'Adam lr=1e-3 l2=1e-4 dropout=0.2',
                           'collectives_per_step': 'all_gather x1 (touched gradient rows + [dW|db], %.2f MB per rank)'
                                                   % (tr.words * 4 / 1e6),

@@ -152,6 +152,8 @@ def test_replicated_trainer_world1_equals_single_gpu_step(overlap):
         torch.cuda.synchronize()
         np.testing.assert_allclose(pred.cpu().numpy(), pred2.cpu().numpy(), rtol=1e-5, atol=1e-6)
         assert float(loss) == pytest.approx(float(loss2), rel=1e-5)
+    assert (tr.be.lazy is not None) == overlap           # the overlapped step runs the windowed lazy regularisation
+    tr.flush()
     # float atomics inside the backward reorder sums between the two runs; Adam turns that into a fraction of lr
     d = (tr.flat_p - p0).abs()
     assert float(d.max()) <= 4 * 1e-3 and int((d > 4 * 5e-3 * 1e-3).sum()) <= 4 * D + 8
@@ -194,6 +196,7 @@ def _rank_main(rank, world, port, out, overlap):
         _, loss = tr.train_step(sched[t, rank], y, X_all=sched[t] if overlap else None,
                                 X_all_next=sched[t + 1] if prep and t + 1 < c['steps'] else None)
         losses.append(float(loss))
+    tr.flush()
     torch.cuda.synchronize()
     assert tr.be.ctx.prepared_steps() == (c['steps'] - 1 if prep else 0)
     np.savez(os.path.join(out, 'r%d_%s.npz' % (rank, tag)), p=tr.flat_p.cpu().numpy(), losses=np.array(losses),
