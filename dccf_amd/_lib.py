@@ -148,7 +148,7 @@ def load():
         'shard_pack_rows': [vp, vp, i64, C.POINTER(vp), C.POINTER(i32), i32, vp, i32, vp],
         'shard_unpack_rows': [vp, i32, i64, vp, C.POINTER(vp), C.POINTER(i32), i32, vp],
         'shard_scatter_add': [vp, i64, vp, i32, vp, vp, vp],
-        'dccf_build_epoch_batches': [vp, vp, vp, vp, i64, i64, vp, vp, vp, vp],
+        'dccf_build_epoch_batches': [vp, vp, vp, vp, i64, i64, vp, vp, vp, u64, u64, vp],
         'shard_pack_multi': [vp, i32, vp],
         'dccf_lazy_scalars': [f32, i64, i32, vp],
         'dccf_lazy_flush': [C.POINTER(OptT), vp],
@@ -518,15 +518,16 @@ def shard_unpack_rows(payload, n, dst, tables):
                                    widths, k, stream()))
 
 
-def build_epoch_batches(uid, iid, neg, perm, batch_size, bad):
-    """(full [n // B, 2B, 2], tail [2 (n % B), 2] or None) int64 from the epoch's permutation — one launch."""
+def build_epoch_batches(uid, iid, neg, perm, batch_size, bad, seed=0, epoch=0):
+    """(full [n // B, 2B, 2], tail [2 (n % B), 2] or None) int64 — one launch.  perm: the epoch's permutation as an int64
+    tensor, or None: a keyed bijection of (seed, epoch) computed inside the kernel."""
     n = uid.numel()
     nb, r = n // batch_size, n % batch_size
     full = torch.empty((nb, 2 * batch_size, 2), dtype=torch.int64, device=uid.device)
     tail = torch.empty((2 * r, 2), dtype=torch.int64, device=uid.device) if r else None
     check(load().dccf_build_epoch_batches(ptr(uid, torch.int64), ptr(iid, torch.int64), ptr(neg, torch.int64), ptr(perm, torch.int64),
                                           n, int(batch_size), ptr(full, torch.int64), ptr(tail, torch.int64), ptr(bad, torch.int32),
-                                          stream()))
+                                          int(seed) & 0xFFFFFFFFFFFFFFFF, int(epoch) & 0xFFFFFFFFFFFFFFFF, stream()))
     return full, tail
 
 

@@ -750,13 +750,34 @@ extern "C" int dccf_sample_train_negatives(const int64_t* rows_indptr, const int
 // pos row j = (uid, iid)[perm[k*B + j]], neg row j = (uid, neg)[perm[k*B + j]] — rows j and B + j carry the same uid.  The
 // n % B rows left over form the shorter last batch `tail` [2r, 2].  A negative of -1 (a user with nothing left to draw,
 // dccf_sample_train_negatives) is replaced by 0 and reported through *bad: no id below 0 ever reaches a kernel as a row index.
+// perm == NULL: the epoch's permutation is computed on the fly — a keyed bijection of [0, 2^b) (b = bits of n - 1; four rounds of
+// "multiply by an odd key, add, xor-shift", each a bijection of b-bit integers) walked until it lands below n (cycle walking: at
+// most two rounds on average).  It plays shuffle_in_unison_scary's role (src/utils/utils.py:82-92) without a sort: no
+// permutation array, no extra launches (torch.randperm is a key sort of five launches, more than a 20-step epoch can hide).
+__device__ __forceinline__ uint64_t perm_round(uint64_t x, uint64_t mask, int b, uint64_t ka, uint64_t kc) {
+  x = (x * (ka | 1ull) + kc) & mask;
+  x ^= x >> ((b + 1) >> 1);
+  return x;
+}
+__device__ __forceinline__ int64_t epoch_perm(int64_t i, int64_t n, int b, uint64_t k0, uint64_t k1) {
+  const uint64_t mask = b >= 64 ? ~0ull : ((1ull << b) - 1);
+  uint64_t x = (uint64_t)i;
+  do {
+    x = perm_round(x, mask, b, k0 * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull, k1 ^ 0x8CB92BA72F3D8DD7ull);
+    x = perm_round(x, mask, b, k1 * 0xC2B2AE3D27D4EB4Full + 0x165667B19E3779F9ull, k0 + 0x27D4EB2F165667C5ull);
+    x = perm_round(x, mask, b, (k0 ^ (k1 << 1)) * 0xFF51AFD7ED558CCDull + 0x9FB21C651E98DF25ull, k1 * 0x2545F4914F6CDD1Dull);
+    x = perm_round(x, mask, b, (k1 ^ (k0 >> 3)) * 0xC4CEB9FE1A85EC53ull + 0x94D049BB133111EBull, k0 * 0xBF58476D1CE4E5B9ull);
+  } while (x >= (uint64_t)n);
+  return (int64_t)x;
+}
+
 __global__ __launch_bounds__(256) void k_epoch_batches(const int64_t* __restrict__ uid, const int64_t* __restrict__ iid,
                                                        const int64_t* __restrict__ neg, const int64_t* __restrict__ perm, int64_t n,
                                                        int64_t B, int64_t* __restrict__ full, int64_t* __restrict__ tail,
-                                                       int32_t* __restrict__ bad) {
+                                                       int32_t* __restrict__ bad, int pbits, uint64_t pk0, uint64_t pk1) {
   const int64_t nb = n / B, r = n - nb * B;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t s = perm[i];
+    const int64_t s = perm ? perm[i] : epoch_perm(i, n, pbits, pk0, pk1);
     const int64_t u = uid[s], ip = iid[s];
     int64_t ng = neg[s];
     if (ng < 0) {
@@ -772,12 +793,25 @@ __global__ __launch_bounds__(256) void k_epoch_batches(const int64_t* __restrict
 }
 
 extern "C" int dccf_build_epoch_batches(const int64_t* uid, const int64_t* iid, const int64_t* neg, const int64_t* perm, int64_t n,
-                                        int64_t batch_size, int64_t* full, int64_t* tail, int32_t* bad, void* stream) {
+                                        int64_t batch_size, int64_t* full, int64_t* tail, int32_t* bad, uint64_t seed, uint64_t epoch,
+                                        void* stream) {
   ARG_CHECK(n >= 0 && batch_size > 0 && bad, "bad arguments");
   if (n == 0) return 0;
-  ARG_CHECK(uid && iid && neg && perm && (n < batch_size || full) && (n % batch_size == 0 || tail), "NULL argument");
+  ARG_CHECK(uid && iid && neg && (n < batch_size || full) && (n % batch_size == 0 || tail), "NULL argument");
   const int grid = (int)min((int64_t)2048, (n + 255) / 256);
-  hipLaunchKernelGGL(k_epoch_batches, dim3(grid), dim3(256), 0, (hipStream_t)stream, uid, iid, neg, perm, n, batch_size, full, tail, bad);
+  int b = 1;
+  while (b < 63 && (1ll << b) < n) ++b;
+  // two 64-bit keys from (seed, epoch): splitmix64 steps
+  uint64_t z = seed * 0x9E3779B97F4A7C15ull + epoch * 0xBF58476D1CE4E5B9ull + 0x94D049BB133111EBull, k[2];
+  for (int i = 0; i < 2; ++i) {
+    z += 0x9E3779B97F4A7C15ull;
+    uint64_t x = z;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    k[i] = x ^ (x >> 31);
+  }
+  hipLaunchKernelGGL(k_epoch_batches, dim3(grid), dim3(256), 0, (hipStream_t)stream, uid, iid, neg, perm, n, batch_size, full, tail, bad,
+                     b, k[0], k[1]);
   HIP_TRY(hipGetLastError());
   return 0;
 }

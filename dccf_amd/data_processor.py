@@ -11,6 +11,7 @@ Two training feeds:
 Evaluation negatives (:73-111, :408-444) are sampled once per run on the host exactly as the reference does.
 """
 import logging
+import os
 from collections import defaultdict
 
 import numpy as np
@@ -318,11 +319,15 @@ class DeviceTrainSet(object):
         assert self.n == 0 or int(self._bad) == 0, 'no admissible training negative left for some user'
 
     def epoch_batches(self, epoch, batch_size):
-        """Three launches per epoch: the sampler, the permutation, the batch tensor."""
+        """Two launches per epoch: the sampler and the batch tensor (the permutation — the in-unison shuffle of
+        src/utils/utils.py:82-92 — is a keyed bijection of (seed, epoch) evaluated inside the batch kernel; DCCF_TORCH_PERM=1
+        draws it with torch.randperm instead: a key sort of five launches)."""
         neg = self.sample_negatives(epoch)
-        g = torch.Generator(device=self.uid.device)
-        g.manual_seed((self.seed * 1000003 + int(epoch)) & 0x7FFFFFFFFFFFFFFF)
-        perm = torch.randperm(self.n, generator=g, device=self.uid.device)
+        perm = None
+        if os.environ.get('DCCF_TORCH_PERM') == '1':
+            g = torch.Generator(device=self.uid.device)
+            g.manual_seed((self.seed * 1000003 + int(epoch)) & 0x7FFFFFFFFFFFFFFF)
+            perm = torch.randperm(self.n, generator=g, device=self.uid.device)
         # a user whose history leaves nothing to draw gets -1 from the sampler; the batch kernel stores 0 instead (an id of -1
         # must never reach a kernel as a row index) and raises the device flag check_negatives() reads
-        return _lib.build_epoch_batches(self.uid, self.iid, neg, perm, batch_size, self._bad)
+        return _lib.build_epoch_batches(self.uid, self.iid, neg, perm, batch_size, self._bad, self.seed, epoch)

@@ -270,9 +270,11 @@ int dccf_sample_train_negatives(const int64_t* rows_indptr, const int64_t* rows,
 /* The epoch's feed dicts (src/data_processor/DataProcessor.py:160-207,227-250) as one tensor: with the epoch's permutation
  * perm [n] (shuffle_in_unison_scary, src/utils/utils.py:82-92) batch k of full [n / B, 2B, 2] is X = [pos ; neg] with
  * pos row j = (uid, iid)[perm[kB + j]] and neg row j = (uid, neg)[perm[kB + j]]; the n % B rows left over are the shorter last
- * batch tail [2 (n % B), 2].  A negative of -1 is stored as 0 and *bad (device int32, zeroed by the caller) set to 1. */
+ * batch tail [2 (n % B), 2].  A negative of -1 is stored as 0 and *bad (device int32, zeroed by the caller) set to 1.
+ * perm == NULL: the permutation is a keyed bijection of (seed, epoch) computed inside the kernel (no array, no sort). */
 int dccf_build_epoch_batches(const int64_t* uid, const int64_t* iid, const int64_t* neg, const int64_t* perm, int64_t n,
-                             int64_t batch_size, int64_t* full, int64_t* tail, int32_t* bad, void* stream);
+                             int64_t batch_size, int64_t* full, int64_t* tail, int32_t* bad, uint64_t seed, uint64_t epoch,
+                             void* stream);
 /* Eval negatives (src/data_processor/DataProcessor.py:408-444,446-524 with train=False): neg_n items per DISTINCT user of a
  * split (users [n_users], first-occurrence order), uniform over the items, outside the user's train + validation/test
  * history (hist CSR by user id, items sorted) and distinct.  Draw j of user u = word j%4 of Philox(c0=u, c1=j/4, c2=tag)
