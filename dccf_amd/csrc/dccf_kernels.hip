@@ -35,6 +35,7 @@ struct Knobs {
   int64_t fold_max_n;     // DCCF_FOLD_MAX_N   largest 2B for which the pair epilogue is folded into the backward
   int64_t hosted_wgs;     // DCCF_HOSTED_WGS   workgroups of a hosted optimizer pass
   bool hostv;             // DCCF_NO_HOSTV=1   turns the hosted item-table pass off
+  int64_t bwd_wgs;        // DCCF_BWD_WGS      role workgroups of the backward at 2B < 2048 (row splits = this / roles)
 };
 static const Knobs& knobs() {
   static const Knobs k = [] {
@@ -43,6 +44,7 @@ static const Knobs& knobs() {
     q.fold_max_n = getenv("DCCF_FOLD_MAX_N") ? atoll(getenv("DCCF_FOLD_MAX_N")) : 1024;
     q.hosted_wgs = getenv("DCCF_HOSTED_WGS") ? atoll(getenv("DCCF_HOSTED_WGS")) : 256;
     q.hostv = getenv("DCCF_NO_HOSTV") == nullptr;
+    q.bwd_wgs = getenv("DCCF_BWD_WGS") ? atoll(getenv("DCCF_BWD_WGS")) : 256;
     return q;
   }();
   return k;
@@ -1386,7 +1388,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     // wave) per workgroup at least
     const int roles = (y.NC + 2) * y.GY;
     // small batches: ~1 workgroup per CU; large ones: ~4 per CU (4 waves per SIMD fill the shared VALU / fp32-MFMA pipe)
-    const int64_t gx = max((int64_t)1, min((N + BWD_NW - 1) / BWD_NW, (int64_t)max(1, (N >= 2048 ? 1024 : 256) / roles)));
+    const int64_t gx = max((int64_t)1, min((N + BWD_NW - 1) / BWD_NW, (int64_t)max(1, (N >= 2048 ? 1024 : (int)knobs().bwd_wgs) / roles)));
     // hosted optimizer pass: as many extra workgroups as CUs (one beside each role workgroup)
     // (hosting the lazy window here as well was measured and lost: its replay is vector-ALU work with long dependent chains, and
     // the hosted waves — one per SIMD beside the 256-VGPR role waves — cannot issue it fast enough: backward 25 -> 68 us)

@@ -296,6 +296,7 @@ def bench_main(args, rank, world, dev):
     sched = schedule(1, args.steps)                            # the epoch's negative sampling is timed
     for k in range(args.steps):
         tr.train_step(sched[k, rank], y, pred, X_all=sched[k], X_all_next=nxt(sched, k, args.steps))
+    tr.flush()          # (timed: the rows the lazy regularisation left behind are brought up to date before the clock stops)
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
