@@ -13,13 +13,13 @@ LIB_PATH = os.path.join(HERE, 'lib', 'libdccf_hip.so')
 EXPORTS = ['dccf_ctx_create', 'dccf_ctx_destroy', 'dccf_ctx_reserve', 'dccf_last_error', 'dccf_abi_version',
            'dccf_predict', 'dccf_train_fwdbwd', 'dccf_dense_opt_step', 'dccf_sumsq', 'mf_predict', 'mf_train_fwdbwd',
            'mf_predict_full', 'dccf_sample_train_negatives', 'dccf_debug_candidates', 'dccf_debug_noise',
-           'dccf_debug_keep', 'dccf_debug_keep_layer', 'dccf_debug_workspace', 'dccf_profile', 'dccf_profile_read',
+           'dccf_debug_keep', 'dccf_debug_keep_layer', 'dccf_debug_opt_elem', 'dccf_debug_workspace', 'dccf_profile', 'dccf_profile_read',
            'shard_pack_rows', 'shard_unpack_rows', 'shard_scatter_add', 'dccf_dense_opt_step_rows', 'dccf_dense_opt_step_dev', 'dccf_advance', 'rank_eval_topk', 'dccf_train_step', 'dp_buffer_words',
            'dp_export_touched', 'dp_import_touched', 'dp_mark_global', 'dccf_dense_opt_phase', 'dccf_ctx_side_stream', 'dp_import_apply',
            'dccf_sample_eval_negatives', 'dccf_eval_prepare', 'dccf_predict_projected', 'dccf_dp_local', 'dccf_dp_overlap',
            'dccf_dp_finish', 'dccf_ctx_prepared_steps', 'dccf_ctx_hosted_rows', 'shard_pack_multi', 'shard_unpack_multi', 'dccf_build_epoch_batches', 'dccf_lazy_scalars', 'dccf_lazy_flush']
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 OPT_KIND = {'gd': 0, 'adagrad': 1, 'adam': 2}
 MF_KIND = {'RecModel': 0, 'BiasedMF': 1, 'IPSBiasedMF': 2}
 
@@ -143,6 +143,7 @@ def load():
         'dccf_debug_candidates': [i64, i32, i64, u64, u64, vp, vp],
         'dccf_debug_noise': [i64, i32, f32, u64, u64, vp, vp],
         'dccf_debug_keep': [i64, i32, f32, u64, u64, vp, vp],
+        'dccf_debug_opt_elem': [i32, i32, vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, vp],
         'dccf_debug_keep_layer': [i64, i32, f32, u64, u64, i32, vp, vp],
         'dccf_debug_workspace': [vp, i64, i32, i32, i32, i32, i32, vp, C.POINTER(C.c_int64), vp],
         'shard_pack_rows': [vp, vp, i64, C.POINTER(vp), C.POINTER(i32), i32, vp, i32, vp],
@@ -336,7 +337,7 @@ class LazyState(object):
         self.claim = torch.zeros(n_rows, dtype=torch.int32, device=device)
         self.list = torch.zeros(list_cap, dtype=torch.int32, device=device)
         self.cnt = torch.zeros(16, dtype=torch.int32, device=device)      # the pending-window records (include/dccf_hip.h)
-        self.scal = torch.zeros(2 * self.NSCAL, dtype=torch.float32, device=device)
+        self.scal = torch.zeros(4 * self.NSCAL, dtype=torch.float32, device=device)
         self.t0 = -1
         self.dirty = False          # True while some row may be behind opt.step
         opt.lazy_K, opt.lazy_nscal = self.K, self.NSCAL
@@ -349,7 +350,7 @@ class LazyState(object):
         lo = max(1, step - self.K + 1)
         if self.t0 < 0 or lo < self.t0 or step >= self.t0 + self.NSCAL:
             self.t0 = max(0, lo - 1)
-            host = (C.c_float * (2 * self.NSCAL))()
+            host = (C.c_float * (4 * self.NSCAL))()
             check(load().dccf_lazy_scalars(self.lr, self.t0, self.NSCAL, host))
             self.scal.copy_(torch.frombuffer(host, dtype=torch.float32).clone().to(self.scal.device))
             self.opt.lazy_t0 = self.t0
@@ -481,6 +482,13 @@ def debug_noise(L, F, std, seed, step, device):
     out = torch.zeros((L, F), dtype=torch.float32, device=device)
     check(load().dccf_debug_noise(L, F, float(std), int(seed), int(step), ptr(out), stream()))
     return out
+
+
+def debug_opt_elem(kind, ieee, p, g, s1, s2, lr, wd, l2, clip, step):
+    """One optimizer step, element by element, in place: the library's element function (ieee=0) or its IEEE twin (ieee=1)."""
+    o = lambda t: ptr(t) if t is not None else None
+    check(load().dccf_debug_opt_elem(OPT_KIND[kind], int(ieee), ptr(p), ptr(g), o(s1), o(s2), p.numel(), float(lr), float(wd),
+                                     float(l2), float(clip), int(step), stream()))
 
 
 def debug_keep(L, D, dropout, seed, step, device, layer=0):

@@ -6,7 +6,7 @@
 #include <string.h>
 #include "../../include/dccf_hip.h"
 
-#define DCCF_ABI_VERSION 3
+#define DCCF_ABI_VERSION 4
 #pragma clang fp contract(off)
 
 // ---------------------------------------------------------------------------------------------- errors

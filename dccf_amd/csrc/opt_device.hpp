@@ -9,6 +9,7 @@ struct OptArgs {
   float lr, wd, l2, clip;
   float step_size_neg;   // Adam: -(lr / (1 - beta1^t))
   float bc2_sqrt;        // Adam: sqrt(1 - beta2^t)
+  float bc2_rsqrt;       // Adam: RN(1 / bc2_sqrt) — what div_by_uniform needs (see there)
   int zero_grad;
   const int64_t* k_dev;  // graph-replayable form: step = step0 + *k_dev, bias corrections computed here
   int64_t step0;
@@ -19,11 +20,72 @@ __device__ __forceinline__ void opt_resolve(OptArgs& a) {
     const double t = (double)(a.step0 + *a.k_dev);
     a.step_size_neg = (float)(-((double)a.lr / (1.0 - pow(0.9, t))));
     a.bc2_sqrt = (float)sqrt(1.0 - pow(0.999, t));
+    a.bc2_rsqrt = (float)(1.0 / (double)a.bc2_sqrt);
   }
 }
 
+// ---- Adam's two divisions and its square root, without the range scaling of the compiler's IEEE expansions -----------
+// `__fdiv_rn` is v_div_scale x2 + v_rcp + 7 fma-class ops + v_div_fixup (11 instructions, none of them packed), `__fsqrt_rn` is
+// v_sqrt_f32 between two conditional v_ldexp (6 instructions): 28 of the 47 vector instructions of one Adam element-step —
+// the windowed lazy replay (16.4 M element-steps per launch at the bench shape) is bound by exactly these.  The operands of
+// Adam's divisions cannot reach the ranges the scaling is for, so the same Newton steps WITHOUT it give the same bits
+// (tests/test_hip_parity.py::test_adam_element_function_equals_ieee: bit-equal to opt_elem_ieee) and pack two lanes of
+// work into v_pk_fma_f32.  Every optimizer kernel (dense, row-aware, hosted, import, lazy) calls the ONE opt_elem below, so
+// dense == lazy bit for bit holds by construction.
+//
+// x / c, c wave-uniform with rc = RN(1 / c) known (host, in double): q0 = x rc is within 2 ulp; one residual correction makes
+// it faithful, the second rounds it correctly (Markstein: q faithful and y = RN(1/c) => RN(q + y (x - c q)) = RN(x / c)) as
+// long as the residuals are exact, i.e. nothing under- or overflows: x = sqrt(v) is 0 or in [2^-75, 2^64], c in [0.03, 1].
+__device__ __forceinline__ float div_by_uniform(float x, float c, float rc) {
+  float q = __fmul_rn(x, rc);
+  float r = fmaf(-c, q, x);
+  q = fmaf(r, rc, q);
+  r = fmaf(-c, q, x);
+  return fmaf(r, rc, q);
+}
+// n / d for d in [1e-8, 2^70] (Adam's denominator: something non-negative + 1e-8) — the compiler's own sequence (reciprocal,
+// one Newton step on it, quotient, two residual corrections) minus v_div_scale / v_div_fmas' scaling / v_div_fixup.  Equal to
+// __fdiv_rn whenever |n| is 0 or in [2^-100, 2^100]; a quotient of -0 comes out as +0 (added to a parameter that is never -0).
+__device__ __forceinline__ float div_normal(float n, float d) {
+  float y = __builtin_amdgcn_rcpf(d);
+  const float e = fmaf(-d, y, 1.0f);
+  y = fmaf(e, y, y);
+  float q = __fmul_rn(n, y);
+  float r = fmaf(-d, q, n);
+  q = fmaf(r, y, q);
+  r = fmaf(-d, q, n);
+  return fmaf(r, y, q);
+}
+// sqrt(v) as the bare v_sqrt_f32 (what __fsqrt_rn lowers to, between scalings by 2^32 / 2^-16 for v < 2^-96): for those v the
+// instruction sees the same significand and exponent parity, and below 2^-126 whatever it returns (<= 2^-63) vanishes in
+// "+ 1e-8" (ulp 2^-50 after the division by c >= 0.03).
+__device__ __forceinline__ float sqrt_bare(float v) { return __builtin_amdgcn_sqrtf(v); }
+
 template <int KIND>
 __device__ __forceinline__ void opt_elem(float& p, float& g, float& s1, float& s2, const OptArgs& a) {
+  // explicit l2 term of the loss, then the clip, then the optimizer's coupled weight decay
+  float gt = __fadd_rn(g, __fmul_rn(a.l2, __fmul_rn(2.0f, p)));
+  gt = fminf(fmaxf(gt, -a.clip), a.clip);
+  gt = __fadd_rn(gt, __fmul_rn(a.wd, p));
+  if (KIND == DCCF_OPT_GD) {
+    p = __fadd_rn(p, __fmul_rn(-a.lr, gt));
+  } else if (KIND == DCCF_OPT_ADAGRAD) {
+    s1 = __fadd_rn(s1, __fmul_rn(gt, gt));
+    const float sd = __fadd_rn(__fsqrt_rn(s1), 1e-10f);
+    p = __fadd_rn(p, __fdiv_rn(__fmul_rn(-a.lr, gt), sd));
+  } else {
+    s1 = __fadd_rn(s1, __fmul_rn(0.1f, __fsub_rn(gt, s1)));                       // lerp_(g, 1-beta1), weight < 0.5
+    s2 = __fadd_rn(__fmul_rn(s2, 0.999f), __fmul_rn(__fmul_rn(0.001f, gt), gt));  // mul_(b2).addcmul_(g, g, 1-b2)
+    const float denom = __fadd_rn(div_by_uniform(sqrt_bare(s2), a.bc2_sqrt, a.bc2_rsqrt), 1e-8f);
+    p = __fadd_rn(p, div_normal(__fmul_rn(a.step_size_neg, s1), denom));
+  }
+  if (a.zero_grad) g = 0.f;
+}
+
+
+// The same element step on the compiler's IEEE division / square root: what opt_elem is checked against (dccf_debug_opt_elem).
+template <int KIND>
+__device__ __forceinline__ void opt_elem_ieee(float& p, float& g, float& s1, float& s2, const OptArgs& a) {
   // explicit l2 term of the loss, then the clip, then the optimizer's coupled weight decay
   float gt = __fadd_rn(g, __fmul_rn(a.l2, __fmul_rn(2.0f, p)));
   gt = fminf(fmaxf(gt, -a.clip), a.clip);
@@ -122,7 +184,7 @@ __device__ __forceinline__ void opt_untouched_pass(const OptJob& j, int64_t bid,
 // ---- windowed lazy regularisation: see dccf_opt_t.lazy_* (include/dccf_hip.h).  Rows are numbered globally: segment q's row r is grow = row_off[q] + r.
 struct LazyArgs {
   int K, nscal;
-  int64_t t0, step;          // scal[2 (s - t0)], scal[2 (s - t0) + 1] are the scalars of step s
+  int64_t t0, step;          // scal[4 (s - t0) ..+2] = {step_size_neg, bc2_sqrt, bc2_rsqrt} of step s
   int* last;
   int* claim;
   int* list;
@@ -159,8 +221,8 @@ template <int KIND>
 __device__ __forceinline__ void lazy_replay(float& p, float& s1, float& s2, OptArgs a, const LazyArgs& z, int from, int to) {
   for (int s = from + 1; s <= to; ++s) {
     if (KIND == DCCF_OPT_ADAM) {
-      a.step_size_neg = z.scal[2 * (s - z.t0)];
-      a.bc2_sqrt = z.scal[2 * (s - z.t0) + 1];
+      const float4 sc = reinterpret_cast<const float4*>(z.scal)[s - z.t0];
+      a.step_size_neg = sc.x; a.bc2_sqrt = sc.y; a.bc2_rsqrt = sc.z;
     }
     float g0 = 0.f;
     opt_elem<KIND>(p, g0, s1, s2, a);
@@ -170,8 +232,8 @@ template <int KIND>
 __device__ __forceinline__ void lazy_replay4(float4& p, float4& s1, float4& s2, OptArgs a, const LazyArgs& z, int from, int to) {
   for (int s = from + 1; s <= to; ++s) {
     if (KIND == DCCF_OPT_ADAM) {
-      a.step_size_neg = z.scal[2 * (s - z.t0)];
-      a.bc2_sqrt = z.scal[2 * (s - z.t0) + 1];
+      const float4 sc = reinterpret_cast<const float4*>(z.scal)[s - z.t0];
+      a.step_size_neg = sc.x; a.bc2_sqrt = sc.y; a.bc2_rsqrt = sc.z;
     }
     float4 g0 = make_float4(0, 0, 0, 0);
     opt_elem<KIND>(p.x, g0.x, s1.x, s2.x, a);

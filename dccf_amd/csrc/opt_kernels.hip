@@ -396,6 +396,7 @@ int opt_make_job(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t
   const double bc1 = 1.0 - pow(0.9, (double)step), bc2 = 1.0 - pow(0.999, (double)step);
   a.step_size_neg = (float)(-((double)lr / bc1));
   a.bc2_sqrt = (float)sqrt(bc2);
+  a.bc2_rsqrt = (float)(1.0 / (double)a.bc2_sqrt);
   out->p = p; out->g = g; out->s1 = s1; out->s2 = s2; out->n = n; out->kind = kind;
   return 0;
 }
@@ -691,7 +692,7 @@ static int lazy_args(const dccf_opt_t* o, const OptJob& j, LazyArgs* z) {
   ARG_CHECK(o->lazy_K >= 2 && o->lazy_last && o->lazy_claim && o->lazy_list && o->lazy_cnt, "lazy optimizer: lazy_K >= 2 and all arrays");
   ARG_CHECK(j.sg.n >= 1, "lazy optimizer needs row segments");
   ARG_CHECK(o->kind != DCCF_OPT_ADAM || (o->lazy_scal && o->lazy_t0 <= max((int64_t)1, o->step - o->lazy_K + 1) &&
-                                         o->step < o->lazy_t0 + o->lazy_nscal),
+                                         o->step < o->lazy_t0 + o->lazy_nscal && (uintptr_t)o->lazy_scal % 16 == 0),
             "lazy optimizer: the step-scalar table does not cover [step - K + 1, step]");
   z->K = o->lazy_K; z->nscal = o->lazy_nscal; z->t0 = o->lazy_t0; z->step = o->step;
   z->pend_slot = (int)((o->step - 1) & 1);
@@ -711,8 +712,11 @@ extern "C" int dccf_lazy_scalars(float lr, int64_t t0, int32_t n, float* out_hos
     const double s = (double)(t0 + i);
     // (step 0 is never applied; its slot keeps the table aligned)
     const double bc1 = 1.0 - pow(0.9, s), bc2 = 1.0 - pow(0.999, s);
-    out_host[2 * i] = s >= 1.0 ? (float)(-((double)lr / bc1)) : 0.f;
-    out_host[2 * i + 1] = s >= 1.0 ? (float)sqrt(bc2) : 1.f;
+    const float c = s >= 1.0 ? (float)sqrt(bc2) : 1.f;
+    out_host[4 * i] = s >= 1.0 ? (float)(-((double)lr / bc1)) : 0.f;
+    out_host[4 * i + 1] = c;
+    out_host[4 * i + 2] = (float)(1.0 / (double)c);
+    out_host[4 * i + 3] = 0.f;
   }
   return 0;
 }
@@ -871,6 +875,48 @@ extern "C" int dccf_advance(int64_t* k_dev, void* stream) {
   return 0;
 }
 
+template <int KIND, int IEEE>
+__global__ void k_debug_opt_elem(float* p, float* g, float* s1, float* s2, int64_t n, OptArgs a, int denom_only) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float pv = p[i], gv = g[i], av = s1 ? s1[i] : 0.f, bv = s2 ? s2[i] : 0.f;
+    if (denom_only) {      // Adam's denominator of the element's second moment AS GIVEN -> g (exhaustive checks of the first division)
+      g[i] = IEEE ? __fadd_rn(__fdiv_rn(__fsqrt_rn(bv), a.bc2_sqrt), 1e-8f)
+                  : __fadd_rn(div_by_uniform(sqrt_bare(bv), a.bc2_sqrt, a.bc2_rsqrt), 1e-8f);
+      continue;
+    }
+    if (IEEE) opt_elem_ieee<KIND>(pv, gv, av, bv, a);
+    else opt_elem<KIND>(pv, gv, av, bv, a);
+    p[i] = pv; g[i] = gv;
+    if (s1) s1[i] = av;
+    if (s2) s2[i] = bv;
+  }
+}
+extern "C" int dccf_debug_opt_elem(int32_t kind, int32_t ieee, float* p, float* g, float* s1, float* s2, int64_t n, float lr,
+                                   float wd, float l2, float clip, int64_t step, void* stream) {
+  ARG_CHECK(p && g && n >= 0 && step >= 1, "NULL p/g, n < 0 or step < 1");
+  ARG_CHECK(kind == DCCF_OPT_GD || kind == DCCF_OPT_ADAGRAD || kind == DCCF_OPT_ADAM, "unknown optimizer kind");
+  ARG_CHECK((kind == DCCF_OPT_GD || s1) && (kind != DCCF_OPT_ADAM || s2), "optimizer state is NULL");
+  ARG_CHECK(ieee >= 0 && ieee <= 3 && (ieee < 2 || kind == DCCF_OPT_ADAM), "ieee is 0 / 1 (a step) or 2 / 3 (Adam's denominator only)");
+  const int denom_only = ieee >> 1;
+  ieee &= 1;
+  if (n == 0) return 0;
+  OptArgs a;
+  a.lr = lr; a.wd = wd; a.l2 = l2; a.clip = clip; a.zero_grad = 0;
+  a.k_dev = nullptr; a.step0 = step;
+  const double bc1 = 1.0 - pow(0.9, (double)step), bc2 = 1.0 - pow(0.999, (double)step);
+  a.step_size_neg = (float)(-((double)lr / bc1));
+  a.bc2_sqrt = (float)sqrt(bc2);
+  a.bc2_rsqrt = (float)(1.0 / (double)a.bc2_sqrt);
+  const int grid = (int)min((int64_t)4096, (n + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+#define DBG_ELEM(K) { if (ieee) hipLaunchKernelGGL((k_debug_opt_elem<K, 1>), dim3(grid), dim3(256), 0, st, p, g, s1, s2, n, a, denom_only); \
+                      else hipLaunchKernelGGL((k_debug_opt_elem<K, 0>), dim3(grid), dim3(256), 0, st, p, g, s1, s2, n, a, denom_only); }
+  if (kind == DCCF_OPT_GD) DBG_ELEM(DCCF_OPT_GD) else if (kind == DCCF_OPT_ADAGRAD) DBG_ELEM(DCCF_OPT_ADAGRAD) else DBG_ELEM(DCCF_OPT_ADAM)
+#undef DBG_ELEM
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 extern "C" int dccf_dense_opt_step(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t n, float lr, float wd,
                                    float l2, float clip, int64_t step, int32_t zero_grad, void* stream) {
   ARG_CHECK(p && g && n >= 0 && step >= 1, "NULL p/g, n < 0 or step < 1");
@@ -888,6 +934,7 @@ extern "C" int dccf_dense_opt_step(int32_t kind, float* p, float* g, float* s1, 
   const double bc1 = 1.0 - pow(0.9, (double)step), bc2 = 1.0 - pow(0.999, (double)step);
   a.step_size_neg = (float)(-((double)lr / bc1));
   a.bc2_sqrt = (float)sqrt(bc2);
+  a.bc2_rsqrt = (float)(1.0 / (double)a.bc2_sqrt);
   const int64_t work = (n + 3) / 4;
   const int grid = (int)min((int64_t)(256 * 16), (work + 255) / 256);
   hipStream_t st = (hipStream_t)stream;

@@ -509,7 +509,7 @@ class DCCF(DMF):
             # (at 2B > 2048 the step touches tens of thousands of rows and the dense pass is a small part of it: measured 5.05 M
             # pairs/s lazy against 5.3 M dense at B = 4096 — the dense pass stays there)
             if (self.lazy_K >= 2 and not overlap and self.row_segments and feed_dict.get('inject') is None
-                    and feed_dict['X'].shape[0] <= 2048):
+                    and feed_dict['X'].shape[0] <= int(os.environ.get('DCCF_LAZY_MAX_N', '2048'))):
                 # windowed lazy regularisation: only 1 / lazy_K of the untouched rows is streamed per step (dccf_opt_t.lazy_*)
                 rows = self.user_num + self.item_num
                 o.lazy = _lib.LazyState(self._opt_struct, self.lazy_K, rows, 16 + 4 * 16384 * (self.sample_num + 2), o.lr, self.device)

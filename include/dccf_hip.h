@@ -195,9 +195,9 @@ typedef struct {
  *              -1 where another slot owns the row
  *   lazy_cnt   int32 [16], zero-initialised: the window whose marks are pending (a step's window is marked by the NEXT
  *              optimizer launch instead of a launch of its own), two records by step parity
-   *   lazy_scal  float [2 * lazy_nscal]: (-(lr / (1 - 0.9^s)), sqrt(1 - 0.999^s)) for s = lazy_t0 .. lazy_t0 + lazy_nscal - 1,
-   *              as dccf_lazy_scalars writes them (the same double arithmetic as the dense launch); must cover
-   *              [step - lazy_K, step] */
+   *   lazy_scal  float [4 * lazy_nscal], 16-byte aligned: (-(lr / (1 - 0.9^s)), c = sqrt(1 - 0.999^s), RN(1 / c), 0) for
+   *              s = lazy_t0 .. lazy_t0 + lazy_nscal - 1, as dccf_lazy_scalars writes them (the same double arithmetic as the
+   *              dense launch); must cover [step - lazy_K, step] */
   int32_t lazy_K;
   int32_t lazy_nscal;
   int32_t* lazy_last;
@@ -207,7 +207,7 @@ typedef struct {
   const float* lazy_scal;
   int64_t lazy_t0;
 } dccf_opt_t;
-/* HOST: out[2 i], out[2 i + 1] = the Adam step scalars of step t0 + i (see lazy_scal), i < n. */
+/* HOST: out[4 i .. 4 i + 3] = the Adam step scalars of step t0 + i (see lazy_scal), i < n. */
 int dccf_lazy_scalars(float lr, int64_t t0, int32_t n, float* out_host);
 /* Brings every row of the segments up to opt->step (rows already there are untouched).  Needs lazy_K > 0. */
 int dccf_lazy_flush(const dccf_opt_t* opt, void* stream);
@@ -416,6 +416,13 @@ int shard_unpack_multi(const shard_job_t* jobs, int32_t njobs, float* zero, int6
 /* ---- the fused-mode random streams written out (for parity tests: fused == injected on the same draws) ---------- */
 int dccf_debug_candidates(int64_t N, int32_t S, int64_t item_num, uint64_t seed, uint64_t step, int64_t* out, void* stream);
 int dccf_debug_noise(int64_t L, int32_t F, float std, uint64_t seed, uint64_t step, float* out, void* stream);
+/* One optimizer step of `kind` (step number `step`) on n elements, element by element: ieee = 0 runs the element function
+ * every optimizer kernel of the library uses (Adam: divisions and square root without the range scaling of the compiler's
+ * IEEE expansions, see opt_device.hpp), ieee = 1 the same step on __fdiv_rn / __fsqrt_rn.  ieee = 2 / 3 (Adam): nothing is
+ * updated; g[i] = sqrt(s2[i]) / sqrt(1 - 0.999^step) + 1e-8 by the library's functions (2) or the IEEE ones (3).  Tests assert
+ * that 0 == 1 and 2 == 3 bit for bit. */
+int dccf_debug_opt_elem(int32_t kind, int32_t ieee, float* p, float* g, float* s1, float* s2, int64_t n, float lr, float wd,
+                        float l2, float clip, int64_t step, void* stream);
 int dccf_debug_keep(int64_t L, int32_t D, float dropout, uint64_t seed, uint64_t step, uint8_t* out, void* stream);
 /* the keep mask of mlp layer `layer` (0 = mlp.0; the extra layers of --n_layers > 1 draw with the layer index in the counter) */
 int dccf_debug_keep_layer(int64_t L, int32_t D, float dropout, uint64_t seed, uint64_t step, int32_t layer, uint8_t* out,

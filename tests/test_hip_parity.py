@@ -387,6 +387,63 @@ def test_dense_optimizer_matches_reference(L, name):
             close(fp.views[k], g[pre + 'after/' + k], 1e-5, 1e-7, name + ' after ' + k)
 
 
+def test_adam_element_function_equals_ieee(L):
+    """The element function every optimizer kernel uses (Adam's divisions as bare Newton steps on v_rcp_f32 / a host-side
+    reciprocal, the bare v_sqrt_f32: opt_device.hpp) against the same step on the compiler's IEEE division and square root:
+    bit-equal (a) for Adam's denominator over EVERY non-negative finite second moment, at step numbers across the range of
+    sqrt(1 - 0.999^t), and (b) for whole element steps on states spread over many orders of magnitude."""
+    d = dev()
+    bits = lambda t: t.view(torch.int32)
+    # (a) exhaustive in v: all 2^31 - 2^23 non-negative finite floats, 2^26 at a time
+    chunk = 1 << 26
+    for step in (1, 2, 3, 7, 40, 333, 1000, 2500, 6000, 20000, 10 ** 6):
+        for c0 in range(0, 0x7f800000, chunk):
+            v = torch.arange(c0, min(c0 + chunk, 0x7f800000), dtype=torch.int32, device=d).view(torch.float32)
+            n = v.numel()
+            z = torch.zeros(n, device=d)
+            ga, gb = torch.empty(n, device=d), torch.empty(n, device=d)
+            L.debug_opt_elem('adam', 2, z, ga, z, v, 1e-3, 1e-4, 1e-4, 50.0, step)
+            L.debug_opt_elem('adam', 3, z, gb, z, v, 1e-3, 1e-4, 1e-4, 50.0, step)
+            assert torch.equal(bits(ga), bits(gb)), (step, c0)
+            if step > 3:
+                break                      # (every v at the first steps — where c is far from 1 — and the low 2^26 at the others)
+    # (b) whole steps: parameters, gradients and moments log-uniform over wide ranges, exact zeros mixed in
+    gen = torch.Generator(device=d).manual_seed(5)
+    n = 1 << 24
+
+    def spread(lo, hi, zero_frac=0.02, signed=True):
+        e = torch.rand(n, generator=gen, device=d) * (hi - lo) + lo
+        x = torch.pow(10.0, e) * (1.0 + torch.rand(n, generator=gen, device=d))
+        if signed:
+            x = x * (torch.randint(0, 2, (n,), generator=gen, device=d).float() * 2 - 1)
+        return torch.where(torch.rand(n, generator=gen, device=d) < zero_frac, torch.zeros_like(x), x).contiguous()
+
+    for step, lr, l2, grad in ((1, 1e-3, 1e-4, True), (2, 1e-3, 1e-4, False), (9, 0.1, 0.0, True), (1500, 1e-3, 1e-4, False),
+                               (100000, 1e-2, 1e-2, True), (7, 1e-3, 1e-4, False)):
+        p0 = spread(-12, 1)
+        g0 = spread(-10, 3) if grad else torch.zeros(n, device=d)           # (beyond +-50: the clip)
+        m0 = spread(-14, 2)
+        v0 = (m0 * m0 * spread(-3, 3, 0.0, signed=False)).contiguous()
+        v0 = torch.where(torch.rand(n, generator=gen, device=d) < 0.02, torch.zeros_like(v0), v0)
+        outs = []
+        for ieee in (0, 1):
+            st = [p0.clone(), g0.clone(), m0.clone(), v0.clone()]
+            for k in range(3):                                               # three steps in a row: the states feed back
+                L.debug_opt_elem('adam', ieee, st[0], st[1], st[2], st[3], lr, l2, l2, 50.0, step + k)
+            outs.append(st)
+        for a, b, nm in zip(outs[0], outs[1], 'pgmv'):
+            assert torch.isfinite(a).all()
+            assert torch.equal(bits(a), bits(b)), (step, nm, int((bits(a) != bits(b)).sum()))
+    # the other optimizers share nothing with the change, but go through the same entry
+    for kind in ('gd', 'adagrad'):
+        outs = []
+        for ieee in (0, 1):
+            st = [p0.clone(), g0.clone(), m0.abs().clone(), v0.clone()]
+            L.debug_opt_elem(kind, ieee, st[0], st[1], st[2], st[3], 1e-2, 1e-4, 1e-4, 50.0, 3)
+            outs.append(st)
+        assert all(torch.equal(bits(a), bits(b)) for a, b in zip(outs[0], outs[1]))
+
+
 def test_dense_optimizer_tail_and_large(L):
     """n not a multiple of 4 and n larger than one grid sweep, against the oracle's optimizer."""
     rng = np.random.RandomState(2)
