@@ -285,7 +285,7 @@ def main():
 
     timed, timed_counts, ev_ms, hosted_rows = profile_structure(full)
     lazy = opt.lazy
-    lazy_rows = int((lazy.list[:2 * B * (S + 2)] >= 0).sum()) if lazy is not None else 0       # distinct rows of the last step
+    lazy_rows = int((lazy.step_list(opt.t, 2 * B * (S + 2)) >= 0).sum()) if lazy is not None else 0       # distinct rows of the last step
     dense_timed = None
     if lazy is not None:
         # the same steps with the dense pass every launch (lazy_K = 0): the HBM-bound form of the optimizer launch, for the record
@@ -333,7 +333,8 @@ def main():
     bwd_tf = (2.0 * L_rows * (D + F) * D + 2.0 * L_rows * D * D) / 1e12
     kernels = {'opt_launch': timed.get('opt_launch', whole_pass_ms), 'noise_fwd': timed['noise_fwd'], 'k_bwd': timed['noise_bwd_eps']}
     if 'lazy_catchup' in timed:
-        kernels['k_lazy_catchup'] = timed['lazy_catchup']
+        kernels['k_lazy_catchup (unprepared steps only: %d of %d; otherwise a role of the previous optimizer launch)'
+                % (timed_counts['lazy_catchup'], n_prof)] = timed['lazy_catchup']
     if 'prep' in timed:
         kernels['k_prep (unprepared steps only: %d of %d)' % (timed_counts['prep'], n_prof)] = timed['prep']
     pmc = None

@@ -19,7 +19,7 @@ EXPORTS = ['dccf_ctx_create', 'dccf_ctx_destroy', 'dccf_ctx_reserve', 'dccf_last
            'dccf_sample_eval_negatives', 'dccf_eval_prepare', 'dccf_predict_projected', 'dccf_dp_local', 'dccf_dp_overlap',
            'dccf_dp_finish', 'dccf_ctx_prepared_steps', 'dccf_ctx_hosted_rows', 'shard_pack_multi', 'shard_unpack_multi', 'dccf_build_epoch_batches', 'dccf_lazy_scalars', 'dccf_lazy_flush']
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 OPT_KIND = {'gd': 0, 'adagrad': 1, 'adam': 2}
 MF_KIND = {'RecModel': 0, 'BiasedMF': 1, 'IPSBiasedMF': 2}
 
@@ -52,7 +52,7 @@ class OptT(C.Structure):
                 ('seg_flags', _f),
                 # windowed lazy regularisation (include/dccf_hip.h: dccf_opt_t.lazy_*)
                 ('lazy_K', C.c_int32), ('lazy_nscal', C.c_int32), ('lazy_last', _f), ('lazy_claim', _f), ('lazy_list', _f),
-                ('lazy_cnt', _f), ('lazy_scal', _f), ('lazy_t0', C.c_int64)]
+                ('lazy_cnt', _f), ('lazy_scal', _f), ('lazy_t0', C.c_int64), ('lazy_list_cap', C.c_int64), ('lazy_id', C.c_int64)]
 
 
 class DpT(C.Structure):
@@ -330,12 +330,14 @@ class LazyState(object):
     """The arrays of the windowed lazy regularisation of a dccf_opt_t (include/dccf_hip.h), owned here as torch tensors: per-row
     step counters, claims, the step's row list, and the table of Adam step scalars (refilled when the step runs off its end)."""
     NSCAL = 1 << 15
+    _ids = 0
 
     def __init__(self, opt, K, n_rows, list_cap, lr, device):
         self.opt, self.K, self.lr = opt, int(K), float(lr)
         self.last = torch.zeros(n_rows, dtype=torch.int32, device=device)
-        self.claim = torch.zeros(n_rows, dtype=torch.int32, device=device)
-        self.list = torch.zeros(list_cap, dtype=torch.int32, device=device)
+        self.claim = torch.zeros(2 * n_rows, dtype=torch.int32, device=device)        # by step parity (include/dccf_hip.h)
+        self.list_cap = int(list_cap)
+        self.list = torch.zeros(2 * self.list_cap, dtype=torch.int32, device=device)
         self.cnt = torch.zeros(16, dtype=torch.int32, device=device)      # the pending-window records (include/dccf_hip.h)
         self.scal = torch.zeros(4 * self.NSCAL, dtype=torch.float32, device=device)
         self.t0 = -1
@@ -344,6 +346,14 @@ class LazyState(object):
         opt.lazy_last, opt.lazy_claim = ptr(self.last, torch.int32), ptr(self.claim, torch.int32)
         opt.lazy_list, opt.lazy_cnt = ptr(self.list, torch.int32), ptr(self.cnt, torch.int32)
         opt.lazy_scal = ptr(self.scal, torch.float32)
+        opt.lazy_list_cap = self.list_cap
+        LazyState._ids += 1
+        opt.lazy_id = LazyState._ids
+
+    def step_list(self, step, n):
+        """The first n slots of the row list of optimizer step `step`."""
+        o = (int(step) & 1) * self.list_cap
+        return self.list[o:o + n]
 
     def cover(self, step):
         """Makes the scalar table cover [step - K + 1, step] (and a long stretch beyond)."""

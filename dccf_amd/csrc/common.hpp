@@ -6,7 +6,7 @@
 #include <string.h>
 #include "../../include/dccf_hip.h"
 
-#define DCCF_ABI_VERSION 4
+#define DCCF_ABI_VERSION 5
 #pragma clang fp contract(off)
 
 // ---------------------------------------------------------------------------------------------- errors
@@ -47,6 +47,9 @@ struct dccf_ctx {
   hipEvent_t ev_fork, ev_join;
   // what the last dccf_train_step prepared for the next one (candidates, exposures, W^T, zeroed accumulators)
   int prep_valid;
+  int64_t lazy_prep_step;        // optimizer step whose rows the last lazy optimizer launch claimed and caught up (-1: none)
+  const void* lazy_prep_claim;   // ... in this claim array
+  int64_t lazy_prep_id;          // ... of the arrays the caller named so (dccf_opt_t.lazy_id)
   int64_t prep_hits;
   const void* prep_X;
   const void* prep_U;
@@ -121,6 +124,8 @@ int dccf_opt_untouched_prep(const void* o, uint8_t* const* flags, const PrepNext
 // item segment) are claimed, listed and brought up to step - 1; then the step's optimizer launch
 int dccf_lazy_catchup(const void* o, const int64_t* X, const int* cand, int64_t N, int S1, int segU, int segV, hipStream_t st);
 int dccf_lazy_step(const void* o, const PrepNext* pn, int64_t nslots, hipStream_t st);      // nslots = N (S + 2) of the catch-up
+// claims somebody made for `step` (pn.cu_blocks of the previous launch) for a batch that did not come: forgotten
+int dccf_lazy_reset_claims(const void* o, hipStream_t st);
 // replicated multi-GPU path (dp_kernels.hip): rows flagged in (flags0, flags1) of segments (seg0, seg1) claimed + caught up;
 // phase 1 = window + marks + next-step preparation; everything brought to step - 1
 int dccf_lazy_catchup_flags(const void* o, const uint8_t* flags0, const uint8_t* flags1, int seg0, int seg1, hipStream_t st);
@@ -323,6 +328,9 @@ struct PrepNext {
   uint32_t* nmask;
   int* nwhere;
   int64_t R, offU, offV;     // rows of all segments; first global row index of the user / item segment
+  // windowed lazy regularisation (k_lazy_opt): cu_blocks > 0 = that many workgroups claim, list and catch up the rows of the
+  // NEXT step (its users X[.][0], true items and Philox candidates, recomputed from `key`) inside this step's optimizer launch
+  int cu_blocks, cu_segU, cu_segV;
 };
 
 __device__ __forceinline__ void prep_next_slots(const PrepNext& pn, int64_t tid, int64_t nthreads) {

@@ -36,6 +36,7 @@ struct Knobs {
   int64_t hosted_wgs;     // DCCF_HOSTED_WGS   workgroups of a hosted optimizer pass
   bool hostv;             // DCCF_NO_HOSTV=1   turns the hosted item-table pass off
   int64_t bwd_wgs;        // DCCF_BWD_WGS      role workgroups of the backward at 2B < 2048 (row splits = this / roles)
+  bool lazy_cu;           // DCCF_LAZY_NO_CU=1 the lazy optimizer launch does not catch up the next step's rows (a launch of its own does)
 };
 static const Knobs& knobs() {
   static const Knobs k = [] {
@@ -45,6 +46,7 @@ static const Knobs& knobs() {
     q.hosted_wgs = getenv("DCCF_HOSTED_WGS") ? atoll(getenv("DCCF_HOSTED_WGS")) : 256;
     q.hostv = getenv("DCCF_NO_HOSTV") == nullptr;
     q.bwd_wgs = getenv("DCCF_BWD_WGS") ? atoll(getenv("DCCF_BWD_WGS")) : 256;
+    q.lazy_cu = getenv("DCCF_LAZY_NO_CU") == nullptr;
     return q;
   }();
   return k;
@@ -1298,10 +1300,19 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     prof_end(ctx, 0, st);
   }
   if (lazy) {
-    // the rows this step reads (its users and candidates, known now) are brought up to the previous step before anything reads them
-    prof_begin(ctx, st);
-    if (int e = dccf_lazy_catchup(plan->opt, X, cand, N, S1, plan->lazy_segU, plan->lazy_segV, st)) return e;
-    prof_end(ctx, 7, st);
+    // the rows this step reads (its users and candidates) must be at the previous step before anything reads them.  The
+    // optimizer launch of the previous step did that when it knew this batch (pn.cu_blocks); otherwise a launch of its own
+    const bool mine = ctx->lazy_prep_step == (int64_t)plan->opt->step && ctx->lazy_prep_claim == (const void*)plan->opt->lazy_claim &&
+                      ctx->lazy_prep_id == plan->opt->lazy_id;
+    if (!(mine && prepared)) {
+      // (claims made for this step number on behalf of a batch that did not come must not shadow the real rows)
+      if (mine)
+        if (int e = dccf_lazy_reset_claims(plan->opt, st)) return e;
+      prof_begin(ctx, st);
+      if (int e = dccf_lazy_catchup(plan->opt, X, cand, N, S1, plan->lazy_segU, plan->lazy_segV, st)) return e;
+      prof_end(ctx, 7, st);
+    }
+    ctx->lazy_prep_step = -1;
   }
   if (plan && plan->overlap && !plan->hosted) {
     // fork: rows NOT on this batch's list see only the l2 term -> their optimizer pass needs nothing from this step
@@ -1483,8 +1494,18 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
         pn.w_begin = M->W - plan->opt->p;
         pn.w_end = pn.w_begin + (int64_t)D * (D + F);
         pn.blocks = (int)min((int64_t)64, (y.NS + pn.Lm + 255) / 256);
+        if (knobs().lazy_cu) {
+          pn.cu_blocks = (int)min((int64_t)256, (N * (int64_t)(S1 + 1) + 3) / 4);
+          pn.cu_segU = plan->lazy_segU;
+          pn.cu_segV = plan->lazy_segV;
+        }
         if (int e = dccf_lazy_step(plan->opt, &pn, N * (int64_t)(S1 + 1), st)) return e;
         dccf_prep_next_commit(ctx, M, N, plan->X_next, rnd->seed, plan->step_next);
+        if (pn.cu_blocks) {
+          ctx->lazy_prep_step = (int64_t)plan->opt->step + 1;
+          ctx->lazy_prep_claim = plan->opt->lazy_claim;
+          ctx->lazy_prep_id = plan->opt->lazy_id;
+        }
       } else {
         if (int e = dccf_lazy_step(plan->opt, nullptr, N * (int64_t)(S1 + 1), st)) return e;
       }

@@ -186,14 +186,18 @@ struct LazyArgs {
   int K, nscal;
   int64_t t0, step;          // scal[4 (s - t0) ..+2] = {step_size_neg, bc2_sqrt, bc2_rsqrt} of step s
   int* last;
-  int* claim;
-  int* list;
+  int* claim;                // two arrays of R entries by step parity (lazy_claim_of): launch t reads the claims of step t while its
+  int* list;                 // catch-up role writes those of step t + 1; likewise two lists of list_cap slots (lazy_list_of)
+  int64_t R, list_cap;       // rows of all segments; slots of ONE list
   int* cnt;
   int pend_slot;             // which record of cnt this launch READS: (step - 1) & 1 for a step, step & 1 for a flush
   const float* scal;
   int64_t row_off[4];        // first global row of segment q
   int64_t rows[4];
 };
+
+__device__ __forceinline__ int* lazy_claim_of(const LazyArgs& z, int t) { return z.claim + (int64_t)(t & 1) * z.R; }
+__device__ __forceinline__ int* lazy_list_of(const LazyArgs& z, int t) { return z.list + (int64_t)(t & 1) * z.list_cap; }
 
 // The window of the PREVIOUS lazy step is marked one launch late (its rows' `last` entries are written by the next optimizer
 // launch instead of a launch of their own): until then a row of that window that was behind counts as being at that step.
@@ -254,6 +258,7 @@ __device__ __forceinline__ void lazy_window_pass(float* __restrict__ p, float* _
                                                  int flush, int64_t bid, int64_t nblk, int nthreads) {
   const int t = (int)z.step;
   const LazyPend pend = lazy_pend_read(z);
+  const int* __restrict__ claim = lazy_claim_of(z, t);
   for (int q = 0; q < sg.n; ++q) {
     const int64_t r0 = max(win0, z.row_off[q]) - z.row_off[q], r1 = min(win1, z.row_off[q] + z.rows[q]) - z.row_off[q];
     if (r1 <= r0) continue;
@@ -264,7 +269,7 @@ __device__ __forceinline__ void lazy_window_pass(float* __restrict__ p, float* _
       const int64_t grow = z.row_off[q] + row;
       const int from = lazy_eff_last(z, pend, grow);
       // a row this step touched is the list's business (its last is t - 1 until that wave has updated it: never replay it here)
-      if (from >= t || (!flush && z.claim[grow] == t)) continue;
+      if (from >= t || (!flush && claim[grow] == t)) continue;
       const int64_t i = (sg.begin[q] >> 2) + row * w4 + x % w4;
       float4 pv = reinterpret_cast<float4*>(p)[i];
       float4 av = make_float4(0, 0, 0, 0), bv = make_float4(0, 0, 0, 0);

@@ -37,6 +37,9 @@ extern "C" int dccf_ctx_create(dccf_ctx** out, int device) {
   c->tl_cnt = nullptr;
   c->tl_parity = 0;
   c->prep_valid = 0;
+  c->lazy_prep_step = -1;
+  c->lazy_prep_claim = nullptr;
+  c->lazy_prep_id = 0;
   c->prep_hits = 0;
   c->prep_dp = c->prep_pending = c->prep_parity = 0;
   c->prep_tables = c->cur_tables = 0;
@@ -571,6 +574,8 @@ __global__ __launch_bounds__(256) void k_lazy_catchup(float* __restrict__ p, flo
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int64_t slots = N * S1 + N;
   const int t = (int)z.step;
+  int* claim = lazy_claim_of(z, t);
+  int* list = lazy_list_of(z, t);
   for (int64_t j = wave; j < slots; j += nw) {
     int q;
     int64_t row;
@@ -578,8 +583,8 @@ __global__ __launch_bounds__(256) void k_lazy_catchup(float* __restrict__ p, flo
     const int64_t grow = z.row_off[q] + row;
     int won = 0;
     if (lane == 0) {
-      won = atomicMax(&z.claim[grow], t) < t ? 1 : 0;
-      z.list[j] = won ? (int)grow : -1;        // the step's rows, one entry per slot (-1: another slot owns the row): no shared
+      won = atomicMax(&claim[grow], t) < t ? 1 : 0;
+      list[j] = won ? (int)grow : -1;        // the step's rows, one entry per slot (-1: another slot owns the row): no shared
     }                                          // counter — 3,000 appends to one address took 40 us
     won = __shfl(won, 0, 64);
     if (!won) continue;
@@ -617,9 +622,67 @@ __global__ __launch_bounds__(256) void k_lazy_opt(float* __restrict__ p, float* 
   const int t = (int)z.step;
   int bid = (int)blockIdx.x - pn.blocks;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (bid < pn.cu_blocks) {
+    // ---- the rows of the NEXT step (known: X_next, and its candidates are a counter-based stream): claimed (the winner of a
+    // row's slots lists it) and brought up to THIS step — unless another role of this launch does that: a row on this step's
+    // list (claim of step t) gets step t there, a row of this step's window is advanced there.  Claims and lists are kept
+    // per step parity, so what this role writes is not what the other roles read.  The next step then starts with its forward.
+    const int S1 = pn.S + 1;
+    const int64_t NS = pn.N * S1, slots = NS + pn.N;
+    const int* __restrict__ claim_t = lazy_claim_of(z, t);
+    int* claim_n = lazy_claim_of(z, t + 1);
+    int* list_n = lazy_list_of(z, t + 1);
+    const LazyPend pend = lazy_pend_read(z);
+    for (int64_t j = (int64_t)bid * 4 + wv; j < slots; j += (int64_t)pn.cu_blocks * 4) {
+      int q;
+      int64_t row;
+      if (j < NS) {
+        const int64_t n = j / S1;
+        const int sl = (int)(j % S1);
+        q = pn.cu_segV;
+        if (sl == 0) {
+          row = pn.X[2 * n + 1];
+        } else {
+          const u32x4 rr = philox4x32_10((uint32_t)n, (uint32_t)((sl - 1) >> 2), pn.key.s0, pn.key.s1, pn.key.k0, pn.key.k1);
+          row = (int64_t)(((uint64_t)pick4(rr, (sl - 1) & 3) * (uint64_t)pn.M.item_num) >> 32);
+        }
+      } else {
+        q = pn.cu_segU;
+        row = pn.X[2 * (j - NS)];
+      }
+      const int64_t grow = z.row_off[q] + row;
+      int won = 0;
+      if (lane == 0) {
+        won = atomicMax(&claim_n[grow], t + 1) < t + 1 ? 1 : 0;
+        list_n[j] = won ? (int)grow : -1;
+      }
+      won = __shfl(won, 0, 64);
+      if (!won) continue;
+      if (claim_t[grow] == t) continue;                         // this step's list role
+      if (grow >= win0 && grow < win1) continue;                // this step's window role
+      const int from = __builtin_amdgcn_readfirstlane(lazy_eff_last(z, pend, grow));
+      if (from >= t) continue;
+      const int w = sg.width[q];
+      float* pr = p + sg.begin[q] + row * w;
+      float* ar = s1 ? s1 + sg.begin[q] + row * w : nullptr;
+      float* br = s2 ? s2 + sg.begin[q] + row * w : nullptr;
+      for (int c = lane; c < w; c += 64) {
+        float pv = pr[c], av = KIND != DCCF_OPT_GD ? ar[c] : 0.f, bv = KIND == DCCF_OPT_ADAM ? br[c] : 0.f;
+        lazy_replay<KIND>(pv, av, bv, a, z, from, t);
+        pr[c] = pv;
+        if (KIND != DCCF_OPT_GD) ar[c] = av;
+        if (KIND == DCCF_OPT_ADAM) br[c] = bv;
+      }
+      // (the marks role of this launch may be writing the pending window's step into the same entry: both are maxima)
+      if (lane == 0) atomicMax(&z.last[grow], t);
+    }
+    return;
+  }
+  bid -= pn.cu_blocks;
   if (bid < lb) {                              // ---- the rows this step touched
+    const int* __restrict__ list = lazy_list_of(z, t);
     for (int e = bid * 4 + wv; e < nslots; e += lb * 4) {
-      const int64_t grow = z.list[e];
+      const int64_t grow = list[e];
       if (grow < 0) continue;
       int q = 0;
 #pragma unroll
@@ -662,7 +725,7 @@ __global__ __launch_bounds__(256) void k_lazy_opt(float* __restrict__ p, float* 
     return;
   }
   bid -= db;
-  const int wb = (int)gridDim.x - pn.blocks - lb - db - mb;
+  const int wb = (int)gridDim.x - pn.blocks - pn.cu_blocks - lb - db - mb;
   if (bid < wb) {                              // ---- the window (unless the backward launch hosted it)
     lazy_window_pass<KIND>(p, s1, s2, a, sg, z, win0, win1, flush, bid, wb, blockDim.x);
     return;
@@ -670,8 +733,9 @@ __global__ __launch_bounds__(256) void k_lazy_opt(float* __restrict__ p, float* 
   bid -= wb;
   // ---- the PREVIOUS lazy step's window gets its marks now (that launch is complete), and this launch's window is recorded
   const LazyPend pend = lazy_pend_read(z);
+  const int* __restrict__ claim = lazy_claim_of(z, t);
   for (int64_t r = pend.w0 + (int64_t)bid * blockDim.x + threadIdx.x; r < pend.w1; r += (int64_t)mb * blockDim.x)
-    if (z.last[r] < pend.t && z.claim[r] != t) z.last[r] = pend.t;
+    if (z.last[r] < pend.t && claim[r] != t) atomicMax(&z.last[r], pend.t);      // (a maximum: the catch-up role may be writing t)
   if (bid == 0 && threadIdx.x == 0) {
     int* w = z.cnt + 5 * (t & 1);
     w[0] = t;
@@ -684,12 +748,13 @@ __global__ __launch_bounds__(256) void k_lazy_opt(float* __restrict__ p, float* 
 __global__ __launch_bounds__(256) void k_lazy_mark(LazyArgs z, int64_t win0, int64_t win1, int flush) {
   const int t = (int)z.step;
   for (int64_t r = win0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < win1; r += (int64_t)gridDim.x * blockDim.x)
-    if (z.last[r] < t && (flush || z.claim[r] != t)) z.last[r] = t;
+    if (z.last[r] < t && (flush || lazy_claim_of(z, t)[r] != t)) z.last[r] = t;
   if (blockIdx.x == 0 && threadIdx.x < 10) z.cnt[threadIdx.x] = threadIdx.x % 5 == 0 ? -1 : 0;      // nothing is pending after a flush
 }
 
 static int lazy_args(const dccf_opt_t* o, const OptJob& j, LazyArgs* z) {
-  ARG_CHECK(o->lazy_K >= 2 && o->lazy_last && o->lazy_claim && o->lazy_list && o->lazy_cnt, "lazy optimizer: lazy_K >= 2 and all arrays");
+  ARG_CHECK(o->lazy_K >= 2 && o->lazy_last && o->lazy_claim && o->lazy_list && o->lazy_cnt && o->lazy_list_cap > 0,
+            "lazy optimizer: lazy_K >= 2 and all arrays");
   ARG_CHECK(j.sg.n >= 1, "lazy optimizer needs row segments");
   ARG_CHECK(o->kind != DCCF_OPT_ADAM || (o->lazy_scal && o->lazy_t0 <= max((int64_t)1, o->step - o->lazy_K + 1) &&
                                          o->step < o->lazy_t0 + o->lazy_nscal && (uintptr_t)o->lazy_scal % 16 == 0),
@@ -703,6 +768,18 @@ static int lazy_args(const dccf_opt_t* o, const OptJob& j, LazyArgs* z) {
     z->rows[q] = q < j.sg.n ? (j.sg.end[q] - j.sg.begin[q]) / j.sg.width[q] : 0;
     off += z->rows[q];
   }
+  z->R = off;
+  z->list_cap = o->lazy_list_cap;
+  return 0;
+}
+
+int dccf_lazy_reset_claims(const void* ov, hipStream_t st) {
+  const dccf_opt_t* o = (const dccf_opt_t*)ov;
+  OptJob j;
+  if (int e = opt_job(ov, &j)) return e;
+  LazyArgs z;
+  if (int e = lazy_args(o, j, &z)) return e;
+  HIP_TRY(hipMemsetAsync(z.claim + (o->step & 1) * z.R, 0, (size_t)z.R * sizeof(int), st));
   return 0;
 }
 
@@ -730,6 +807,7 @@ int dccf_lazy_catchup(const void* ov, const int64_t* X, const int* cand, int64_t
   ARG_CHECK(segU >= 0 && segU < j.sg.n && segV >= 0 && segV < j.sg.n, "bad segment index");
   const int64_t slots = N * S1 + N;
   if (slots == 0) return 0;
+  ARG_CHECK(slots <= z.list_cap, "lazy optimizer: the step's row list is too short (lazy_list_cap)");
   const int grid = (int)min((int64_t)2048, (slots + 3) / 4);
   BY_KIND(j.kind, k_lazy_catchup, dim3(grid), dim3(256), 0, st, j.p, j.s1, j.s2, j.a, j.sg, z, X, cand, N, S1, segU, segV);
   HIP_TRY(hipGetLastError());
@@ -757,7 +835,9 @@ static int lazy_launch(const dccf_opt_t* o, int flush, const PrepNext* pnp, int6
   const int db = flush ? 0 : (int)min((int64_t)256, (dense_total + 255) / 256);
   const int wb = (int)max((int64_t)1, min((int64_t)8192, ((win1 - win0) * maxw4 + 255) / 256));
   const int mb = flush ? 0 : 32;       // (a flush marks with a launch of its own: every row, and nothing stays pending)
-  const int grid = pn.blocks + lb + db + wb + mb;
+  ARG_CHECK(nslots <= z.list_cap && (pn.cu_blocks == 0 || pn.N * (pn.S + 2) <= z.list_cap), "lazy optimizer: lazy_list_cap too small");
+  if (flush) pn.cu_blocks = 0;
+  const int grid = pn.blocks + pn.cu_blocks + lb + db + wb + mb;
   BY_KIND(j.kind, k_lazy_opt, dim3(grid), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.a, j.sg, ds, z, lb, db, mb, win0, win1, flush,
           (int)nslots, pn);
   if (flush)
@@ -795,7 +875,7 @@ __global__ __launch_bounds__(256) void k_lazy_catchup_flags(float* __restrict__ 
         bits &= bits - 1;
         const int64_t row = r0 + b, grow = z.row_off[q] + row;
         const int from = __builtin_amdgcn_readfirstlane(lazy_eff_last(z, pend, grow));
-        if (lane == 0) z.claim[grow] = t;
+        if (lane == 0) lazy_claim_of(z, t)[grow] = t;
         if (from >= t - 1) continue;
         float* pr = p + sg.begin[q] + row * w;
         float* ar = s1 ? s1 + sg.begin[q] + row * w : nullptr;
@@ -847,6 +927,7 @@ int dccf_lazy_phase1(const void* ov, const PrepNext* pnp, hipStream_t st) {
   for (int q = 0; q < j.sg.n; ++q) maxw4 = max(maxw4, j.sg.width[q] >> 2);
   const int wb = (int)max((int64_t)1, min((int64_t)8192, ((win1 - win0) * maxw4 + 255) / 256));
   const int mb = 32;
+  pn.cu_blocks = 0;
   BY_KIND(j.kind, k_lazy_opt, dim3(pn.blocks + wb + mb), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.a, j.sg, ds, z, 0, 0, mb, win0, win1,
           0, 0, pn);
   HIP_TRY(hipGetLastError());

@@ -517,7 +517,7 @@ class DCCF(DMF):
         g = self.grads
         o.t += 1
         if o.lazy is not None:
-            if feed_dict['X'].shape[0] * (self.sample_num + 2) > o.lazy.list.numel():
+            if feed_dict['X'].shape[0] * (self.sample_num + 2) > o.lazy.list_cap:
                 raise RuntimeError('batch too large for the lazy optimizer row list')
             o.lazy.cover(o.t)
             o.lazy.dirty = True

@@ -190,9 +190,10 @@ typedef struct {
    * (k_lazy_catchup, before the forward).  dccf_lazy_flush brings every row up to date (before evaluation, checkpoints, l2,
    * or any dense call).  All arrays are the caller's, in HBM:
    *   lazy_last  int32 [rows of all segments, segment after segment]: steps applied to the row so far
-   *   lazy_claim int32 [same]: the last step that used the row (0-initialised)
-   *   lazy_list  int32 [>= N (S + 2)]: the rows of the running step, one entry per (row of X, candidate) slot and per user slot,
- *              -1 where another slot owns the row
+   *   lazy_claim int32 [2 x the same], 0-initialised: the last step of each parity that used the row (two arrays: the
+   *              optimizer launch of step t claims the rows of step t + 1 while its other roles read the claims of step t)
+   *   lazy_list  int32 [2 x lazy_list_cap], lazy_list_cap >= N (S + 2): the rows of a step, one entry per (row of X, candidate)
+   *              slot and per user slot, -1 where another slot owns the row; by step parity like the claims
  *   lazy_cnt   int32 [16], zero-initialised: the window whose marks are pending (a step's window is marked by the NEXT
  *              optimizer launch instead of a launch of its own), two records by step parity
    *   lazy_scal  float [4 * lazy_nscal], 16-byte aligned: (-(lr / (1 - 0.9^s)), c = sqrt(1 - 0.999^s), RN(1 / c), 0) for
@@ -206,6 +207,9 @@ typedef struct {
   int32_t* lazy_cnt;
   const float* lazy_scal;
   int64_t lazy_t0;
+  int64_t lazy_list_cap;
+  int64_t lazy_id;       /* names THIS set of lazy_* arrays: a new value whenever they are re-created or cleared (the context
+                          * remembers for which arrays the previous optimizer launch claimed the next step's rows) */
 } dccf_opt_t;
 /* HOST: out[4 i .. 4 i + 3] = the Adam step scalars of step t0 + i (see lazy_scal), i < n. */
 int dccf_lazy_scalars(float lr, int64_t t0, int32_t n, float* out_host);
