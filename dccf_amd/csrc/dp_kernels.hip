@@ -629,8 +629,15 @@ extern "C" int dccf_dp_local(dccf_ctx* ctx, const dccf_model_t* model, const dcc
     // rows ANY rank touches this step: known as bytes when the previous step prepared this one -> claimed and brought up to
     // step - 1 before the forward reads them; otherwise the whole table is brought up to date first, and the rows are claimed
     // once the export launch below has marked them
+    // (phase 1 of the previous step does the claiming and the catch-up itself when it knows this step: pn.cu_blocks)
+    const bool mine = ctx->lazy_prep_step == (int64_t)opt->step && ctx->lazy_prep_claim == (const void*)opt->lazy_claim &&
+                      ctx->lazy_prep_id == opt->lazy_id;
+    if (mine && !prepared)
+      if (int e = dccf_lazy_reset_claims(opt, st)) return e;
+    ctx->lazy_prep_step = -1;
     if (prepared) {
-      if (int e = dccf_lazy_catchup_flags(opt, dp_gflags(dp, parity, 0), dp_gflags(dp, parity, 1), dp->segU, dp->segV, st)) return e;
+      if (!mine)
+        if (int e = dccf_lazy_catchup_flags(opt, dp_gflags(dp, parity, 0), dp_gflags(dp, parity, 1), dp->segU, dp->segV, st)) return e;
     } else {
       if (int e = dccf_lazy_flush_to_prev(opt, st)) return e;
     }
@@ -761,7 +768,18 @@ extern "C" int dccf_dp_overlap(const dccf_opt_t* opt, const dccf_dp_t* dp, int32
   ctx->prep_dp = 0;
   ctx->prep_pending = 1;             // committed by dccf_dp_finish (W^T is written there)
   ctx->prep_parity = 1 - parity;
-  if (opt->lazy_K > 0) return dccf_lazy_phase1(opt, &pn, (hipStream_t)stream);
+  if (opt->lazy_K > 0) {
+    // the rows ANY rank touches at the next step are claimed and caught up here too, while the all-gather is in flight
+    const int64_t slots = (int64_t)dp->G * next->N * (M->S + 2);
+    pn.cu_blocks = (int)max((int64_t)1, min((int64_t)1024, (slots + 3) / 4));
+    pn.cu_segU = dp->segU;
+    pn.cu_segV = dp->segV;
+    if (int e = dccf_lazy_phase1(opt, &pn, (hipStream_t)stream)) return e;
+    ctx->lazy_prep_step = (int64_t)opt->step + 1;
+    ctx->lazy_prep_claim = opt->lazy_claim;
+    ctx->lazy_prep_id = opt->lazy_id;
+    return 0;
+  }
   return dccf_opt_untouched_prep(opt, gf, &pn, (hipStream_t)stream);
 }
 

@@ -628,12 +628,18 @@ __global__ __launch_bounds__(256) void k_lazy_opt(float* __restrict__ p, float* 
     // list (claim of step t) gets step t there, a row of this step's window is advanced there.  Claims and lists are kept
     // per step parity, so what this role writes is not what the other roles read.  The next step then starts with its forward.
     const int S1 = pn.S + 1;
-    const int64_t NS = pn.N * S1, slots = NS + pn.N;
+    // (replicated multi-GPU step: the rows of EVERY rank's next batch, from the replicated schedule; no list — the import
+    // works from its own tables)
+    const int G = pn.X_all ? pn.G : 1;
+    const int64_t NS = pn.N * S1, per_rank = NS + pn.N, slots = (int64_t)G * per_rank;
     const int* __restrict__ claim_t = lazy_claim_of(z, t);
     int* claim_n = lazy_claim_of(z, t + 1);
-    int* list_n = lazy_list_of(z, t + 1);
+    int* list_n = pn.X_all ? nullptr : lazy_list_of(z, t + 1);
     const LazyPend pend = lazy_pend_read(z);
-    for (int64_t j = (int64_t)bid * 4 + wv; j < slots; j += (int64_t)pn.cu_blocks * 4) {
+    for (int64_t jg = (int64_t)bid * 4 + wv; jg < slots; jg += (int64_t)pn.cu_blocks * 4) {
+      const int r = (int)(jg / per_rank);
+      const int64_t j = jg - (int64_t)r * per_rank;
+      const int64_t* __restrict__ Xr = pn.X_all ? pn.X_all + (int64_t)r * pn.N * 2 : pn.X;
       int q;
       int64_t row;
       if (j < NS) {
@@ -641,20 +647,21 @@ __global__ __launch_bounds__(256) void k_lazy_opt(float* __restrict__ p, float* 
         const int sl = (int)(j % S1);
         q = pn.cu_segV;
         if (sl == 0) {
-          row = pn.X[2 * n + 1];
+          row = Xr[2 * n + 1];
         } else {
-          const u32x4 rr = philox4x32_10((uint32_t)n, (uint32_t)((sl - 1) >> 2), pn.key.s0, pn.key.s1, pn.key.k0, pn.key.k1);
+          const rng_key key = pn.X_all ? key_plus(pn.gkey0, r) : pn.key;
+          const u32x4 rr = philox4x32_10((uint32_t)n, (uint32_t)((sl - 1) >> 2), key.s0, key.s1, key.k0, key.k1);
           row = (int64_t)(((uint64_t)pick4(rr, (sl - 1) & 3) * (uint64_t)pn.M.item_num) >> 32);
         }
       } else {
         q = pn.cu_segU;
-        row = pn.X[2 * (j - NS)];
+        row = Xr[2 * (j - NS)];
       }
       const int64_t grow = z.row_off[q] + row;
       int won = 0;
       if (lane == 0) {
         won = atomicMax(&claim_n[grow], t + 1) < t + 1 ? 1 : 0;
-        list_n[j] = won ? (int)grow : -1;
+        if (list_n) list_n[j] = won ? (int)grow : -1;
       }
       won = __shfl(won, 0, 64);
       if (!won) continue;
@@ -835,7 +842,7 @@ static int lazy_launch(const dccf_opt_t* o, int flush, const PrepNext* pnp, int6
   const int db = flush ? 0 : (int)min((int64_t)256, (dense_total + 255) / 256);
   const int wb = (int)max((int64_t)1, min((int64_t)8192, ((win1 - win0) * maxw4 + 255) / 256));
   const int mb = flush ? 0 : 32;       // (a flush marks with a launch of its own: every row, and nothing stays pending)
-  ARG_CHECK(nslots <= z.list_cap && (pn.cu_blocks == 0 || pn.N * (pn.S + 2) <= z.list_cap), "lazy optimizer: lazy_list_cap too small");
+  ARG_CHECK(nslots <= z.list_cap && (pn.cu_blocks == 0 || pn.X_all || pn.N * (pn.S + 2) <= z.list_cap), "lazy optimizer: lazy_list_cap too small");
   if (flush) pn.cu_blocks = 0;
   const int grid = pn.blocks + pn.cu_blocks + lb + db + wb + mb;
   BY_KIND(j.kind, k_lazy_opt, dim3(grid), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.a, j.sg, ds, z, lb, db, mb, win0, win1, flush,
@@ -927,8 +934,7 @@ int dccf_lazy_phase1(const void* ov, const PrepNext* pnp, hipStream_t st) {
   for (int q = 0; q < j.sg.n; ++q) maxw4 = max(maxw4, j.sg.width[q] >> 2);
   const int wb = (int)max((int64_t)1, min((int64_t)8192, ((win1 - win0) * maxw4 + 255) / 256));
   const int mb = 32;
-  pn.cu_blocks = 0;
-  BY_KIND(j.kind, k_lazy_opt, dim3(pn.blocks + wb + mb), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.a, j.sg, ds, z, 0, 0, mb, win0, win1,
+  BY_KIND(j.kind, k_lazy_opt, dim3(pn.blocks + pn.cu_blocks + wb + mb), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.a, j.sg, ds, z, 0, 0, mb, win0, win1,
           0, 0, pn);
   HIP_TRY(hipGetLastError());
   return 0;
