@@ -17,7 +17,7 @@ EXPORTS = ['dccf_ctx_create', 'dccf_ctx_destroy', 'dccf_ctx_reserve', 'dccf_last
            'shard_pack_rows', 'shard_unpack_rows', 'shard_scatter_add', 'dccf_dense_opt_step_rows', 'dccf_dense_opt_step_dev', 'dccf_advance', 'rank_eval_topk', 'dccf_train_step', 'dp_buffer_words',
            'dp_export_touched', 'dp_import_touched', 'dp_mark_global', 'dccf_dense_opt_phase', 'dccf_ctx_side_stream', 'dp_import_apply',
            'dccf_sample_eval_negatives', 'dccf_eval_prepare', 'dccf_predict_projected', 'dccf_dp_local', 'dccf_dp_overlap',
-           'dccf_dp_finish', 'dccf_ctx_prepared_steps', 'dccf_ctx_hosted_rows', 'shard_pack_multi', 'shard_unpack_multi', 'dccf_build_epoch_batches', 'dccf_lazy_scalars', 'dccf_lazy_flush']
+           'dccf_dp_finish', 'dccf_ctx_prepared_steps', 'dccf_ctx_hosted_rows', 'shard_pack_multi', 'shard_unpack_multi', 'dccf_build_epoch_batches', 'dccf_lazy_scalars', 'dccf_lazy_flush', 'dccf_lazy_catchup_rows', 'dccf_lazy_opt_step']
 
 ABI_VERSION = 5
 OPT_KIND = {'gd': 0, 'adagrad': 1, 'adam': 2}
@@ -152,6 +152,8 @@ def load():
         'dccf_build_epoch_batches': [vp, vp, vp, vp, i64, i64, vp, vp, vp, u64, u64, vp],
         'shard_pack_multi': [vp, i32, vp],
         'dccf_lazy_scalars': [f32, i64, i32, vp],
+        'dccf_lazy_catchup_rows': [C.POINTER(OptT), vp, i64, i32, vp, i64, i32, vp],
+        'dccf_lazy_opt_step': [C.POINTER(OptT), i64, vp],
         'dccf_lazy_flush': [C.POINTER(OptT), vp],
         'shard_unpack_multi': [vp, i32, vp, i64, vp],
     }
@@ -369,6 +371,19 @@ class LazyState(object):
         """Every row IS at `step` (dense steps ran, or nothing ran yet): reset the counters."""
         self.last.fill_(int(step))
         self.dirty = False
+
+    def catchup_rows(self, step, rows, n, seg=0):
+        """Before a step that drives its own launches (the row-sharded trainer) reads the parameters: rows[:n] (int32, of segment
+        `seg`) are claimed for `step`, listed and brought up to step - 1 (dccf_lazy_catchup_rows)."""
+        self.opt.step = int(step)
+        self.cover(step)
+        self.dirty = True
+        check(load().dccf_lazy_catchup_rows(C.byref(self.opt), ptr(rows, torch.int32), int(n), int(seg), None, 0, 0, stream()))
+
+    def opt_step(self, step, nslots):
+        """The optimizer launch of that step (dccf_lazy_opt_step), once the gradient rows are complete."""
+        self.opt.step = int(step)
+        check(load().dccf_lazy_opt_step(C.byref(self.opt), int(nslots), stream()))
 
     def flush(self, step):
         """Brings every row up to `step` (dccf_lazy_flush); no-op when nothing is behind."""

@@ -1495,7 +1495,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
         pn.w_end = pn.w_begin + (int64_t)D * (D + F);
         pn.blocks = (int)min((int64_t)64, (y.NS + pn.Lm + 255) / 256);
         if (knobs().lazy_cu) {
-          pn.cu_blocks = (int)min((int64_t)256, (N * (int64_t)(S1 + 1) + 3) / 4);
+          pn.cu_blocks = (int)min((int64_t)(getenv("DCCF_LAZY_CU_BLOCKS") ? atoi(getenv("DCCF_LAZY_CU_BLOCKS")) : 256), (N * (int64_t)(S1 + 1) + 3) / 4);
           pn.cu_segU = plan->lazy_segU;
           pn.cu_segV = plan->lazy_segV;
         }

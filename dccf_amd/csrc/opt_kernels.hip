@@ -566,6 +566,37 @@ extern "C" int dccf_dense_opt_step_dev(int32_t kind, float* p, float* g, float* 
 // (LazyArgs, lazy_replay and the window pass: opt_device.hpp — the backward launch can host the window)
 // Before the forward of step t: every distinct row the step reads (the batch's users, its candidates) is claimed by ONE wave
 // (atomicMax on claim), appended to the step's list and brought up to step t - 1.
+// one slot of a step's row list: the wave claims the row (the winner of a row's slots lists it) and brings it up to step t - 1
+template <int KIND>
+__device__ __forceinline__ void lazy_catchup_slot(float* __restrict__ p, float* __restrict__ s1, float* __restrict__ s2, const OptArgs& a,
+                                                  const RowSegs& sg, const LazyArgs& z, int* claim, int* list, int64_t j, int q,
+                                                  int64_t row, int lane) {
+  const int t = (int)z.step;
+  const int64_t grow = z.row_off[q] + row;
+  int won = 0;
+  if (lane == 0) {
+    won = atomicMax(&claim[grow], t) < t ? 1 : 0;
+    list[j] = won ? (int)grow : -1;        // the step's rows, one entry per slot (-1: another slot owns the row): no shared
+  }                                        // counter — 3,000 appends to one address took 40 us
+  won = __shfl(won, 0, 64);
+  if (!won) return;
+  const LazyPend pend = lazy_pend_read(z);
+  const int from = __builtin_amdgcn_readfirstlane(lazy_eff_last(z, pend, grow));      // (uniform: scalar loads of the table)
+  if (from >= t - 1) return;
+  const int w = sg.width[q];
+  float* pr = p + sg.begin[q] + row * w;
+  float* ar = s1 ? s1 + sg.begin[q] + row * w : nullptr;
+  float* br = s2 ? s2 + sg.begin[q] + row * w : nullptr;
+  for (int c = lane; c < w; c += 64) {
+    float pv = pr[c], av = KIND != DCCF_OPT_GD ? ar[c] : 0.f, bv = KIND == DCCF_OPT_ADAM ? br[c] : 0.f;
+    lazy_replay<KIND>(pv, av, bv, a, z, from, t - 1);
+    pr[c] = pv;
+    if (KIND != DCCF_OPT_GD) ar[c] = av;
+    if (KIND == DCCF_OPT_ADAM) br[c] = bv;
+  }
+  if (lane == 0) z.last[grow] = t - 1;
+}
+
 template <int KIND>
 __global__ __launch_bounds__(256) void k_lazy_catchup(float* __restrict__ p, float* __restrict__ s1, float* __restrict__ s2,
                                                       OptArgs a, RowSegs sg, LazyArgs z, const int64_t* __restrict__ X,
@@ -573,36 +604,28 @@ __global__ __launch_bounds__(256) void k_lazy_catchup(float* __restrict__ p, flo
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int64_t slots = N * S1 + N;
-  const int t = (int)z.step;
-  int* claim = lazy_claim_of(z, t);
-  int* list = lazy_list_of(z, t);
+  int* claim = lazy_claim_of(z, (int)z.step);
+  int* list = lazy_list_of(z, (int)z.step);
   for (int64_t j = wave; j < slots; j += nw) {
-    int q;
-    int64_t row;
-    if (j < N * S1) { q = segV; row = cand[j]; } else { q = segU; row = X[2 * (j - N * S1)]; }
-    const int64_t grow = z.row_off[q] + row;
-    int won = 0;
-    if (lane == 0) {
-      won = atomicMax(&claim[grow], t) < t ? 1 : 0;
-      list[j] = won ? (int)grow : -1;        // the step's rows, one entry per slot (-1: another slot owns the row): no shared
-    }                                          // counter — 3,000 appends to one address took 40 us
-    won = __shfl(won, 0, 64);
-    if (!won) continue;
-    const LazyPend pend = lazy_pend_read(z);
-    const int from = __builtin_amdgcn_readfirstlane(lazy_eff_last(z, pend, grow));      // (uniform: scalar loads of the table)
-    if (from >= t - 1) continue;
-    const int w = sg.width[q];
-    float* pr = p + sg.begin[q] + row * w;
-    float* ar = s1 ? s1 + sg.begin[q] + row * w : nullptr;
-    float* br = s2 ? s2 + sg.begin[q] + row * w : nullptr;
-    for (int c = lane; c < w; c += 64) {
-      float pv = pr[c], av = KIND != DCCF_OPT_GD ? ar[c] : 0.f, bv = KIND == DCCF_OPT_ADAM ? br[c] : 0.f;
-      lazy_replay<KIND>(pv, av, bv, a, z, from, t - 1);
-      pr[c] = pv;
-      if (KIND != DCCF_OPT_GD) ar[c] = av;
-      if (KIND == DCCF_OPT_ADAM) br[c] = bv;
-    }
-    if (lane == 0) z.last[grow] = t - 1;
+    if (j < N * S1) lazy_catchup_slot<KIND>(p, s1, s2, a, sg, z, claim, list, j, segV, cand[j], lane);
+    else lazy_catchup_slot<KIND>(p, s1, s2, a, sg, z, claim, list, j, segU, X[2 * (j - N * S1)], lane);
+  }
+}
+
+// the same for a caller that names the rows itself (the row-sharded trainer: the rows it is about to send to its peers):
+// slot j < n_a is row rows_a[j] of segment seg_a, slot n_a + j row rows_b[j] of segment seg_b
+template <int KIND>
+__global__ __launch_bounds__(256) void k_lazy_catchup_rows(float* __restrict__ p, float* __restrict__ s1, float* __restrict__ s2,
+                                                           OptArgs a, RowSegs sg, LazyArgs z, const int* __restrict__ rows_a,
+                                                           int64_t n_a, int seg_a, const int* __restrict__ rows_b, int64_t n_b,
+                                                           int seg_b) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  int* claim = lazy_claim_of(z, (int)z.step);
+  int* list = lazy_list_of(z, (int)z.step);
+  for (int64_t j = wave; j < n_a + n_b; j += nw) {
+    if (j < n_a) lazy_catchup_slot<KIND>(p, s1, s2, a, sg, z, claim, list, j, seg_a, rows_a[j], lane);
+    else lazy_catchup_slot<KIND>(p, s1, s2, a, sg, z, claim, list, j, seg_b, rows_b[j - n_a], lane);
   }
 }
 
@@ -821,6 +844,24 @@ int dccf_lazy_catchup(const void* ov, const int64_t* X, const int* cand, int64_t
   return 0;
 }
 
+extern "C" int dccf_lazy_catchup_rows(const dccf_opt_t* o, const int32_t* rows_a, int64_t n_a, int32_t seg_a, const int32_t* rows_b,
+                                      int64_t n_b, int32_t seg_b, void* stream) {
+  ARG_CHECK(o != nullptr && n_a >= 0 && n_b >= 0 && (n_a == 0 || rows_a) && (n_b == 0 || rows_b), "NULL opt / rows");
+  OptJob j;
+  if (int e = opt_job(o, &j)) return e;
+  LazyArgs z;
+  if (int e = lazy_args(o, j, &z)) return e;
+  ARG_CHECK((n_a == 0 || (seg_a >= 0 && seg_a < j.sg.n)) && (n_b == 0 || (seg_b >= 0 && seg_b < j.sg.n)), "bad segment index");
+  const int64_t slots = n_a + n_b;
+  if (slots == 0) return 0;
+  ARG_CHECK(slots <= z.list_cap, "lazy optimizer: the step's row list is too short (lazy_list_cap)");
+  const int grid = (int)min((int64_t)2048, (slots + 3) / 4);
+  BY_KIND(j.kind, k_lazy_catchup_rows, dim3(grid), dim3(256), 0, (hipStream_t)stream, j.p, j.s1, j.s2, j.a, j.sg, z, rows_a, n_a,
+          (int)seg_a, rows_b, n_b, (int)seg_b);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 static int lazy_launch(const dccf_opt_t* o, int flush, const PrepNext* pnp, int64_t nslots, hipStream_t st) {
   OptJob j;
   if (int e = opt_job(o, &j)) return e;
@@ -856,6 +897,10 @@ static int lazy_launch(const dccf_opt_t* o, int flush, const PrepNext* pnp, int6
 
 int dccf_lazy_step(const void* ov, const PrepNext* pn, int64_t nslots, hipStream_t st) {
   return lazy_launch((const dccf_opt_t*)ov, 0, pn, nslots, st);
+}
+extern "C" int dccf_lazy_opt_step(const dccf_opt_t* opt, int64_t nslots, void* stream) {
+  ARG_CHECK(opt != nullptr && opt->lazy_K > 0 && nslots >= 0, "dccf_lazy_opt_step needs a lazy optimizer (lazy_K > 0)");
+  return lazy_launch(opt, 0, nullptr, nslots, (hipStream_t)stream);
 }
 
 // Replicated multi-GPU path: the rows ANY rank touches at step t are known before the step as bytes (the replicated

@@ -65,6 +65,16 @@ class HipBackend(object):
         self._r.sample_item, self._r.step = self.L.ptr(cand_c, torch.int64), int(step)
         return self.L.dccf_train_fwdbwd(self.ctx, self._m, self._r, Xc, Y, 1, dropout, gU, gV, gW, gb, pred=pred, loss=loss)
 
+    # windowed lazy regularisation of the shard (include/dccf_hip.h, dccf_opt_t.lazy_*): the rows this rank is about to send are
+    # brought up to date before they are packed; the optimizer launch then takes them (with the gradient rows that came back),
+    # W, b and one K-th of the shard's other rows — at BASELINE config 5's size the dense pass over the shard IS the step
+    def lazy_state(self, p, g, s1, s2, lr, l2, segments, K, list_cap):
+        opt = self.L.opt_struct('adam', p, g, s1, s2, lr, l2, l2, 50.0, segments, 0)
+        n_rows = sum(int(s[1]) for s in segments)
+        st = self.L.LazyState(opt, K, n_rows, list_cap, lr, p.device)
+        st._opt_keep = opt
+        return st
+
     def opt_step(self, p, g, s1, s2, lr, l2, t, segments=None):
         if segments:       # rows no peer sent a gradient for: g neither read nor re-zeroed (24 instead of 32 B/param)
             self.L.dense_opt_step_rows('adam', p, g, s1, s2, lr, l2, l2, 50.0, t, segments)
@@ -111,7 +121,7 @@ class _Route(object):
 
 class ShardedDCCF(object):
     def __init__(self, rank, world, user_num, item_num, D, S, A, std, dropout, lr, l2, seed, backend, device,
-                 feat_local, ips_local, group=None):
+                 feat_local, ips_local, group=None, lazy_K=None):
         """feat_local: [ceil(item_num/G), F] rows of the items i = rank (mod G); ips_local: dict P [nU_loc,Dq], bu [nU_loc],
         Q [nI_loc,Dq], bi [nI_loc], prop [nI_loc], b0, M — the IPSBiasedMF factors of the exposure score."""
         self.rank, self.G, self.group, self.dev, self.be = rank, world, group, device, backend
@@ -148,6 +158,14 @@ class ShardedDCCF(object):
         self.user_pad = torch.ones((max(self.nU, 1), 1), dtype=f32, device=device)           # the "prop" column of user rows
         self.t = 0
         self.plan = None
+        import os
+        self.lazy_K = int(os.environ.get('DCCF_LAZY_K', '8')) if lazy_K is None else int(lazy_K)
+        self.lazy = None                 # created with the first epoch plan (the row list is sized by it)
+
+    def flush(self):
+        """Every row of the shard up to date (before anything but train_step reads U, V or the optimizer state)."""
+        if self.lazy is not None:
+            self.lazy.flush(self.t)
 
     def init_params(self, std=0.01):
         """BaseModel.init_paras (src/models/BaseModel.py:130-142): N(0, 0.01); W, b identical on every rank."""
@@ -207,6 +225,12 @@ class ShardedDCCF(object):
                                          (None, p['feat_dst'][0], N, [p['featc']], p['recv_f'])])
         p['ipsc'] = dict(P=p['PQ'], bu=p['bb'].view(-1), Q=p['PQ'], bi=p['bb'].view(-1), prop=p['prop'].view(-1),
                          b0=self.ips['b0'], M=self.ips['M'])
+        if self.lazy_K >= 2 and self.segments and hasattr(self.be, 'lazy_state') and \
+                (self.lazy is None or self.lazy.list_cap < re.send_max):
+            self.flush()
+            self.lazy = self.be.lazy_state(self.flat_p, self.flat_g, self.s1, self.s2, self.lr, self.l2, self.segments, self.lazy_K,
+                                           max(G * T, re.send_max))
+            self.lazy.sync_all(self.t)
 
     # ------------------------------------------------------------------------------------------------ one step
     def _a2a(self, out, inp, out_splits, in_splits):
@@ -221,6 +245,9 @@ class ShardedDCCF(object):
         re, rf = p['re'], p['rf']
         N, T = p['N'], p['T']
         ne, nf = re.send_n[k], rf.send_n[k]
+        if self.lazy is not None:        # the rows about to leave (= the rows whose gradients come back) at step t, everything else may lag
+            self.lazy.catchup_rows(self.t + 1, re.g_row[k], ne)
+            mark('lazy_catchup')
         # rows out: users and items share one payload (both are [embedding | IPS factor | bias | prop] rows); one launch
         pk = p['pack']
         be.set_job(pk, 0, re.a_src[k], re.a_dst[k], re.na[k])
@@ -249,7 +276,10 @@ class ShardedDCCF(object):
         work.wait()
         mark('a2a_grads+all_reduce+scatter')
         self.t += 1
-        be.opt_step(self.flat_p, self.flat_g, self.s1, self.s2, self.lr, self.l2, self.t, self.segments)
+        if self.lazy is not None:
+            self.lazy.opt_step(self.t, ne)
+        else:
+            be.opt_step(self.flat_p, self.flat_g, self.s1, self.s2, self.lr, self.l2, self.t, self.segments)
         mark('adam')
         return pred, loss
 
@@ -293,6 +323,7 @@ def bench_main(args, rank, world, dev):
     tr.begin_epoch(schedule(1)[:args.steps], 1)                # the epoch's sampling + routing tables are timed
     for k in range(args.steps):
         tr.train_step(k)
+    tr.flush()                 # (timed: every row of the shard has received every step when the clock stops)
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
@@ -325,11 +356,32 @@ def bench_main(args, rank, world, dev):
     phase_us = {nm: round(sum(r[i].elapsed_time(r[i + 1]) for r in evs) / n_prof * 1e3, 2) for i, nm in enumerate(names)}
     adam_ms = max(phase_us['adam'] / 1e3, 1e-6)
     n_local = tr.flat_p.numel()
-    roofline = {'kernel': 'k_dense_opt_rows<Adam> over the local shard (rows mod G)', 'bound': 'hbm',
-                'achieved': round(24.0 * n_local / 1e9 / (adam_ms / 1e3), 1), 'peak': 8000.0, 'unit': 'GB/s',
-                'frac': round(24.0 * n_local / 1e9 / (adam_ms / 1e3) / 8000.0, 4), 'traffic': None,
-                'algorithmic_per_launch': round(24.0 * n_local / 1e9, 4), 'avg_launch_ms': round(adam_ms, 5),
-                'note': 'includes one event boundary (~4 us); p + m + v of a shard below 256 MiB sit in the Infinity Cache'}
+    # the dense regularised Adam pass over THIS rank's shard (what every step runs with lazy_K = 0), timed on its own
+    tr.flush()
+    evs2 = []
+    for k in range(12):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        be.opt_step(tr.flat_p, tr.flat_g, tr.s1, tr.s2, tr.lr, tr.l2, tr.t + 1 + k, tr.segments)
+        b.record()
+        evs2.append((a, b))
+    torch.cuda.synchronize()
+    dense_ms = sum(a.elapsed_time(b) for a, b in evs2[2:]) / 10
+    whole = {'kernel': 'k_dense_opt_rows<Adam> over the local shard (rows mod G)', 'avg_launch_ms': round(dense_ms, 5),
+             'algorithmic_GB': round(24.0 * n_local / 1e9, 4), 'achieved': round(24.0 * n_local / 1e9 / (dense_ms / 1e3), 1),
+             'frac': round(24.0 * n_local / 1e9 / (dense_ms / 1e3) / 8000.0, 4)}
+    if tr.lazy is not None:
+        alg = 24.0 * n_local / tr.lazy_K / 1e9
+        roofline = {'kernel': 'k_lazy_opt<Adam> over the local shard (windowed lazy regularisation, K = %d)' % tr.lazy_K, 'bound': 'hbm',
+                    'achieved': round(alg / (adam_ms / 1e3), 1), 'peak': 8000.0, 'unit': 'GB/s',
+                    'frac': round(alg / (adam_ms / 1e3) / 8000.0, 4), 'traffic': None, 'algorithmic_per_launch': round(alg, 4),
+                    'avg_launch_ms': round(adam_ms, 5), 'whole_pass': whole,
+                    'note': 'the lazy launch is bound by the vector ALU of its replay, not by HBM (DESIGN.md 4b); whole_pass = the '
+                            'dense pass over the shard that lazy_K = 0 runs every step; figures include one event boundary (~4 us); '
+                            'p + m + v of a shard below 256 MiB sit in the Infinity Cache'}
+    else:
+        roofline = dict(whole, bound='hbm', peak=8000.0, unit='GB/s', traffic=None, algorithmic_per_launch=whole['algorithmic_GB'],
+                        note='includes one event boundary (~4 us); p + m + v of a shard below 256 MiB sit in the Infinity Cache')
     if rank == 0:
         out = {'metric': 'train pairs/sec at rank=64 Electronics', 'value': round(args.steps * B * world / dt, 1),
                'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -340,6 +392,7 @@ def bench_main(args, rank, world, dev):
                                       'row exchange, all-reduce of [dW|db]), exposure from IPS factors, fused on-device negatives'
                                       % (U, I, D, F, S, A, world),
                           'layout': 'sharded',
+                          'regularisation': ('windowed lazy (K = %d) over the local shard' % tr.lazy_K) if tr.lazy is not None else 'dense pass',
                           'batch_size_per_gpu': B, 'global_batch': B * world, 'optimizer': 'Adam lr=1e-3 l2=1e-4 dropout=0.2',
                           'collectives_per_step': 'all_to_all x3 (rows, feature rows, grad rows) + all_reduce([dW|db])'},
                'roofline': roofline, 'phase_us': phase_us, 'host_us_per_step': round(host_us, 1), 'cpu_baseline': None}

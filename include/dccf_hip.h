@@ -213,6 +213,15 @@ typedef struct {
 } dccf_opt_t;
 /* HOST: out[4 i .. 4 i + 3] = the Adam step scalars of step t0 + i (see lazy_scal), i < n. */
 int dccf_lazy_scalars(float lr, int64_t t0, int32_t n, float* out_host);
+/* The two launches of a lazy step for a caller that drives the step itself (the row-sharded trainer, dccf_amd/sharded.py;
+ * dccf_train_step does the same internally).  dccf_lazy_catchup_rows, BEFORE anything reads the parameters: the rows the step
+ * will touch — rows_a[0..n_a) of segment seg_a, rows_b[0..n_b) of segment seg_b, duplicates allowed — are claimed for
+ * opt->step, listed (n_a + n_b <= lazy_list_cap) and brought up to step - 1.  dccf_lazy_opt_step, once their gradient rows are
+ * complete in opt->g: the listed rows get step opt->step with their gradient (which is zeroed), everything outside the row
+ * segments (W, b) the dense step, and this step's window of the other rows is advanced; nslots = n_a + n_b of the catch-up. */
+int dccf_lazy_catchup_rows(const dccf_opt_t* opt, const int32_t* rows_a, int64_t n_a, int32_t seg_a, const int32_t* rows_b,
+                           int64_t n_b, int32_t seg_b, void* stream);
+int dccf_lazy_opt_step(const dccf_opt_t* opt, int64_t nslots, void* stream);
 /* Brings every row of the segments up to opt->step (rows already there are untouched).  Needs lazy_K > 0. */
 int dccf_lazy_flush(const dccf_opt_t* opt, void* stream);
 /* The context's side stream (hipStream_t): least priority, or confined to the first n CUs when the environment variable

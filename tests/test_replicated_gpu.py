@@ -255,7 +255,7 @@ def test_two_ranks_hip_backend_replicas_bit_identical(tmp_path, overlap, world):
 
 
 # ------------------------------------------------------------------------------------------------ row-sharded layout, 2 ranks
-def _sharded_rank_main(rank, world, port, out):
+def _sharded_rank_main(rank, world, port, out, lazy_K):
     """One rank of the row-sharded trainer with the HIP backend; both ranks share this box's one GPU, gloo moves the bytes."""
     import torch.distributed as dist
     import test_sharded_gloo as TS
@@ -265,13 +265,13 @@ def _sharded_rank_main(rank, world, port, out):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(dev)
-    c = TS.CFG
+    c = dict(TS.CFG, steps=5)      # (five steps: the lazy window cycles at K = 2)
     P, feat, ips, X = TS.make_world(c)
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     ips_loc = dict(P=T(ips['P'][rank::world]), bu=T(ips['bu'][rank::world]), Q=T(ips['Q'][rank::world]),
                    bi=T(ips['bi'][rank::world]), prop=T(ips['prop'][rank::world]), b0=0.1, M=0.1)
     tr = sharded.ShardedDCCF(rank, world, c['U'], c['I'], c['D'], c['S'], c['A'], c['std'], c['dropout'], c['lr'], c['l2'],
-                             c['seed'], sharded.HipBackend(dev), dev, T(feat[rank::world]), ips_loc)
+                             c['seed'], sharded.HipBackend(dev), dev, T(feat[rank::world]), ips_loc, lazy_K=lazy_K)
     K = TS.KEYS
     tr.set_global_params(T(P[K[0]]), T(P[K[1]]), T(P[K[2]]), T(P[K[3]]))
     preds, losses = [], []
@@ -280,6 +280,8 @@ def _sharded_rank_main(rank, world, port, out):
         pred, loss = tr.train_step(step)
         preds.append(pred.cpu().numpy().copy())
         losses.append(float(loss))
+    assert (tr.lazy is not None) == (lazy_K >= 2)
+    tr.flush()                 # rows the lazy regularisation left behind are brought up to date before anybody looks
     torch.cuda.synchronize()
     np.savez(os.path.join(out, 'sh%d.npz' % rank), U=tr.U.cpu().numpy(), V=tr.V.cpu().numpy(), W=tr.W.cpu().numpy(),
              b=tr.b.cpu().numpy(), preds=np.stack(preds), losses=np.array(losses), gmax=float(tr.flat_g.abs().max()),
@@ -287,9 +289,11 @@ def _sharded_rank_main(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_ranks_hip_backend_row_sharded_equals_union_batch(tmp_path):
+@pytest.mark.parametrize('lazy_K', [0, 2, 8])
+def test_two_ranks_hip_backend_row_sharded_equals_union_batch(tmp_path, lazy_K):
     """World size 2 of the ROW-SHARDED layout with the HIP backend (pack / all-to-all / unpack / the single-GPU kernels on
-    compact tables / all-to-all / scatter-add / all-reduce / row-aware Adam): every rank's predictions equal the oracle's on
+    compact tables / all-to-all / scatter-add / all-reduce / row-aware Adam — dense, or the windowed lazy regularisation of the
+    shard: the rows about to be sent are caught up first): every rank's predictions equal the oracle's on
     the same counter-based draws, the shards partition the tables (rank r holds rows r, r + G, ...), W and b stay
     replicated, and the parameters equal ONE oracle step on the union of the ranks' batches to the float-atomic tolerance."""
     import torch.multiprocessing as mp
@@ -298,8 +302,8 @@ def test_two_ranks_hip_backend_row_sharded_equals_union_batch(tmp_path):
     from oracle import philox as PH
     world = 2
     port = 36000 + os.getpid() % 2000
-    mp.spawn(_sharded_rank_main, args=(world, port, str(tmp_path)), nprocs=world, join=True)
-    c = TS.CFG
+    mp.spawn(_sharded_rank_main, args=(world, port, str(tmp_path), lazy_K), nprocs=world, join=True)
+    c = dict(TS.CFG, steps=5)      # (five steps: the lazy window cycles at K = 2)
     K = TS.KEYS
     P, feat, ips, X = TS.make_world(c)
     expo = TS.expo_from_ips(ips)
