@@ -65,7 +65,7 @@ template <int KIND>
 __device__ __forceinline__ void opt_elem(float& p, float& g, float& s1, float& s2, const OptArgs& a) {
   // explicit l2 term of the loss, then the clip, then the optimizer's coupled weight decay
   float gt = __fadd_rn(g, __fmul_rn(a.l2, __fmul_rn(2.0f, p)));
-  gt = fminf(fmaxf(gt, -a.clip), a.clip);
+  gt = __builtin_amdgcn_fmed3f(gt, -a.clip, a.clip);      // clamp(gt, -clip, clip), clip >= 0 (checked on the host): one instruction
   gt = __fadd_rn(gt, __fmul_rn(a.wd, p));
   if (KIND == DCCF_OPT_GD) {
     p = __fadd_rn(p, __fmul_rn(-a.lr, gt));

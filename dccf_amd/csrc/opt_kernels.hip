@@ -392,6 +392,7 @@ int opt_make_job(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t
     sg.width[q] = w;
     sg.flags[q] = seg_flags[q];
   }
+  ARG_CHECK(clip >= 0.f, "clip must be >= 0");
   OptArgs& a = out->a;
   a.lr = lr; a.wd = wd; a.l2 = l2; a.clip = clip; a.zero_grad = 1;
   a.k_dev = k_dev; a.step0 = step;
@@ -1031,6 +1032,7 @@ extern "C" int dccf_debug_opt_elem(int32_t kind, int32_t ieee, float* p, float* 
   ARG_CHECK(ieee >= 0 && ieee <= 3 && (ieee < 2 || kind == DCCF_OPT_ADAM), "ieee is 0 / 1 (a step) or 2 / 3 (Adam's denominator only)");
   const int denom_only = ieee >> 1;
   ieee &= 1;
+  ARG_CHECK(clip >= 0.f, "clip must be >= 0");
   if (n == 0) return 0;
   OptArgs a;
   a.lr = lr; a.wd = wd; a.l2 = l2; a.clip = clip; a.zero_grad = 0;
@@ -1058,6 +1060,7 @@ extern "C" int dccf_dense_opt_step(int32_t kind, float* p, float* g, float* s1, 
   ARG_CHECK(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && (!s1 || (uintptr_t)s1 % 16 == 0) &&
                 (!s2 || (uintptr_t)s2 % 16 == 0),
             "buffers must be 16-byte aligned");
+  ARG_CHECK(clip >= 0.f, "clip must be >= 0");
   if (n == 0) return 0;
   OptArgs a;
   a.lr = lr; a.wd = wd; a.l2 = l2; a.clip = clip; a.zero_grad = zero_grad;
