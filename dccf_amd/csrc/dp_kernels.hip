@@ -771,10 +771,12 @@ extern "C" int dccf_dp_overlap(const dccf_opt_t* opt, const dccf_dp_t* dp, int32
   if (opt->lazy_K > 0) {
     // the rows ANY rank touches at the next step are claimed and caught up here too, while the all-gather is in flight
     const int64_t slots = (int64_t)dp->G * next->N * (M->S + 2);
-    pn.cu_blocks = (int)max((int64_t)1, min((int64_t)1024, (slots + 3) / 4));
+    static const int cu_cap = getenv("DCCF_DP_CU_BLOCKS") ? atoi(getenv("DCCF_DP_CU_BLOCKS")) : 1024;      // 0: the flag-scan catch-up instead
+    pn.cu_blocks = cu_cap > 0 ? (int)max((int64_t)1, min((int64_t)cu_cap, (slots + 3) / 4)) : 0;
     pn.cu_segU = dp->segU;
     pn.cu_segV = dp->segV;
     if (int e = dccf_lazy_phase1(opt, &pn, (hipStream_t)stream)) return e;
+    if (pn.cu_blocks == 0) return 0;
     ctx->lazy_prep_step = (int64_t)opt->step + 1;
     ctx->lazy_prep_claim = opt->lazy_claim;
     ctx->lazy_prep_id = opt->lazy_id;
