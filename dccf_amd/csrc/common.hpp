@@ -47,6 +47,8 @@ struct dccf_ctx {
   hipEvent_t ev_fork, ev_join;
   // what the last dccf_train_step prepared for the next one (candidates, exposures, W^T, zeroed accumulators)
   int prep_valid;
+  float* gw_part;                // scratch of GwPart (grown on demand)
+  size_t gw_part_bytes;
   int64_t lazy_prep_step;        // optimizer step whose rows the last lazy optimizer launch claimed and caught up (-1: none)
   const void* lazy_prep_claim;   // ... in this claim array
   int64_t lazy_prep_id;          // ... of the arrays the caller named so (dccf_opt_t.lazy_id)
@@ -112,6 +114,14 @@ struct dccf_opt_args;      // == dccf_opt_t of include/dccf_hip.h
 // opt_kernels.hip: one phase of the dense regularised optimizer step described by `o` (dccf_opt_t)
 int dccf_opt_phase(const void* o, int phase, const int64_t* list, const int* cnt, int64_t max_rows, hipStream_t st);
 struct PrepNext;
+// dW of a training step as per-row-split partial sums instead of float atomics into gW (k_bwd writes split r's copy with plain
+// stores, the optimizer launch that follows adds the copies in split order while it reads the gradient of W anyway)
+struct GwPart {
+  const float* part;        // [nsplit][stride] floats; NULL = gW holds the gradient
+  int nsplit;
+  int64_t stride;           // D (D + F)
+  int64_t w_begin, w_end;   // elements of W inside the flat parameter / gradient buffer
+};
 int dccf_opt_all_prep(const void* o, const PrepNext* pn, hipStream_t st);
 // the same with the flags of one segment replaced and only its MARKED rows belonging to the pass (the unmarked ones were
 // updated by the pass hosted in the backward launch) — for its first rows_hosted rows; the rest of the segment is ordinary
@@ -123,7 +133,7 @@ int dccf_opt_untouched_prep(const void* o, uint8_t* const* flags, const PrepNext
 // windowed lazy regularisation (dccf_opt_t.lazy_K > 0): the rows of the running step (X, cand, first global row of the user /
 // item segment) are claimed, listed and brought up to step - 1; then the step's optimizer launch
 int dccf_lazy_catchup(const void* o, const int64_t* X, const int* cand, int64_t N, int S1, int segU, int segV, hipStream_t st);
-int dccf_lazy_step(const void* o, const PrepNext* pn, int64_t nslots, hipStream_t st);      // nslots = N (S + 2) of the catch-up
+int dccf_lazy_step(const void* o, const PrepNext* pn, int64_t nslots, hipStream_t st, const GwPart* gp = nullptr);      // nslots = N (S + 2) of the catch-up
 // claims somebody made for `step` (pn.cu_blocks of the previous launch) for a batch that did not come: forgotten
 int dccf_lazy_reset_claims(const void* o, hipStream_t st);
 // replicated multi-GPU path (dp_kernels.hip): rows flagged in (flags0, flags1) of segments (seg0, seg1) claimed + caught up;

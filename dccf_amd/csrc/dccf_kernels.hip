@@ -37,6 +37,7 @@ struct Knobs {
   bool hostv;             // DCCF_NO_HOSTV=1   turns the hosted item-table pass off
   int64_t bwd_wgs;        // DCCF_BWD_WGS      role workgroups of the backward at 2B < 2048 (row splits = this / roles)
   bool lazy_cu;           // DCCF_LAZY_NO_CU=1 the lazy optimizer launch does not catch up the next step's rows (a launch of its own does)
+  bool gw_part;           // DCCF_NO_GW_PART=1 dW of a lazy step as float atomics into gW (not per-split partial sums)
 };
 static const Knobs& knobs() {
   static const Knobs k = [] {
@@ -47,6 +48,7 @@ static const Knobs& knobs() {
     q.hostv = getenv("DCCF_NO_HOSTV") == nullptr;
     q.bwd_wgs = getenv("DCCF_BWD_WGS") ? atoll(getenv("DCCF_BWD_WGS")) : 256;
     q.lazy_cu = getenv("DCCF_LAZY_NO_CU") == nullptr;
+    q.gw_part = getenv("DCCF_NO_GW_PART") == nullptr;
     return q;
   }();
   return k;
@@ -461,6 +463,8 @@ struct BwdArgs {
   const float *dmns, *hbuf, *noise;
   const float* dh;           // DH (n_layers > 1): d loss / d h0 [L, DP] from the layers above; dz0 = dh * [h0 > 0] * kscale
   float *gU, *gV, *gW, *gb;
+  float* gw_part;            // != NULL: dW leaves as this row split's partial sums (plain stores into copy blockIdx.x), not as
+  int64_t gw_stride;         // float atomics into gW — the optimizer launch that follows adds the copies (GwPart)
   uint8_t *touchedU, *touchedV;
   int64_t N;
   int S1, A, F, NC;
@@ -738,18 +742,60 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
       red[(wave * RQ + qq) * 64 + lane] = acc[q / (NB * 16)][(q / 16) % NB][q % 16];
     }
     __syncthreads();
-    for (int qq = wave; qq < RQ; qq += BWD_NW) {
-      const int q = q0 + qq;
-      const int mt = q / (NB * 16), o = (q / 16) % NB, r = q % 16;
-      float v = red[qq * 64 + lane];
+    if (q0 == 0) TRACEB(role, 5);
+    // every wave emits RQ / BWD_NW registers of the round: ALL their LDS reads first, then the sums, then the stores back to
+    // back (as a rolled loop this was one LDS round trip + one atomic per iteration: 1.15 us per round, 4.6 of the 22 us of a
+    // chunk role at B = 128)
+    constexpr int PER = RQ / BWD_NW;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    if (p.gw_part && ((Dr | F) & 3) == 0) {
+      // partial-sum copy, rows 16-byte aligned: a lane takes 4 consecutive columns of one accumulator register (4 lanes' values:
+      // one ds_read_b128 per wave copy) and stores them as ONE dwordx4 — 8 store instructions of 1 KB per round instead of 32
+      // of 256 B (a CU retires a dword-per-lane store or atomic instruction only every ~40 ns: 4.8 us per chunk role)
+      float* __restrict__ dstw = p.gw_part + (int64_t)blockIdx.x * p.gw_stride;
+      constexpr int PERW = RQ / 4 / BWD_NW;
 #pragma unroll
-      for (int w = 1; w < BWD_NW; ++w) v += red[(w * RQ + qq) * 64 + lane];
+      for (int k = 0; k < PERW; ++k) {
+        const int qq = 4 * (wv + k * BWD_NW) + (lane >> 4), j = lane & 15;
+        float4 t = *reinterpret_cast<const float4*>(&red[qq * 64 + 4 * j]);
+#pragma unroll
+        for (int w = 1; w < BWD_NW; ++w) {
+          const float4 u = *reinterpret_cast<const float4*>(&red[(w * RQ + qq) * 64 + 4 * j]);
+          t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        const int q = q0 + qq;
+        const int mt = q / (NB * 16), o = (q / 16) % NB, r = q % 16;
+        const int hh = j >> 3, c = 4 * (j & 7);
+        const int d = dbase + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const int col = CHUNK ? Dr + role * 128 + 32 * o + c : o * 32 + c;
+        const bool ok = d < Dr && (CHUNK ? (role * 128 + 32 * o + c < F) : (col < Dr));
+        if (ok) *reinterpret_cast<float4*>(&dstw[(int64_t)d * (Dr + F) + col]) = t;
+      }
+      continue;
+    }
+    float part[PER][BWD_NW];
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+#pragma unroll
+      for (int w = 0; w < BWD_NW; ++w) part[k][w] = red[(w * RQ + wv + k * BWD_NW) * 64 + lane];
+    float* __restrict__ dst = p.gw_part ? p.gw_part + (int64_t)blockIdx.x * p.gw_stride : p.gW;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int q = q0 + wv + k * BWD_NW;
+      const int mt = q / (NB * 16), o = (q / 16) % NB, r = q % 16;
+      float v = part[k][0];
+#pragma unroll
+      for (int w = 1; w < BWD_NW; ++w) v += part[k][w];
       const int d = dbase + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
       const int col = CHUNK ? Dr + role * 128 + 32 * o + c31 : o * 32 + c31;
       const bool ok = d < Dr && (CHUNK ? (role * 128 + 32 * o + c31 < F) : (col < Dr));
-      if (ok) atomicAdd(&p.gW[(int64_t)d * (Dr + F) + col], v);
+      if (ok) {
+        if (p.gw_part) dst[(int64_t)d * (Dr + F) + col] = v;
+        else atomicAdd(&dst[(int64_t)d * (Dr + F) + col], v);
+      }
     }
   }
+  TRACEB(role, 6);
   if (CHUNK && role == 0 && h == 0) {
 #pragma unroll
     for (int mt = 0; mt < ND; ++mt)
@@ -1257,6 +1303,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
   const bool prepared = train && !(plan && plan->overlap) && dccf_prep_matches(ctx, M, rnd, X, N);
   // hosted item table (dccf_train_step, no other overlap mode): two sets of "item row touched" bytes owned by the context
   const bool lazy = plan && train && plan->lazy_segU >= 0;
+  int gw_splits = 0;         // > 0: this step's backward left dW as that many partial sums in ctx->gw_part (GwPart)
   const bool hostv = plan && !plan->overlap && plan->hostv_seg >= 0 && train && !lazy;
   if (hostv) {
     const int64_t nb = (M->item_num + 3) / 4 * 4;
@@ -1455,6 +1502,24 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     ba.m = m; ba.Y = Y; ba.pred = pred; ba.loss = loss; ba.rank = rank;
     ba.slot_where = ctx->slot_where; ba.slot_rows = ctx->slot_rows; ba.slot_offU = ctx->slot_offU; ba.slot_offV = ctx->slot_offV;
     ba.slot_cap = ctx->slot_cap;
+    // small batches under the lazy optimizer: dW as per-split partial sums that the optimizer launch adds (32 KB of float
+    // atomics per CU were the last 6 us of every chunk-role workgroup: ~1 wave instruction per 50 ns per CU)
+    ba.gw_part = nullptr;
+    ba.gw_stride = (int64_t)D * (D + F);
+    gw_splits = 0;
+    if (lazy && knobs().gw_part && N < 2048 && !ctx->slot_where && plan->opt->p <= M->W &&
+        M->W + (int64_t)D * (D + F) <= plan->opt->p + plan->opt->n && G->gW == plan->opt->g + (M->W - plan->opt->p)) {
+      const size_t need = (size_t)gx * (size_t)ba.gw_stride * sizeof(float);
+      if (need > ctx->gw_part_bytes) {
+        if (ctx->gw_part) HIP_TRY(hipFree(ctx->gw_part));
+        ctx->gw_part = nullptr;
+        ctx->gw_part_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&ctx->gw_part, need));
+        ctx->gw_part_bytes = need;
+      }
+      ba.gw_part = ctx->gw_part;
+      gw_splits = (int)gx;
+    }
     memset(&ba.oj, 0, sizeof(ba.oj));
     ba.opt_rows_y = opt_rows_y;
     if (opt_rows_y) {
@@ -1485,6 +1550,15 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
   if (plan) {
     prof_begin(ctx, st);
     if (lazy) {
+      GwPart gp;
+      memset(&gp, 0, sizeof(gp));
+      if (gw_splits > 0) {
+        gp.part = ctx->gw_part;
+        gp.nsplit = gw_splits;
+        gp.stride = (int64_t)D * (D + F);
+        gp.w_begin = M->W - plan->opt->p;
+        gp.w_end = gp.w_begin + gp.stride;
+      }
       // touched rows + W, b + this step's window of the untouched rows (+ the next step's preparation)
       const bool prep_ok = plan->X_next && fused_cand && rnd->k_dev == nullptr && plan->opt->p <= M->W &&
                            M->W + (int64_t)D * (D + F) <= plan->opt->p + plan->opt->n;
@@ -1499,7 +1573,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
           pn.cu_segU = plan->lazy_segU;
           pn.cu_segV = plan->lazy_segV;
         }
-        if (int e = dccf_lazy_step(plan->opt, &pn, N * (int64_t)(S1 + 1), st)) return e;
+        if (int e = dccf_lazy_step(plan->opt, &pn, N * (int64_t)(S1 + 1), st, &gp)) return e;
         dccf_prep_next_commit(ctx, M, N, plan->X_next, rnd->seed, plan->step_next);
         if (pn.cu_blocks) {
           ctx->lazy_prep_step = (int64_t)plan->opt->step + 1;
@@ -1507,7 +1581,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
           ctx->lazy_prep_id = plan->opt->lazy_id;
         }
       } else {
-        if (int e = dccf_lazy_step(plan->opt, nullptr, N * (int64_t)(S1 + 1), st)) return e;
+        if (int e = dccf_lazy_step(plan->opt, nullptr, N * (int64_t)(S1 + 1), st, &gp)) return e;
       }
     } else if (plan->overlap) {
       if (!plan->hosted) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));

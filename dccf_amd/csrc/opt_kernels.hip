@@ -38,6 +38,8 @@ extern "C" int dccf_ctx_create(dccf_ctx** out, int device) {
   c->tl_parity = 0;
   c->prep_valid = 0;
   c->lazy_prep_step = -1;
+  c->gw_part = nullptr;
+  c->gw_part_bytes = 0;
   c->lazy_prep_claim = nullptr;
   c->lazy_prep_id = 0;
   c->prep_hits = 0;
@@ -90,6 +92,7 @@ extern "C" int dccf_ctx_destroy(dccf_ctx* ctx) {
     delete[] ctx->ev;
     delete[] ctx->ev_slot;
   }
+  if (ctx->gw_part) (void)hipFree(ctx->gw_part);
   if (ctx->side) (void)hipStreamDestroy(ctx->side);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
@@ -638,7 +641,7 @@ template <int KIND>
 __global__ __launch_bounds__(256) void k_lazy_opt(float* __restrict__ p, float* __restrict__ g, float* __restrict__ s1,
                                                   float* __restrict__ s2, OptArgs a, RowSegs sg, DenseSegs ds, LazyArgs z,
                                                   int lb, int db, int mb, int64_t win0, int64_t win1, int flush, int nslots,
-                                                  PrepNext pn) {
+                                                  PrepNext pn, GwPart gp) {
   if ((int)blockIdx.x < pn.blocks) {
     prep_next_slots(pn, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)pn.blocks * blockDim.x);
     return;
@@ -746,6 +749,18 @@ __global__ __launch_bounds__(256) void k_lazy_opt(float* __restrict__ p, float* 
         float pv = p[i], gv = g[i], av = 0.f, bv = 0.f;
         if (KIND != DCCF_OPT_GD) av = s1[i];
         if (KIND == DCCF_OPT_ADAM) bv = s2[i];
+        if (gp.part && i >= gp.w_begin && i < gp.w_end) {
+          // dW arrived as one partial sum per row split of the backward (plain stores there instead of 32 KB of float atomics
+          // per CU): added here in split order — 8 loads in flight (32 were slower), unconditional from clamped indices
+          const float* q = gp.part + (i - gp.w_begin);
+          for (int r0 = 0; r0 < gp.nsplit; r0 += 8) {
+            float tv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) tv[u] = q[(int64_t)min(r0 + u, gp.nsplit - 1) * gp.stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) gv = __fadd_rn(gv, r0 + u < gp.nsplit ? tv[u] : 0.f);
+          }
+        }
         opt_elem<KIND>(pv, gv, av, bv, a);
         p[i] = pv;
         g[i] = 0.f;
@@ -863,7 +878,7 @@ extern "C" int dccf_lazy_catchup_rows(const dccf_opt_t* o, const int32_t* rows_a
   return 0;
 }
 
-static int lazy_launch(const dccf_opt_t* o, int flush, const PrepNext* pnp, int64_t nslots, hipStream_t st) {
+static int lazy_launch(const dccf_opt_t* o, int flush, const PrepNext* pnp, int64_t nslots, hipStream_t st, const GwPart* gpp = nullptr) {
   OptJob j;
   if (int e = opt_job(o, &j)) return e;
   LazyArgs z;
@@ -887,8 +902,11 @@ static int lazy_launch(const dccf_opt_t* o, int flush, const PrepNext* pnp, int6
   ARG_CHECK(nslots <= z.list_cap && (pn.cu_blocks == 0 || pn.X_all || pn.N * (pn.S + 2) <= z.list_cap), "lazy optimizer: lazy_list_cap too small");
   if (flush) pn.cu_blocks = 0;
   const int grid = pn.blocks + pn.cu_blocks + lb + db + wb + mb;
+  GwPart gp;
+  memset(&gp, 0, sizeof(gp));
+  if (gpp && !flush) gp = *gpp;
   BY_KIND(j.kind, k_lazy_opt, dim3(grid), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.a, j.sg, ds, z, lb, db, mb, win0, win1, flush,
-          (int)nslots, pn);
+          (int)nslots, pn, gp);
   if (flush)
     hipLaunchKernelGGL(k_lazy_mark, dim3((unsigned)max((int64_t)1, min((int64_t)1024, (win1 - win0 + 255) / 256))), dim3(256), 0, st, z,
                        win0, win1, flush);
@@ -896,8 +914,8 @@ static int lazy_launch(const dccf_opt_t* o, int flush, const PrepNext* pnp, int6
   return 0;
 }
 
-int dccf_lazy_step(const void* ov, const PrepNext* pn, int64_t nslots, hipStream_t st) {
-  return lazy_launch((const dccf_opt_t*)ov, 0, pn, nslots, st);
+int dccf_lazy_step(const void* ov, const PrepNext* pn, int64_t nslots, hipStream_t st, const GwPart* gp) {
+  return lazy_launch((const dccf_opt_t*)ov, 0, pn, nslots, st, gp);
 }
 extern "C" int dccf_lazy_opt_step(const dccf_opt_t* opt, int64_t nslots, void* stream) {
   ARG_CHECK(opt != nullptr && opt->lazy_K > 0 && nslots >= 0, "dccf_lazy_opt_step needs a lazy optimizer (lazy_K > 0)");
@@ -980,8 +998,10 @@ int dccf_lazy_phase1(const void* ov, const PrepNext* pnp, hipStream_t st) {
   for (int q = 0; q < j.sg.n; ++q) maxw4 = max(maxw4, j.sg.width[q] >> 2);
   const int wb = (int)max((int64_t)1, min((int64_t)8192, ((win1 - win0) * maxw4 + 255) / 256));
   const int mb = 32;
+  GwPart gp;
+  memset(&gp, 0, sizeof(gp));
   BY_KIND(j.kind, k_lazy_opt, dim3(pn.blocks + pn.cu_blocks + wb + mb), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.a, j.sg, ds, z, 0, 0, mb, win0, win1,
-          0, 0, pn);
+          0, 0, pn, gp);
   HIP_TRY(hipGetLastError());
   return 0;
 }
