@@ -235,23 +235,58 @@ __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT,
   const float bias_d = bias[dv ? dcol : 0];
   TRACE(1);
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    // epilogue operands of this wave's 4 rows (wave, wave+8, wave+16, wave+24): independent of the k-loop, fetched first
+    // epilogue operands of this wave's 4 rows: independent of the k-loop, fetched first.
+    // !GEN: the wave takes the CONSECUTIVE rows 4 wave .. 4 wave + 3 — ONE Philox call per lane (= column) then yields the
+    // dropout draws of all four (a call covers 4 consecutive rows of a column), kept as four wave-uniform column masks — and in
+    // the epilogue a lane owns 4 consecutive columns of one of them (RPL lanes per row), so that h leaves as ONE dwordx4 store
+    // instruction per wave instead of four dword ones (a CU retires a dword-per-lane store only every ~40 ns).
+    // GEN (run-time row width, rows not 16-byte aligned): rows wave, wave + 8, ..., a lane per column.
+    constexpr int RPL = DW / 4;
+    const int erow = min(lane / RPL, 3);
+    const bool eact = lane / RPL < 4 && dbase + 4 * (lane % RPL) < Dr;      // (D = 16: half of the tile's 32 columns are padding)
+    const int ecol = eact ? 4 * (lane % RPL) : 0;
     float uval[4];
     uint32_t kbits = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int64_t lr = tile * 32 + wave + 8 * i;
-      const int64_t lrc = lr < L ? lr : (L - 1);
-      const int64_t u = X[2 * (int64_t)((uint32_t)lrc / rows_per_n)];
-      uval[i] = U[u * Dr + (dv ? dcol : 0)];
-      bool kept = true;
+    if (!GEN) {
+      const int64_t base = tile * 32 + 4 * wave;
+      const int64_t lre = base + erow, lrec = lre < L ? lre : (L - 1);
+      const int64_t ue = X[2 * (int64_t)((uint32_t)lrec / rows_per_n)];
+      const float4 u4 = *reinterpret_cast<const float4*>(&U[ue * Dr + dbase + ecol]);
+      uval[0] = u4.x; uval[1] = u4.y; uval[2] = u4.z; uval[3] = u4.w;
+      uint64_t km[4];
       if (MODE == 1) {
-        if (keep) kept = keep[lrc * Dr + (dv ? dcol : 0)] != 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int64_t lrc = base + i < L ? base + i : (L - 1);
+          km[i] = __ballot(dv && (keep ? keep[lrc * Dr + (dv ? dcol : 0)] != 0 : true));
+        }
       } else if (drop_thr) {
-        const u32x4 r4 = philox4x32_10((uint32_t)(lrc >> 2), (uint32_t)(dv ? dcol : 0), dkey.s0, dkey.s1, dkey.k0, dkey.k1);
-        kept = pick4(r4, (int)(lrc & 3)) >= drop_thr;
+        const u32x4 r4 = philox4x32_10((uint32_t)(base >> 2), (uint32_t)(dv ? dcol : 0), dkey.s0, dkey.s1, dkey.k0, dkey.k1);
+        km[0] = __ballot(dv && r4.x >= drop_thr);
+        km[1] = __ballot(dv && r4.y >= drop_thr);
+        km[2] = __ballot(dv && r4.z >= drop_thr);
+        km[3] = __ballot(dv && r4.w >= drop_thr);
+      } else {
+        km[0] = km[1] = km[2] = km[3] = ~0ull;
       }
-      kbits |= (kept ? 1u : 0u) << i;
+      const uint64_t mine = erow == 0 ? km[0] : (erow == 1 ? km[1] : (erow == 2 ? km[2] : km[3]));
+      kbits = (uint32_t)(mine >> ecol) & 15u;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t lr = tile * 32 + wave + 8 * i;
+        const int64_t lrc = lr < L ? lr : (L - 1);
+        const int64_t u = X[2 * (int64_t)((uint32_t)lrc / rows_per_n)];
+        uval[i] = U[u * Dr + (dv ? dcol : 0)];
+        bool kept = true;
+        if (MODE == 1) {
+          if (keep) kept = keep[lrc * Dr + (dv ? dcol : 0)] != 0;
+        } else if (drop_thr) {
+          const u32x4 r4 = philox4x32_10((uint32_t)(lrc >> 2), (uint32_t)(dv ? dcol : 0), dkey.s0, dkey.s1, dkey.k0, dkey.k1);
+          kept = pick4(r4, (int)(lrc & 3)) >= drop_thr;
+        }
+        kbits |= (kept ? 1u : 0u) << i;
+      }
     }
     const int64_t l = tile * 32 + c31;
     const bool lv = l < L;
@@ -318,6 +353,35 @@ __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT,
       }
     __syncthreads();
     TRACE(3);
+    if (!GEN) {
+      const int row = 4 * wave + erow;
+      const int64_t lr = tile * 32 + row;
+      const bool on = eact && lr < L;
+      float part = 0.f;
+      if (on) {
+        float4 z = *reinterpret_cast<const float4*>(&zpart[row * DW + ecol]);
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {
+          const float4 t = *reinterpret_cast<const float4*>(&zpart[(w * 32 + row) * DW + ecol]);
+          z.x += t.x; z.y += t.y; z.z += t.z; z.w += t.w;
+        }
+        const float4 b4 = *reinterpret_cast<const float4*>(&bias[dbase + ecol]);
+        z.x += b4.x; z.y += b4.y; z.z += b4.z; z.w += b4.w;
+        float4 hv;
+        hv.x = (z.x > 0.f && (kbits & 1u)) ? z.x * kscale : 0.f;
+        hv.y = (z.y > 0.f && (kbits & 2u)) ? z.y * kscale : 0.f;
+        hv.z = (z.z > 0.f && (kbits & 4u)) ? z.z * kscale : 0.f;
+        hv.w = (z.w > 0.f && (kbits & 8u)) ? z.w * kscale : 0.f;
+        if (store_h) *reinterpret_cast<float4*>(&hbuf[lr * DP + dbase + ecol]) = hv;          // the backward's input
+        part = uval[0] * hv.x + uval[1] * hv.y + uval[2] * hv.z + uval[3] * hv.w;
+      }
+#pragma unroll
+      for (int o = RPL / 2; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+      if (on && (lane % RPL) == 0) {
+        if (gridDim.y == 1) m[lr] = part;
+        else atomicAdd(&m[lr], part);
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = wave + 8 * i;
@@ -339,6 +403,7 @@ __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT,
           else atomicAdd(&m[lr], part);
         }
       }
+    }
     }
     TRACE(4);
     __syncthreads();
