@@ -38,6 +38,7 @@ struct Knobs {
   int64_t bwd_wgs;        // DCCF_BWD_WGS      role workgroups of the backward at 2B < 2048 (row splits = this / roles)
   bool lazy_cu;           // DCCF_LAZY_NO_CU=1 the lazy optimizer launch does not catch up the next step's rows (a launch of its own does)
   bool gw_part;           // DCCF_NO_GW_PART=1 dW of a lazy step as float atomics into gW (not per-split partial sums)
+  int64_t lazy_cu_blocks; // DCCF_LAZY_CU_BLOCKS workgroups of the next-step catch-up role (256: 128 / 512 / 768 measured, no better)
 };
 static const Knobs& knobs() {
   static const Knobs k = [] {
@@ -49,6 +50,7 @@ static const Knobs& knobs() {
     q.bwd_wgs = getenv("DCCF_BWD_WGS") ? atoll(getenv("DCCF_BWD_WGS")) : 256;
     q.lazy_cu = getenv("DCCF_LAZY_NO_CU") == nullptr;
     q.gw_part = getenv("DCCF_NO_GW_PART") == nullptr;
+    q.lazy_cu_blocks = getenv("DCCF_LAZY_CU_BLOCKS") ? max(1, atoi(getenv("DCCF_LAZY_CU_BLOCKS"))) : 256;
     return q;
   }();
   return k;
@@ -1634,7 +1636,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
         pn.w_end = pn.w_begin + (int64_t)D * (D + F);
         pn.blocks = (int)min((int64_t)64, (y.NS + pn.Lm + 255) / 256);
         if (knobs().lazy_cu) {
-          pn.cu_blocks = (int)min((int64_t)(getenv("DCCF_LAZY_CU_BLOCKS") ? atoi(getenv("DCCF_LAZY_CU_BLOCKS")) : 256), (N * (int64_t)(S1 + 1) + 3) / 4);
+          pn.cu_blocks = (int)min((int64_t)knobs().lazy_cu_blocks, (N * (int64_t)(S1 + 1) + 3) / 4);
           pn.cu_segU = plan->lazy_segU;
           pn.cu_segV = plan->lazy_segV;
         }
