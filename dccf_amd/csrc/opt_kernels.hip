@@ -570,49 +570,55 @@ extern "C" int dccf_dense_opt_step_dev(int32_t kind, float* p, float* g, float* 
 // (LazyArgs, lazy_replay and the window pass: opt_device.hpp — the backward launch can host the window)
 // Before the forward of step t: every distinct row the step reads (the batch's users, its candidates) is claimed by ONE wave
 // (atomicMax on claim), appended to the step's list and brought up to step t - 1.
-// one slot of a step's row list: the wave claims the row (the winner of a row's slots lists it) and brings it up to step t - 1
+// one slot of a step's row list, served by a 16-lane group (a float4 per lane, two for 128-wide rows): the group claims the row
+// (the winner of a row's slots lists it) and brings it up to step t - 1.  `live` = the group has a slot at all.
 template <int KIND>
 __device__ __forceinline__ void lazy_catchup_slot(float* __restrict__ p, float* __restrict__ s1, float* __restrict__ s2, const OptArgs& a,
                                                   const RowSegs& sg, const LazyArgs& z, int* claim, int* list, int64_t j, int q,
-                                                  int64_t row, int lane) {
+                                                  int64_t row, int lane, bool live) {
   const int t = (int)z.step;
+  const int sub = lane & 15;
   const int64_t grow = z.row_off[q] + row;
   int won = 0;
-  if (lane == 0) {
+  if (live && sub == 0) {
     won = atomicMax(&claim[grow], t) < t ? 1 : 0;
     list[j] = won ? (int)grow : -1;        // the step's rows, one entry per slot (-1: another slot owns the row): no shared
   }                                        // counter — 3,000 appends to one address took 40 us
-  won = __shfl(won, 0, 64);
+  won = __shfl(won, lane & 48, 64);
   if (!won) return;
   const LazyPend pend = lazy_pend_read(z);
-  const int from = __builtin_amdgcn_readfirstlane(lazy_eff_last(z, pend, grow));      // (uniform: scalar loads of the table)
+  const int from = lazy_eff_last(z, pend, grow);
   if (from >= t - 1) return;
-  const int w = sg.width[q];
-  float* pr = p + sg.begin[q] + row * w;
-  float* ar = s1 ? s1 + sg.begin[q] + row * w : nullptr;
-  float* br = s2 ? s2 + sg.begin[q] + row * w : nullptr;
-  for (int c = lane; c < w; c += 64) {
-    float pv = pr[c], av = KIND != DCCF_OPT_GD ? ar[c] : 0.f, bv = KIND == DCCF_OPT_ADAM ? br[c] : 0.f;
-    lazy_replay<KIND>(pv, av, bv, a, z, from, t - 1);
-    pr[c] = pv;
-    if (KIND != DCCF_OPT_GD) ar[c] = av;
-    if (KIND == DCCF_OPT_ADAM) br[c] = bv;
+  const int w4 = sg.width[q] >> 2;
+  const int64_t b4 = (sg.begin[q] + row * sg.width[q]) >> 2;
+  for (int c = sub; c < w4; c += 16) {
+    float4 pv = reinterpret_cast<float4*>(p)[b4 + c];
+    float4 av = make_float4(0, 0, 0, 0), bv = make_float4(0, 0, 0, 0);
+    if (KIND != DCCF_OPT_GD) av = reinterpret_cast<float4*>(s1)[b4 + c];
+    if (KIND == DCCF_OPT_ADAM) bv = reinterpret_cast<float4*>(s2)[b4 + c];
+    lazy_replay4<KIND>(pv, av, bv, a, z, from, t - 1);
+    reinterpret_cast<float4*>(p)[b4 + c] = pv;
+    if (KIND != DCCF_OPT_GD) reinterpret_cast<float4*>(s1)[b4 + c] = av;
+    if (KIND == DCCF_OPT_ADAM) reinterpret_cast<float4*>(s2)[b4 + c] = bv;
   }
-  if (lane == 0) z.last[grow] = t - 1;
+  if (sub == 0) z.last[grow] = t - 1;
 }
 
 template <int KIND>
 __global__ __launch_bounds__(256) void k_lazy_catchup(float* __restrict__ p, float* __restrict__ s1, float* __restrict__ s2,
                                                       OptArgs a, RowSegs sg, LazyArgs z, const int64_t* __restrict__ X,
                                                       const int* __restrict__ cand, int64_t N, int S1, int segU, int segV) {
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, grp = lane >> 4;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int64_t slots = N * S1 + N;
   int* claim = lazy_claim_of(z, (int)z.step);
   int* list = lazy_list_of(z, (int)z.step);
-  for (int64_t j = wave; j < slots; j += nw) {
-    if (j < N * S1) lazy_catchup_slot<KIND>(p, s1, s2, a, sg, z, claim, list, j, segV, cand[j], lane);
-    else lazy_catchup_slot<KIND>(p, s1, s2, a, sg, z, claim, list, j, segU, X[2 * (j - N * S1)], lane);
+  for (int64_t j0 = wave * 4; j0 < slots; j0 += nw * 4) {
+    const int64_t j = j0 + grp;
+    const bool live = j < slots;
+    const int64_t jc = live ? j : slots - 1;
+    if (jc < N * S1) lazy_catchup_slot<KIND>(p, s1, s2, a, sg, z, claim, list, jc, segV, cand[jc], lane, live);
+    else lazy_catchup_slot<KIND>(p, s1, s2, a, sg, z, claim, list, jc, segU, X[2 * (jc - N * S1)], lane, live);
   }
 }
 
@@ -623,13 +629,17 @@ __global__ __launch_bounds__(256) void k_lazy_catchup_rows(float* __restrict__ p
                                                            OptArgs a, RowSegs sg, LazyArgs z, const int* __restrict__ rows_a,
                                                            int64_t n_a, int seg_a, const int* __restrict__ rows_b, int64_t n_b,
                                                            int seg_b) {
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, grp = lane >> 4;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
   int* claim = lazy_claim_of(z, (int)z.step);
   int* list = lazy_list_of(z, (int)z.step);
-  for (int64_t j = wave; j < n_a + n_b; j += nw) {
-    if (j < n_a) lazy_catchup_slot<KIND>(p, s1, s2, a, sg, z, claim, list, j, seg_a, rows_a[j], lane);
-    else lazy_catchup_slot<KIND>(p, s1, s2, a, sg, z, claim, list, j, seg_b, rows_b[j - n_a], lane);
+  const int64_t slots = n_a + n_b;
+  for (int64_t j0 = wave * 4; j0 < slots; j0 += nw * 4) {
+    const int64_t j = j0 + grp;
+    const bool live = j < slots;
+    const int64_t jc = live ? j : slots - 1;
+    if (jc < n_a) lazy_catchup_slot<KIND>(p, s1, s2, a, sg, z, claim, list, jc, seg_a, rows_a[jc], lane, live);
+    else lazy_catchup_slot<KIND>(p, s1, s2, a, sg, z, claim, list, jc, seg_b, rows_b[jc - n_a], lane, live);
   }
 }
 
@@ -663,9 +673,14 @@ __global__ __launch_bounds__(256) void k_lazy_opt(float* __restrict__ p, float* 
     int* claim_n = lazy_claim_of(z, t + 1);
     int* list_n = pn.X_all ? nullptr : lazy_list_of(z, t + 1);
     const LazyPend pend = lazy_pend_read(z);
-    for (int64_t jg = (int64_t)bid * 4 + wv; jg < slots; jg += (int64_t)pn.cu_blocks * 4) {
-      const int r = (int)(jg / per_rank);
-      const int64_t j = jg - (int64_t)r * per_rank;
+    // a slot per 16-lane group, a float4 per lane (see the list role)
+    const int grp = lane >> 4, sub = lane & 15;
+    for (int64_t jg0 = ((int64_t)bid * 4 + wv) * 4; jg0 < slots; jg0 += (int64_t)pn.cu_blocks * 16) {
+      const int64_t jg = jg0 + grp;
+      const bool live = jg < slots;
+      const int64_t jc = live ? jg : slots - 1;
+      const int r = (int)(jc / per_rank);
+      const int64_t j = jc - (int64_t)r * per_rank;
       const int64_t* __restrict__ Xr = pn.X_all ? pn.X_all + (int64_t)r * pn.N * 2 : pn.X;
       int q;
       int64_t row;
@@ -686,55 +701,64 @@ __global__ __launch_bounds__(256) void k_lazy_opt(float* __restrict__ p, float* 
       }
       const int64_t grow = z.row_off[q] + row;
       int won = 0;
-      if (lane == 0) {
+      if (live && sub == 0) {
         won = atomicMax(&claim_n[grow], t + 1) < t + 1 ? 1 : 0;
         if (list_n) list_n[j] = won ? (int)grow : -1;
       }
-      won = __shfl(won, 0, 64);
-      if (!won) continue;
-      if (claim_t[grow] == t) continue;                         // this step's list role
-      if (grow >= win0 && grow < win1) continue;                // this step's window role
-      const int from = __builtin_amdgcn_readfirstlane(lazy_eff_last(z, pend, grow));
+      won = __shfl(won, lane & 48, 64);
+      // not mine: lost the row to another slot; on this step's list (that role brings it to t); in this step's window (ditto)
+      if (!won || claim_t[grow] == t || (grow >= win0 && grow < win1)) continue;
+      const int from = lazy_eff_last(z, pend, grow);
       if (from >= t) continue;
-      const int w = sg.width[q];
-      float* pr = p + sg.begin[q] + row * w;
-      float* ar = s1 ? s1 + sg.begin[q] + row * w : nullptr;
-      float* br = s2 ? s2 + sg.begin[q] + row * w : nullptr;
-      for (int c = lane; c < w; c += 64) {
-        float pv = pr[c], av = KIND != DCCF_OPT_GD ? ar[c] : 0.f, bv = KIND == DCCF_OPT_ADAM ? br[c] : 0.f;
-        lazy_replay<KIND>(pv, av, bv, a, z, from, t);
-        pr[c] = pv;
-        if (KIND != DCCF_OPT_GD) ar[c] = av;
-        if (KIND == DCCF_OPT_ADAM) br[c] = bv;
+      const int w4 = sg.width[q] >> 2;
+      const int64_t b4 = (sg.begin[q] + row * sg.width[q]) >> 2;
+      for (int c = sub; c < w4; c += 16) {
+        float4 pv = reinterpret_cast<float4*>(p)[b4 + c];
+        float4 av = make_float4(0, 0, 0, 0), bv = make_float4(0, 0, 0, 0);
+        if (KIND != DCCF_OPT_GD) av = reinterpret_cast<float4*>(s1)[b4 + c];
+        if (KIND == DCCF_OPT_ADAM) bv = reinterpret_cast<float4*>(s2)[b4 + c];
+        lazy_replay4<KIND>(pv, av, bv, a, z, from, t);
+        reinterpret_cast<float4*>(p)[b4 + c] = pv;
+        if (KIND != DCCF_OPT_GD) reinterpret_cast<float4*>(s1)[b4 + c] = av;
+        if (KIND == DCCF_OPT_ADAM) reinterpret_cast<float4*>(s2)[b4 + c] = bv;
       }
       // (the marks role of this launch may be writing the pending window's step into the same entry: both are maxima)
-      if (lane == 0) atomicMax(&z.last[grow], t);
+      if (sub == 0) atomicMax(&z.last[grow], t);
     }
     return;
   }
   bid -= pn.cu_blocks;
   if (bid < lb) {                              // ---- the rows this step touched
+    // a row per 16-lane group, a float4 per lane (two for 128-wide rows): 4 rows per store instruction — a CU retires a
+    // dword-per-lane store only every ~40 ns, and four rows of a wave progress together instead of one after the other
     const int* __restrict__ list = lazy_list_of(z, t);
-    for (int e = bid * 4 + wv; e < nslots; e += lb * 4) {
-      const int64_t grow = list[e];
+    const int grp = lane >> 4, sub = lane & 15;
+    for (int e0 = (bid * 4 + wv) * 4; e0 < nslots; e0 += lb * 16) {
+      const int e = e0 + grp;
+      const int64_t grow = e < nslots ? list[e] : -1;
       if (grow < 0) continue;
       int q = 0;
 #pragma unroll
       for (int k = 1; k < 4; ++k)
         if (k < sg.n && grow >= z.row_off[k]) q = k;
       const int64_t row = grow - z.row_off[q];
-      const int w = sg.width[q];
-      const int64_t base = sg.begin[q] + row * w;
-      for (int c = lane; c < w; c += 64) {
-        float pv = p[base + c], gv = g[base + c], av = KIND != DCCF_OPT_GD ? s1[base + c] : 0.f,
-              bv = KIND == DCCF_OPT_ADAM ? s2[base + c] : 0.f;
-        opt_elem<KIND>(pv, gv, av, bv, a);
-        p[base + c] = pv;
-        g[base + c] = 0.f;
-        if (KIND != DCCF_OPT_GD) s1[base + c] = av;
-        if (KIND == DCCF_OPT_ADAM) s2[base + c] = bv;
+      const int w4 = sg.width[q] >> 2;
+      const int64_t b4 = (sg.begin[q] + row * sg.width[q]) >> 2;
+      for (int c = sub; c < w4; c += 16) {
+        float4 pv = reinterpret_cast<float4*>(p)[b4 + c], gv = reinterpret_cast<float4*>(g)[b4 + c];
+        float4 av = make_float4(0, 0, 0, 0), bv = make_float4(0, 0, 0, 0);
+        if (KIND != DCCF_OPT_GD) av = reinterpret_cast<float4*>(s1)[b4 + c];
+        if (KIND == DCCF_OPT_ADAM) bv = reinterpret_cast<float4*>(s2)[b4 + c];
+        opt_elem<KIND>(pv.x, gv.x, av.x, bv.x, a);
+        opt_elem<KIND>(pv.y, gv.y, av.y, bv.y, a);
+        opt_elem<KIND>(pv.z, gv.z, av.z, bv.z, a);
+        opt_elem<KIND>(pv.w, gv.w, av.w, bv.w, a);
+        reinterpret_cast<float4*>(p)[b4 + c] = pv;
+        reinterpret_cast<float4*>(g)[b4 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (KIND != DCCF_OPT_GD) reinterpret_cast<float4*>(s1)[b4 + c] = av;
+        if (KIND == DCCF_OPT_ADAM) reinterpret_cast<float4*>(s2)[b4 + c] = bv;
       }
-      if (lane == 0) {
+      if (sub == 0) {
         z.last[grow] = t;
         sg.flags[q][row] = 0;
       }
