@@ -61,11 +61,9 @@ __device__ __forceinline__ float div_normal(float n, float d) {
 // "+ 1e-8" (ulp 2^-50 after the division by c >= 0.03).
 __device__ __forceinline__ float sqrt_bare(float v) { return __builtin_amdgcn_sqrtf(v); }
 
+// everything after the clip: the optimizer's coupled weight decay and its step
 template <int KIND>
-__device__ __forceinline__ void opt_elem(float& p, float& g, float& s1, float& s2, const OptArgs& a) {
-  // explicit l2 term of the loss, then the clip, then the optimizer's coupled weight decay
-  float gt = __fadd_rn(g, __fmul_rn(a.l2, __fmul_rn(2.0f, p)));
-  gt = __builtin_amdgcn_fmed3f(gt, -a.clip, a.clip);      // clamp(gt, -clip, clip), clip >= 0 (checked on the host): one instruction
+__device__ __forceinline__ void opt_elem_rest(float& p, float gt, float& s1, float& s2, const OptArgs& a) {
   gt = __fadd_rn(gt, __fmul_rn(a.wd, p));
   if (KIND == DCCF_OPT_GD) {
     p = __fadd_rn(p, __fmul_rn(-a.lr, gt));
@@ -79,9 +77,34 @@ __device__ __forceinline__ void opt_elem(float& p, float& g, float& s1, float& s
     const float denom = __fadd_rn(div_by_uniform(sqrt_bare(s2), a.bc2_sqrt, a.bc2_rsqrt), 1e-8f);
     p = __fadd_rn(p, div_normal(__fmul_rn(a.step_size_neg, s1), denom));
   }
+}
+
+template <int KIND>
+__device__ __forceinline__ void opt_elem(float& p, float& g, float& s1, float& s2, const OptArgs& a) {
+  // explicit l2 term of the loss, then the clip, then the optimizer's coupled weight decay
+  float gt = __fadd_rn(g, __fmul_rn(a.l2, __fmul_rn(2.0f, p)));
+  gt = __builtin_amdgcn_fmed3f(gt, -a.clip, a.clip);      // clamp(gt, -clip, clip), clip >= 0 (checked on the host): one instruction
+  opt_elem_rest<KIND>(p, gt, s1, s2, a);
   if (a.zero_grad) g = 0.f;
 }
 
+// Four elements at once: the same operations in the same order per element (hence the same bits as four opt_elem calls); the
+// head g + l2 (2 p) is written on 2-vectors because the compiler packs everything AFTER the clip into v_pk_*_f32 on its own but
+// leaves these three operations scalar (12 of the 83 vector instructions of four Adam element-steps).
+typedef float opt_f2 __attribute__((ext_vector_type(2)));
+template <int KIND>
+__device__ __forceinline__ void opt_elem4(float4& p, float4& g, float4& s1, float4& s2, const OptArgs& a) {
+  const opt_f2 two = {2.0f, 2.0f}, l2v = {a.l2, a.l2};
+  const opt_f2 plo = {p.x, p.y}, phi = {p.z, p.w}, glo = {g.x, g.y}, ghi = {g.z, g.w};
+  const opt_f2 tlo = glo + l2v * (two * plo), thi = ghi + l2v * (two * phi);
+  const float gx = __builtin_amdgcn_fmed3f(tlo.x, -a.clip, a.clip), gy = __builtin_amdgcn_fmed3f(tlo.y, -a.clip, a.clip);
+  const float gz = __builtin_amdgcn_fmed3f(thi.x, -a.clip, a.clip), gw = __builtin_amdgcn_fmed3f(thi.y, -a.clip, a.clip);
+  opt_elem_rest<KIND>(p.x, gx, s1.x, s2.x, a);
+  opt_elem_rest<KIND>(p.y, gy, s1.y, s2.y, a);
+  opt_elem_rest<KIND>(p.z, gz, s1.z, s2.z, a);
+  opt_elem_rest<KIND>(p.w, gw, s1.w, s2.w, a);
+  if (a.zero_grad) g = make_float4(0.f, 0.f, 0.f, 0.f);
+}
 
 // The same element step on the compiler's IEEE division / square root: what opt_elem is checked against (dccf_debug_opt_elem).
 template <int KIND>
@@ -167,10 +190,7 @@ __device__ __forceinline__ void opt_untouched_pass(const OptJob& j, int64_t bid,
       if (fv[u] == 0) {
         const int64_t i = i0 + u * stride;
         float4 gv = make_float4(0, 0, 0, 0);
-        opt_elem<KIND>(pv[u].x, gv.x, av[u].x, bv[u].x, j.a);
-        opt_elem<KIND>(pv[u].y, gv.y, av[u].y, bv[u].y, j.a);
-        opt_elem<KIND>(pv[u].z, gv.z, av[u].z, bv[u].z, j.a);
-        opt_elem<KIND>(pv[u].w, gv.w, av[u].w, bv[u].w, j.a);
+        opt_elem4<KIND>(pv[u], gv, av[u], bv[u], j.a);
         reinterpret_cast<float4*>(p)[i] = pv[u];
         if (KIND != DCCF_OPT_GD) reinterpret_cast<float4*>(s1)[i] = av[u];
         if (KIND == DCCF_OPT_ADAM) reinterpret_cast<float4*>(s2)[i] = bv[u];
@@ -240,10 +260,7 @@ __device__ __forceinline__ void lazy_replay4(float4& p, float4& s1, float4& s2, 
       a.step_size_neg = sc.x; a.bc2_sqrt = sc.y; a.bc2_rsqrt = sc.z;
     }
     float4 g0 = make_float4(0, 0, 0, 0);
-    opt_elem<KIND>(p.x, g0.x, s1.x, s2.x, a);
-    opt_elem<KIND>(p.y, g0.y, s1.y, s2.y, a);
-    opt_elem<KIND>(p.z, g0.z, s1.z, s2.z, a);
-    opt_elem<KIND>(p.w, g0.w, s1.w, s2.w, a);
+    opt_elem4<KIND>(p, g0, s1, s2, a);
   }
 }
 

@@ -177,10 +177,7 @@ __global__ __launch_bounds__(256) void k_dense_opt(float* __restrict__ p, float*
     float4 av = make_float4(0, 0, 0, 0), bv = make_float4(0, 0, 0, 0);
     if (KIND != DCCF_OPT_GD) av = reinterpret_cast<float4*>(s1)[i];
     if (KIND == DCCF_OPT_ADAM) bv = reinterpret_cast<float4*>(s2)[i];
-    opt_elem<KIND>(pv.x, gv.x, av.x, bv.x, a);
-    opt_elem<KIND>(pv.y, gv.y, av.y, bv.y, a);
-    opt_elem<KIND>(pv.z, gv.z, av.z, bv.z, a);
-    opt_elem<KIND>(pv.w, gv.w, av.w, bv.w, a);
+    opt_elem4<KIND>(pv, gv, av, bv, a);
     reinterpret_cast<float4*>(p)[i] = pv;
     if (a.zero_grad) reinterpret_cast<float4*>(g)[i] = gv;
     if (KIND != DCCF_OPT_GD) reinterpret_cast<float4*>(s1)[i] = av;
@@ -224,10 +221,7 @@ __device__ __forceinline__ void touched_rows(float* __restrict__ p, float* __res
       float4 av = make_float4(0, 0, 0, 0), bv = make_float4(0, 0, 0, 0);
       if (KIND != DCCF_OPT_GD) av = reinterpret_cast<float4*>(s1)[i];
       if (KIND == DCCF_OPT_ADAM) bv = reinterpret_cast<float4*>(s2)[i];
-      opt_elem<KIND>(pv.x, gv.x, av.x, bv.x, a);
-      opt_elem<KIND>(pv.y, gv.y, av.y, bv.y, a);
-      opt_elem<KIND>(pv.z, gv.z, av.z, bv.z, a);
-      opt_elem<KIND>(pv.w, gv.w, av.w, bv.w, a);
+      opt_elem4<KIND>(pv, gv, av, bv, a);
       reinterpret_cast<float4*>(p)[i] = pv;
       reinterpret_cast<float4*>(g)[i] = make_float4(0, 0, 0, 0);
       if (KIND != DCCF_OPT_GD) reinterpret_cast<float4*>(s1)[i] = av;
@@ -314,10 +308,7 @@ __global__ __launch_bounds__(256) void k_dense_opt_rows(float* __restrict__ p, f
       if (!live[u]) continue;
       if (phase == OPT_PHASE_UNTOUCHED && (!fl[u] || touched[u])) continue;     // those wait for the backward (k_opt_touched)
       if (touched[u]) gv[u] = reinterpret_cast<float4*>(g)[i];
-      opt_elem<KIND>(pv[u].x, gv[u].x, av[u].x, bv[u].x, a);
-      opt_elem<KIND>(pv[u].y, gv[u].y, av[u].y, bv[u].y, a);
-      opt_elem<KIND>(pv[u].z, gv[u].z, av[u].z, bv[u].z, a);
-      opt_elem<KIND>(pv[u].w, gv[u].w, av[u].w, bv[u].w, a);
+      opt_elem4<KIND>(pv[u], gv[u], av[u], bv[u], a);
       reinterpret_cast<float4*>(p)[i] = pv[u];
       if (pn.blocks && i * 4 >= pn.w_begin && i * 4 < pn.w_end) {      // the forward's transposed copy of W, for the next step
         prep_next_wt(pn, i * 4, pv[u].x);
@@ -749,10 +740,7 @@ __global__ __launch_bounds__(256) void k_lazy_opt(float* __restrict__ p, float* 
         float4 av = make_float4(0, 0, 0, 0), bv = make_float4(0, 0, 0, 0);
         if (KIND != DCCF_OPT_GD) av = reinterpret_cast<float4*>(s1)[b4 + c];
         if (KIND == DCCF_OPT_ADAM) bv = reinterpret_cast<float4*>(s2)[b4 + c];
-        opt_elem<KIND>(pv.x, gv.x, av.x, bv.x, a);
-        opt_elem<KIND>(pv.y, gv.y, av.y, bv.y, a);
-        opt_elem<KIND>(pv.z, gv.z, av.z, bv.z, a);
-        opt_elem<KIND>(pv.w, gv.w, av.w, bv.w, a);
+        opt_elem4<KIND>(pv, gv, av, bv, a);
         reinterpret_cast<float4*>(p)[b4 + c] = pv;
         reinterpret_cast<float4*>(g)[b4 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (KIND != DCCF_OPT_GD) reinterpret_cast<float4*>(s1)[b4 + c] = av;
