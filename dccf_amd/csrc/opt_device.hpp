@@ -265,6 +265,29 @@ __device__ __forceinline__ void lazy_replay4(float4& p, float4& s1, float4& s2, 
 }
 
 
+// lazy_replay4 with a WAVE-UNIFORM loop counter: `lo` <= every lane's `from` (lanes with nothing to do pass from = to).  The
+// step scalars are then read by scalar loads the compiler can issue ahead, not by a vector load per lane and step inside the
+// dependent chain; a lane joins at its own first step.
+__device__ __forceinline__ int wave_min_int(int v) {          // (every lane of the wave must call it)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+  return __builtin_amdgcn_readfirstlane(v);
+}
+template <int KIND>
+__device__ __forceinline__ void lazy_replay4_u(float4& p, float4& s1, float4& s2, OptArgs a, const float4* sct, int sct_base,
+                                               int from, int to, int lo) {
+  for (int s = lo + 1; s <= to; ++s) {
+    if (KIND == DCCF_OPT_ADAM) {
+      const float4 sc = sct[s - sct_base];          // (sct: the launch's copy of the step scalars in LDS, or the table itself)
+      a.step_size_neg = sc.x; a.bc2_sqrt = sc.y; a.bc2_rsqrt = sc.z;
+    }
+    if (s > from) {
+      float4 g0 = make_float4(0, 0, 0, 0);
+      opt_elem4<KIND>(p, g0, s1, s2, a);
+    }
+  }
+}
+
 // The window of step t: the float4 slots of the rows [win0, win1) of the global row space are advanced to step t (rows this
 // step uses — claim == t — excepted: the step's list updates them with their gradient).  All lanes busy: rows are contiguous.
 // Runs as workgroups bid of nblk — of the optimizer launch, or hosted in the backward launch, whose role waves leave most of
@@ -272,7 +295,7 @@ __device__ __forceinline__ void lazy_replay4(float4& p, float4& s1, float4& s2, 
 template <int KIND>
 __device__ __forceinline__ void lazy_window_pass(float* __restrict__ p, float* __restrict__ s1, float* __restrict__ s2,
                                                  const OptArgs& a, const RowSegs& sg, const LazyArgs& z, int64_t win0, int64_t win1,
-                                                 int flush, int64_t bid, int64_t nblk, int nthreads) {
+                                                 int flush, int64_t bid, int64_t nblk, int nthreads, const float4* sct, int sct_base) {
   const int t = (int)z.step;
   const LazyPend pend = lazy_pend_read(z);
   const int* __restrict__ claim = lazy_claim_of(z, t);
@@ -281,18 +304,24 @@ __device__ __forceinline__ void lazy_window_pass(float* __restrict__ p, float* _
     if (r1 <= r0) continue;
     const int w4 = sg.width[q] >> 2;
     const int64_t nslot = (r1 - r0) * w4;
-    for (int64_t x = bid * nthreads + threadIdx.x; x < nslot; x += nblk * nthreads) {
-      const int64_t row = r0 + x / w4;
+    for (int64_t x0 = bid * nthreads; x0 < nslot; x0 += nblk * nthreads) {      // (uniform per workgroup: every lane reaches wave_min_int)
+      const int64_t x = x0 + threadIdx.x;
+      const bool live = x < nslot;
+      const int64_t xc = live ? x : nslot - 1;
+      const int64_t row = r0 + xc / w4;
       const int64_t grow = z.row_off[q] + row;
       const int from = lazy_eff_last(z, pend, grow);
       // a row this step touched is the list's business (its last is t - 1 until that wave has updated it: never replay it here)
-      if (from >= t || (!flush && claim[grow] == t)) continue;
-      const int64_t i = (sg.begin[q] >> 2) + row * w4 + x % w4;
+      const bool need = live && from < t && (flush || claim[grow] != t);
+      const int fr = need ? from : t;
+      const int lo = max(wave_min_int(fr), sct_base);      // (no row is more than K steps behind: the bound is for memory safety)
+      if (lo >= t || !need) continue;
+      const int64_t i = (sg.begin[q] >> 2) + row * w4 + xc % w4;
       float4 pv = reinterpret_cast<float4*>(p)[i];
       float4 av = make_float4(0, 0, 0, 0), bv = make_float4(0, 0, 0, 0);
       if (KIND != DCCF_OPT_GD) av = reinterpret_cast<float4*>(s1)[i];
       if (KIND == DCCF_OPT_ADAM) bv = reinterpret_cast<float4*>(s2)[i];
-      lazy_replay4<KIND>(pv, av, bv, a, z, from, t);
+      lazy_replay4_u<KIND>(pv, av, bv, a, sct, sct_base, fr, t, lo);
       reinterpret_cast<float4*>(p)[i] = pv;
       if (KIND != DCCF_OPT_GD) reinterpret_cast<float4*>(s1)[i] = av;
       if (KIND == DCCF_OPT_ADAM) reinterpret_cast<float4*>(s2)[i] = bv;

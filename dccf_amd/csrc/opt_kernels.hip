@@ -558,6 +558,7 @@ extern "C" int dccf_dense_opt_step_dev(int32_t kind, float* p, float* g, float* 
 }
 
 // ---------------------------------------------------------------------------------------------- windowed lazy regularisation
+#define LAZY_KMAX 64      // largest lazy_K (the launch keeps K + 1 step-scalar entries in LDS)
 // (LazyArgs, lazy_replay and the window pass: opt_device.hpp — the backward launch can host the window)
 // Before the forward of step t: every distinct row the step reads (the batch's users, its candidates) is claimed by ONE wave
 // (atomicMax on claim), appended to the step's list and brought up to step t - 1.
@@ -643,6 +644,15 @@ __global__ __launch_bounds__(256) void k_lazy_opt(float* __restrict__ p, float* 
                                                   float* __restrict__ s2, OptArgs a, RowSegs sg, DenseSegs ds, LazyArgs z,
                                                   int lb, int db, int mb, int64_t win0, int64_t win1, int flush, int nslots,
                                                   PrepNext pn, GwPart gp) {
+  // the step scalars of the steps this launch can replay (t - K + 1 .. t), copied to LDS once: the replay loops read them with
+  // a broadcast ds_read instead of a global load per lane and step inside their dependent chains
+  __shared__ float4 s_sct[LAZY_KMAX + 1];
+  const int sct_base = max((int)z.step - z.K, 0);
+  if (KIND == DCCF_OPT_ADAM) {
+    const int s = sct_base + (int)threadIdx.x;
+    if ((int)threadIdx.x <= z.K && s >= (int)z.t0 && s <= (int)z.step) s_sct[threadIdx.x] = reinterpret_cast<const float4*>(z.scal)[s - z.t0];
+    __syncthreads();
+  }
   if ((int)blockIdx.x < pn.blocks) {
     prep_next_slots(pn, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)pn.blocks * blockDim.x);
     return;
@@ -785,7 +795,7 @@ __global__ __launch_bounds__(256) void k_lazy_opt(float* __restrict__ p, float* 
   bid -= db;
   const int wb = (int)gridDim.x - pn.blocks - pn.cu_blocks - lb - db - mb;
   if (bid < wb) {                              // ---- the window (unless the backward launch hosted it)
-    lazy_window_pass<KIND>(p, s1, s2, a, sg, z, win0, win1, flush, bid, wb, blockDim.x);
+    lazy_window_pass<KIND>(p, s1, s2, a, sg, z, win0, win1, flush, bid, wb, blockDim.x, s_sct, sct_base);
     return;
   }
   bid -= wb;
@@ -811,7 +821,7 @@ __global__ __launch_bounds__(256) void k_lazy_mark(LazyArgs z, int64_t win0, int
 }
 
 static int lazy_args(const dccf_opt_t* o, const OptJob& j, LazyArgs* z) {
-  ARG_CHECK(o->lazy_K >= 2 && o->lazy_last && o->lazy_claim && o->lazy_list && o->lazy_cnt && o->lazy_list_cap > 0,
+  ARG_CHECK(o->lazy_K >= 2 && o->lazy_K <= LAZY_KMAX && o->lazy_last && o->lazy_claim && o->lazy_list && o->lazy_cnt && o->lazy_list_cap > 0,
             "lazy optimizer: lazy_K >= 2 and all arrays");
   ARG_CHECK(j.sg.n >= 1, "lazy optimizer needs row segments");
   ARG_CHECK(o->kind != DCCF_OPT_ADAM || (o->lazy_scal && o->lazy_t0 <= max((int64_t)1, o->step - o->lazy_K + 1) &&
@@ -909,7 +919,8 @@ static int lazy_launch(const dccf_opt_t* o, int flush, const PrepNext* pnp, int6
   for (int q = 0; q < j.sg.n; ++q) maxw4 = max(maxw4, j.sg.width[q] >> 2);
   const int lb = (flush || nslots == 0) ? 0 : (int)min((int64_t)256, (nslots + 3) / 4);
   const int db = flush ? 0 : (int)min((int64_t)256, (dense_total + 255) / 256);
-  const int wb = (int)max((int64_t)1, min((int64_t)8192, ((win1 - win0) * maxw4 + 255) / 256));
+  static const int wb_cap = getenv("DCCF_LAZY_WB") ? max(1, atoi(getenv("DCCF_LAZY_WB"))) : 8192;
+  const int wb = (int)max((int64_t)1, min((int64_t)(flush ? 8192 : wb_cap), ((win1 - win0) * maxw4 + 255) / 256));
   const int mb = flush ? 0 : 32;       // (a flush marks with a launch of its own: every row, and nothing stays pending)
   ARG_CHECK(nslots <= z.list_cap && (pn.cu_blocks == 0 || pn.X_all || pn.N * (pn.S + 2) <= z.list_cap), "lazy optimizer: lazy_list_cap too small");
   if (flush) pn.cu_blocks = 0;
