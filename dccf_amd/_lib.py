@@ -17,7 +17,8 @@ EXPORTS = ['dccf_ctx_create', 'dccf_ctx_destroy', 'dccf_ctx_reserve', 'dccf_last
            'shard_pack_rows', 'shard_unpack_rows', 'shard_scatter_add', 'dccf_dense_opt_step_rows', 'dccf_dense_opt_step_dev', 'dccf_advance', 'rank_eval_topk', 'dccf_train_step', 'dp_buffer_words',
            'dp_export_touched', 'dp_import_touched', 'dp_mark_global', 'dccf_dense_opt_phase', 'dccf_ctx_side_stream', 'dp_import_apply',
            'dccf_sample_eval_negatives', 'dccf_eval_prepare', 'dccf_predict_projected', 'dccf_dp_local', 'dccf_dp_overlap',
-           'dccf_dp_finish', 'dccf_ctx_prepared_steps', 'dccf_ctx_hosted_rows', 'shard_pack_multi', 'shard_unpack_multi', 'dccf_build_epoch_batches', 'dccf_lazy_scalars', 'dccf_lazy_flush', 'dccf_lazy_catchup_rows', 'dccf_lazy_opt_step']
+           'dccf_dp_finish', 'dccf_ctx_prepared_steps', 'dccf_ctx_hosted_rows', 'shard_pack_multi', 'shard_unpack_multi', 'dccf_build_epoch_batches', 'dccf_lazy_scalars', 'dccf_lazy_flush', 'dccf_lazy_catchup_rows', 'dccf_lazy_opt_step', 'dccf_comm_unique_id',
+           'dccf_comm_create', 'dccf_comm_destroy', 'dccf_comm_all_to_all_rows', 'dccf_comm_all_reduce_sum']
 
 ABI_VERSION = 5
 OPT_KIND = {'gd': 0, 'adagrad': 1, 'adam': 2}
@@ -154,6 +155,11 @@ def load():
         'dccf_lazy_scalars': [f32, i64, i32, vp],
         'dccf_lazy_catchup_rows': [C.POINTER(OptT), vp, i64, i32, vp, i64, i32, vp],
         'dccf_lazy_opt_step': [C.POINTER(OptT), i64, vp],
+        'dccf_comm_unique_id': [vp],
+        'dccf_comm_create': [C.POINTER(vp), vp, i32, i32],
+        'dccf_comm_destroy': [vp],
+        'dccf_comm_all_to_all_rows': [vp, vp, vp, vp, vp, i64, vp],
+        'dccf_comm_all_reduce_sum': [vp, vp, i64, vp],
         'dccf_lazy_flush': [C.POINTER(OptT), vp],
         'shard_unpack_multi': [vp, i32, vp, i64, vp],
     }
@@ -183,7 +189,15 @@ def ptr(t, dtype=None):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_cur_device = getattr(torch._C, '_cuda_getDevice', None)
+
+
 def stream():
+    """torch's current stream of the current device as a hipStream_t.  (torch.cuda.current_stream() builds a Stream object
+    through several Python layers: 4-8 us per call, and a step of the sharded trainer asks ten times.)"""
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -326,6 +340,40 @@ def opt_struct(kind, p, g, s1, s2, lr, wd, l2, clip, segments, overlap):
     o.lr, o.wd, o.l2, o.clip, o.nseg = float(lr), float(wd), float(l2), float(clip), n
     o.seg_begin, o.seg_rows, o.seg_width, o.seg_flags = [C.cast(a, C.c_void_p) for a in o._refs[:4]]
     return o
+
+
+class Comm(object):
+    """The row-sharded trainer's collectives straight on RCCL (include/dccf_hip.h, dccf_comm_*): one C call each on torch's
+    current stream instead of a torch.distributed call.  Collective constructor: every rank of `group` calls it."""
+
+    def __init__(self, rank, world, device, group=None):
+        import torch.distributed as dist
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = (C.c_uint8 * 128)()
+            check(load().dccf_comm_unique_id(buf))
+            ident = torch.tensor(list(buf), dtype=torch.uint8)
+        ident = ident.to(device)
+        if world > 1:
+            dist.broadcast(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        raw = (C.c_uint8 * 128)(*ident.cpu().tolist())
+        self.h = C.c_void_p()
+        self.world = int(world)
+        with torch.cuda.device(device):
+            check(load().dccf_comm_create(C.byref(self.h), raw, int(world), int(rank)))
+
+    def all_to_all_rows(self, out, inp, send_rows, recv_rows, width):
+        """send_rows / recv_rows: int64 numpy arrays [world] (rows per peer); out / inp: float32 tensors."""
+        check(load().dccf_comm_all_to_all_rows(self.h, ptr(inp), send_rows.ctypes.data, ptr(out), recv_rows.ctypes.data, int(width),
+                                               stream()))
+
+    def all_reduce_sum(self, buf):
+        check(load().dccf_comm_all_reduce_sum(self.h, ptr(buf), buf.numel(), stream()))
+
+    def close(self):
+        if self.h:
+            load().dccf_comm_destroy(self.h)
+            self.h = C.c_void_p()
 
 
 class LazyState(object):

@@ -42,7 +42,7 @@ def build(force=False, verbose=True):
         subprocess.check_call(c)
         objs.append(obj)
     cmd = [os.environ.get('CXX', 'g++'), '-shared', '-o', LIB] + objs + \
-          ['-L' + tlib, '-lamdhip64', '-Wl,-rpath,' + tlib, '-Wl,--no-undefined']
+          ['-L' + tlib, '-lamdhip64', '-ldl', '-Wl,-rpath,' + tlib, '-Wl,--no-undefined']
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)

@@ -103,6 +103,7 @@ class _Route(object):
         lf, af = lidx.reshape(nb, G * T), is_a.reshape(nb, G * T)
         counts = mine.sum(2)                                   # [nb, G] rows I send to q
         self.send_splits, self.send_n = counts.tolist(), counts.sum(1).tolist()
+        self.send_np = counts.to(torch.int64).cpu().numpy().copy()             # [nb, G] rows per peer (the direct RCCL path)
         self.send_max = max(1, max(self.send_n))
         na, nbb = (mf & af).sum(1), (mf & ~af).sum(1)
         self.na, self.nb_ = na.tolist(), nbb.tolist()
@@ -115,13 +116,15 @@ class _Route(object):
         self.perm = perm
         self.inv = torch.empty_like(perm)
         self.inv.scatter_(1, perm, torch.arange(T, device=dev).expand(nb, T))    # slot t sits at inv[t]
-        self.recv_splits = torch.stack([(my_owner == o).sum(1) for o in range(G)], 1).tolist()
+        rs = torch.stack([(my_owner == o).sum(1) for o in range(G)], 1)
+        self.recv_splits = rs.tolist()
+        self.recv_np = rs.to(torch.int64).cpu().numpy().copy()
         self.T = T
 
 
 class ShardedDCCF(object):
     def __init__(self, rank, world, user_num, item_num, D, S, A, std, dropout, lr, l2, seed, backend, device,
-                 feat_local, ips_local, group=None, lazy_K=None):
+                 feat_local, ips_local, group=None, lazy_K=None, direct=None):
         """feat_local: [ceil(item_num/G), F] rows of the items i = rank (mod G); ips_local: dict P [nU_loc,Dq], bu [nU_loc],
         Q [nI_loc,Dq], bi [nI_loc], prop [nI_loc], b0, M — the IPSBiasedMF factors of the exposure score."""
         self.rank, self.G, self.group, self.dev, self.be = rank, world, group, device, backend
@@ -161,6 +164,13 @@ class ShardedDCCF(object):
         import os
         self.lazy_K = int(os.environ.get('DCCF_LAZY_K', '8')) if lazy_K is None else int(lazy_K)
         self.lazy = None                 # created with the first epoch plan (the row list is sized by it)
+        # collectives straight on RCCL (one C call each on the launch stream) when the process group is RCCL; through
+        # torch.distributed otherwise (gloo: the CPU tests and the one-GPU rehearsals) or with DCCF_SHARD_DIRECT=0
+        if direct is None:
+            direct = os.environ.get('DCCF_SHARD_DIRECT', '1') != '0'
+        self.comm = None
+        if direct and hasattr(backend, 'L') and dist.is_initialized() and dist.get_backend(group) == 'nccl':
+            self.comm = backend.L.Comm(rank, world, device, group)
 
     def flush(self):
         """Every row of the shard up to date (before anything but train_step reads U, V or the optimizer state)."""
@@ -233,8 +243,11 @@ class ShardedDCCF(object):
             self.lazy.sync_all(self.t)
 
     # ------------------------------------------------------------------------------------------------ one step
-    def _a2a(self, out, inp, out_splits, in_splits):
-        dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)
+    def _a2a(self, out, inp, out_splits, in_splits, out_np=None, in_np=None):
+        if self.comm is not None:
+            self.comm.all_to_all_rows(out, inp, in_np, out_np, inp.shape[1] if inp.dim() > 1 else out.shape[1])
+        else:
+            dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)
 
     def train_step(self, k, marks=None):
         """Step k of the epoch prepared by begin_epoch.  Returns (prediction [2B], loss [1]) of THIS rank's pairs.
@@ -255,8 +268,8 @@ class ShardedDCCF(object):
         be.set_job(pk, 2, rf.a_src[k], rf.a_dst[k], nf)
         be.pack_multi(pk)
         mark('pack')
-        self._a2a(p['recv_e'], p['send_e'][:ne], re.recv_splits[k], re.send_splits[k])
-        self._a2a(p['recv_f'], p['send_f'][:nf], rf.recv_splits[k], rf.send_splits[k])
+        self._a2a(p['recv_e'], p['send_e'][:ne], re.recv_splits[k], re.send_splits[k], re.recv_np[k], re.send_np[k])
+        self._a2a(p['recv_f'], p['send_f'][:nf], rf.recv_splits[k], rf.send_splits[k], rf.recv_np[k], rf.send_np[k])
         mark('a2a_rows')
         # compact tables in receive order: ONE table serves users and items (compact id = receive position); the same launch
         # zeroes the step's compact gradient table
@@ -270,10 +283,15 @@ class ShardedDCCF(object):
         # [dW | db] is complete after the backward: its all-reduce travels while the gradient rows go back to their owners
         # (compact order == receive order: nothing to permute) and are summed there
         mark('fwd_bwd')
-        work = dist.all_reduce(self.g_dense, group=self.group, async_op=True)
-        self._a2a(p['gback'][:ne], p['gc'], re.send_splits[k], re.recv_splits[k])
-        be.scatter_add(re.g_row[k], ne, p['gback'], self.g_rows, self.touched if self.segments else None)
-        work.wait()
+        if self.comm is not None:        # (everything on the launch stream, in order: no cross-stream wait to pay for)
+            self._a2a(p['gback'][:ne], p['gc'], re.send_splits[k], re.recv_splits[k], re.send_np[k], re.recv_np[k])
+            self.comm.all_reduce_sum(self.g_dense)
+            be.scatter_add(re.g_row[k], ne, p['gback'], self.g_rows, self.touched if self.segments else None)
+        else:
+            work = dist.all_reduce(self.g_dense, group=self.group, async_op=True)
+            self._a2a(p['gback'][:ne], p['gc'], re.send_splits[k], re.recv_splits[k])
+            be.scatter_add(re.g_row[k], ne, p['gback'], self.g_rows, self.touched if self.segments else None)
+            work.wait()
         mark('a2a_grads+all_reduce+scatter')
         self.t += 1
         if self.lazy is not None:

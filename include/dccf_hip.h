@@ -426,6 +426,21 @@ typedef struct {
 int shard_pack_multi(const shard_job_t* jobs, int32_t njobs, void* stream);
 int shard_unpack_multi(const shard_job_t* jobs, int32_t njobs, float* zero, int64_t zero_n, void* stream);
 
+/* ---- the row-sharded trainer's collectives straight on RCCL (dccf_amd/sharded.py; no reference counterpart: the reference is
+ * single-GPU, src/main.py:106,153-155).  torch.distributed issues the same ncclSend / ncclRecv / ncclAllReduce calls, at 25-40 us
+ * of host time per call; these are one C call each on the caller's stream.  RCCL is resolved at run time from the copy the
+ * process has mapped (PyTorch-ROCm's) — no link-time dependency.  dccf_comm_unique_id: on rank 0, 128 bytes to hand to every
+ * rank (e.g. by a torch.distributed broadcast); dccf_comm_create: collective over the `world` ranks, the calling thread's
+ * current HIP device.  dccf_comm_all_to_all_rows: peer q receives send_rows[q] rows of `width` floats (contiguous in `send`,
+ * peers in rank order) and delivers recv_rows[q] rows (contiguous in `recv`, in rank order), one RCCL group;
+ * dccf_comm_all_reduce_sum: in place.  Error codes >= 1000 are 1000 + ncclResult_t. */
+int dccf_comm_unique_id(uint8_t* out128);
+int dccf_comm_create(void** comm, const uint8_t* id128, int32_t world, int32_t rank);
+int dccf_comm_destroy(void* comm);
+int dccf_comm_all_to_all_rows(void* comm, const float* send, const int64_t* send_rows, float* recv, const int64_t* recv_rows,
+                              int64_t width, void* stream);
+int dccf_comm_all_reduce_sum(void* comm, float* buf, int64_t n, void* stream);
+
 /* ---- the fused-mode random streams written out (for parity tests: fused == injected on the same draws) ---------- */
 int dccf_debug_candidates(int64_t N, int32_t S, int64_t item_num, uint64_t seed, uint64_t step, int64_t* out, void* stream);
 int dccf_debug_noise(int64_t L, int32_t F, float std, uint64_t seed, uint64_t step, float* out, void* stream);

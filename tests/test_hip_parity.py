@@ -636,9 +636,11 @@ def test_tables_beyond_2g_elements_equal_compact_tables(L):
         close(b, a.cpu().numpy(), 1e-5, 1e-6, 'predictions')
 
 
-def test_sharded_trainer_with_hip_backend_world1(L):
+@pytest.mark.parametrize('direct', [True, False])
+def test_sharded_trainer_with_hip_backend_world1(L, direct):
     """dccf_amd/sharded.py with the real HIP backend over RCCL at world size 1 (the routing at world size 2 is covered
-    on CPU by tests/test_sharded_gloo.py): two steps must equal the oracle on the same counter-based draws."""
+    on CPU by tests/test_sharded_gloo.py): two steps must equal the oracle on the same counter-based draws — with the
+    collectives straight on RCCL (dccf_comm_*, the default under an RCCL process group) and through torch.distributed."""
     import os
     import torch.distributed as dist
     from dccf_amd.sharded import ShardedDCCF, HipBackend
@@ -652,7 +654,8 @@ def test_sharded_trainer_with_hip_backend_world1(L):
         P, feat, ips, X = make_world(c)
         ips_t = dict(P=T(ips['P']), bu=T(ips['bu']), Q=T(ips['Q']), bi=T(ips['bi']), prop=T(ips['prop']), b0=0.1, M=0.1)
         tr = ShardedDCCF(0, 1, c['U'], c['I'], c['D'], c['S'], c['A'], c['std'], c['dropout'], c['lr'], c['l2'], c['seed'],
-                         HipBackend(dev()), dev(), T(feat), ips_t)
+                         HipBackend(dev()), dev(), T(feat), ips_t, direct=direct)
+        assert (tr.comm is not None) == direct
         tr.set_global_params(T(P[KEYS[0]]), T(P[KEYS[1]]), T(P[KEYS[2]]), T(P[KEYS[3]]))
         expo = expo_from_ips(ips)
         opt = O.DenseOptimizer('adam', c['lr'], c['l2'])
