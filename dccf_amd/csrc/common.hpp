@@ -285,7 +285,20 @@ __device__ __forceinline__ void mark_row(uint32_t* flags, int64_t row, int64_t t
 __device__ __forceinline__ float expo_at(const dccf_model_t& M, int64_t u, int64_t i) {
   if (M.expo) return M.expo[u * M.item_num + i];
   float acc = 0.f;
-  for (int k = 0; k < M.ipsD; ++k) acc = fmaf(M.ipsP[u * M.ipsD + k], M.ipsQ[i * M.ipsD + k], acc);
+  const float* __restrict__ pu = M.ipsP + u * M.ipsD;
+  const float* __restrict__ qi = M.ipsQ + i * M.ipsD;
+  if (((M.ipsD & 3) | (int)((uintptr_t)pu & 15) | (int)((uintptr_t)qi & 15)) == 0) {
+    // 16-byte rows: a quarter of the loads, the same fma chain (one thread walks a row pair alone — the loads are its time)
+    for (int k = 0; k < M.ipsD; k += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(pu + k), b = *reinterpret_cast<const float4*>(qi + k);
+      acc = fmaf(a.x, b.x, acc);
+      acc = fmaf(a.y, b.y, acc);
+      acc = fmaf(a.z, b.z, acc);
+      acc = fmaf(a.w, b.w, acc);
+    }
+  } else {
+    for (int k = 0; k < M.ipsD; ++k) acc = fmaf(pu[k], qi[k], acc);
+  }
   acc = acc + M.ipsBu[u] + M.ipsBi[i] + M.ipsB0;
   return acc / fmaxf(M.ipsProp[i], M.ipsM);
 }
