@@ -363,9 +363,9 @@ class Comm(object):
             check(load().dccf_comm_create(C.byref(self.h), raw, int(world), int(rank)))
 
     def all_to_all_rows(self, out, inp, send_rows, recv_rows, width):
-        """send_rows / recv_rows: int64 numpy arrays [world] (rows per peer); out / inp: float32 tensors."""
-        check(load().dccf_comm_all_to_all_rows(self.h, ptr(inp), send_rows.ctypes.data, ptr(out), recv_rows.ctypes.data, int(width),
-                                               stream()))
+        """send_rows / recv_rows: HOST addresses (int) of int64[world] arrays, rows per peer — the caller keeps the arrays alive
+        and does the address arithmetic (numpy's .ctypes.data costs microseconds per call); out / inp: float32 tensors."""
+        check(load().dccf_comm_all_to_all_rows(self.h, inp.data_ptr(), send_rows, out.data_ptr(), recv_rows, width, stream()))
 
     def all_reduce_sum(self, buf):
         check(load().dccf_comm_all_reduce_sum(self.h, ptr(buf), buf.numel(), stream()))

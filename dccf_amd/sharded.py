@@ -104,6 +104,7 @@ class _Route(object):
         counts = mine.sum(2)                                   # [nb, G] rows I send to q
         self.send_splits, self.send_n = counts.tolist(), counts.sum(1).tolist()
         self.send_np = counts.to(torch.int64).cpu().numpy().copy()             # [nb, G] rows per peer (the direct RCCL path)
+        self.send_ad = self.send_np.ctypes.data                                # (row k of it: + 8 G k)
         self.send_max = max(1, max(self.send_n))
         na, nbb = (mf & af).sum(1), (mf & ~af).sum(1)
         self.na, self.nb_ = na.tolist(), nbb.tolist()
@@ -119,6 +120,7 @@ class _Route(object):
         rs = torch.stack([(my_owner == o).sum(1) for o in range(G)], 1)
         self.recv_splits = rs.tolist()
         self.recv_np = rs.to(torch.int64).cpu().numpy().copy()
+        self.recv_ad = self.recv_np.ctypes.data
         self.T = T
 
 
@@ -245,7 +247,7 @@ class ShardedDCCF(object):
     # ------------------------------------------------------------------------------------------------ one step
     def _a2a(self, out, inp, out_splits, in_splits, out_np=None, in_np=None):
         if self.comm is not None:
-            self.comm.all_to_all_rows(out, inp, in_np, out_np, inp.shape[1] if inp.dim() > 1 else out.shape[1])
+            self.comm.all_to_all_rows(out, inp, in_np, out_np, out.shape[1])
         else:
             dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)
 
@@ -268,8 +270,9 @@ class ShardedDCCF(object):
         be.set_job(pk, 2, rf.a_src[k], rf.a_dst[k], nf)
         be.pack_multi(pk)
         mark('pack')
-        self._a2a(p['recv_e'], p['send_e'][:ne], re.recv_splits[k], re.send_splits[k], re.recv_np[k], re.send_np[k])
-        self._a2a(p['recv_f'], p['send_f'][:nf], rf.recv_splits[k], rf.send_splits[k], rf.recv_np[k], rf.send_np[k])
+        o8 = 8 * self.G * k              # byte offset of step k in the [nb, G] int64 split arrays
+        self._a2a(p['recv_e'], p['send_e'][:ne], re.recv_splits[k], re.send_splits[k], re.recv_ad + o8, re.send_ad + o8)
+        self._a2a(p['recv_f'], p['send_f'][:nf], rf.recv_splits[k], rf.send_splits[k], rf.recv_ad + o8, rf.send_ad + o8)
         mark('a2a_rows')
         # compact tables in receive order: ONE table serves users and items (compact id = receive position); the same launch
         # zeroes the step's compact gradient table
@@ -284,7 +287,7 @@ class ShardedDCCF(object):
         # (compact order == receive order: nothing to permute) and are summed there
         mark('fwd_bwd')
         if self.comm is not None:        # (everything on the launch stream, in order: no cross-stream wait to pay for)
-            self._a2a(p['gback'][:ne], p['gc'], re.send_splits[k], re.recv_splits[k], re.send_np[k], re.recv_np[k])
+            self._a2a(p['gback'][:ne], p['gc'], re.send_splits[k], re.recv_splits[k], re.send_ad + o8, re.recv_ad + o8)
             self.comm.all_reduce_sum(self.g_dense)
             be.scatter_add(re.g_row[k], ne, p['gback'], self.g_rows, self.touched if self.segments else None)
         else:
