@@ -18,7 +18,7 @@ EXPORTS = ['dccf_ctx_create', 'dccf_ctx_destroy', 'dccf_ctx_reserve', 'dccf_last
            'dp_export_touched', 'dp_import_touched', 'dp_mark_global', 'dccf_dense_opt_phase', 'dccf_ctx_side_stream', 'dp_import_apply',
            'dccf_sample_eval_negatives', 'dccf_eval_prepare', 'dccf_predict_projected', 'dccf_dp_local', 'dccf_dp_overlap',
            'dccf_dp_finish', 'dccf_ctx_prepared_steps', 'dccf_ctx_hosted_rows', 'shard_pack_multi', 'shard_unpack_multi', 'dccf_build_epoch_batches', 'dccf_lazy_scalars', 'dccf_lazy_flush', 'dccf_lazy_catchup_rows', 'dccf_lazy_opt_step', 'dccf_comm_unique_id',
-           'dccf_comm_create', 'dccf_comm_destroy', 'dccf_comm_all_to_all_rows', 'dccf_comm_all_reduce_sum']
+           'dccf_comm_create', 'dccf_comm_destroy', 'dccf_comm_all_to_all_rows', 'dccf_comm_all_to_all_rows2', 'dccf_comm_all_reduce_sum']
 
 ABI_VERSION = 5
 OPT_KIND = {'gd': 0, 'adagrad': 1, 'adam': 2}
@@ -159,6 +159,7 @@ def load():
         'dccf_comm_create': [C.POINTER(vp), vp, i32, i32],
         'dccf_comm_destroy': [vp],
         'dccf_comm_all_to_all_rows': [vp, vp, vp, vp, vp, i64, vp],
+        'dccf_comm_all_to_all_rows2': [vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, i64, vp],
         'dccf_comm_all_reduce_sum': [vp, vp, i64, vp],
         'dccf_lazy_flush': [C.POINTER(OptT), vp],
         'shard_unpack_multi': [vp, i32, vp, i64, vp],
@@ -366,6 +367,11 @@ class Comm(object):
         """send_rows / recv_rows: HOST addresses (int) of int64[world] arrays, rows per peer — the caller keeps the arrays alive
         and does the address arithmetic (numpy's .ctypes.data costs microseconds per call); out / inp: float32 tensors."""
         check(load().dccf_comm_all_to_all_rows(self.h, inp.data_ptr(), send_rows, out.data_ptr(), recv_rows, width, stream()))
+
+    def all_to_all_rows2(self, out_a, inp_a, send_a, recv_a, out_b, inp_b, send_b, recv_b):
+        """Two payloads of different row widths in one RCCL group."""
+        check(load().dccf_comm_all_to_all_rows2(self.h, inp_a.data_ptr(), send_a, out_a.data_ptr(), recv_a, out_a.shape[1],
+                                                inp_b.data_ptr(), send_b, out_b.data_ptr(), recv_b, out_b.shape[1], stream()))
 
     def all_reduce_sum(self, buf):
         check(load().dccf_comm_all_reduce_sum(self.h, ptr(buf), buf.numel(), stream()))

@@ -101,28 +101,54 @@ extern "C" int dccf_comm_destroy(void* comm) {
 }
 
 // All-to-all of rows of `width` floats: peer q gets send_rows[q] rows (contiguous, peers in rank order in `send`) and delivers
-// recv_rows[q] rows (contiguous, in rank order in `recv`).  One RCCL group on `stream`.
-extern "C" int dccf_comm_all_to_all_rows(void* comm, const float* send, const int64_t* send_rows, float* recv,
-                                         const int64_t* recv_rows, int64_t width, void* stream) {
-  ARG_CHECK(comm && send_rows && recv_rows && width >= 1, "bad arguments");
-  Comm* c = (Comm*)comm;
-  hipStream_t st = (hipStream_t)stream;
+// recv_rows[q] rows (contiguous, in rank order in `recv`).  Up to two payloads of different row widths travel in ONE RCCL group
+// on `stream` (the sharded step's forward exchange: embedding-side rows and 768-d feature rows).
+static int a2a_enqueue(Comm* c, const float* send, const int64_t* send_rows, float* recv, const int64_t* recv_rows, int64_t width,
+                       hipStream_t st) {
   int64_t so = 0, ro = 0;
-  for (int q = 0; q < c->world; ++q) ARG_CHECK(send_rows[q] >= 0 && recv_rows[q] >= 0, "negative row count");
-  NCCL_TRY(api().GroupStart());
   for (int q = 0; q < c->world; ++q) {
-    if (send_rows[q] > 0) {
-      ARG_CHECK(send != nullptr, "NULL send buffer");
-      NCCL_TRY(api().Send(send + so * width, (size_t)(send_rows[q] * width), ncclFloat, q, c->c, st));
-    }
-    if (recv_rows[q] > 0) {
-      ARG_CHECK(recv != nullptr, "NULL receive buffer");
-      NCCL_TRY(api().Recv(recv + ro * width, (size_t)(recv_rows[q] * width), ncclFloat, q, c->c, st));
-    }
+    if (send_rows[q] > 0) NCCL_TRY(api().Send(send + so * width, (size_t)(send_rows[q] * width), ncclFloat, q, c->c, st));
+    if (recv_rows[q] > 0) NCCL_TRY(api().Recv(recv + ro * width, (size_t)(recv_rows[q] * width), ncclFloat, q, c->c, st));
     so += send_rows[q];
     ro += recv_rows[q];
   }
-  NCCL_TRY(api().GroupEnd());
+  return 0;
+}
+static int a2a_check(const Comm* c, const float* send, const int64_t* send_rows, const float* recv, const int64_t* recv_rows,
+                     int64_t width) {
+  ARG_CHECK(send_rows && recv_rows && width >= 1, "bad arguments");
+  for (int q = 0; q < c->world; ++q) {
+    ARG_CHECK(send_rows[q] >= 0 && recv_rows[q] >= 0, "negative row count");
+    ARG_CHECK((send_rows[q] == 0 || send) && (recv_rows[q] == 0 || recv), "NULL buffer");
+  }
+  return 0;
+}
+extern "C" int dccf_comm_all_to_all_rows(void* comm, const float* send, const int64_t* send_rows, float* recv,
+                                         const int64_t* recv_rows, int64_t width, void* stream) {
+  ARG_CHECK(comm != nullptr, "NULL communicator");
+  Comm* c = (Comm*)comm;
+  if (int e = a2a_check(c, send, send_rows, recv, recv_rows, width)) return e;
+  NCCL_TRY(api().GroupStart());
+  const int e = a2a_enqueue(c, send, send_rows, recv, recv_rows, width, (hipStream_t)stream);
+  const ncclResult_t r = api().GroupEnd();
+  if (e) return e;
+  NCCL_TRY(r);
+  return 0;
+}
+extern "C" int dccf_comm_all_to_all_rows2(void* comm, const float* send_a, const int64_t* send_rows_a, float* recv_a,
+                                          const int64_t* recv_rows_a, int64_t width_a, const float* send_b,
+                                          const int64_t* send_rows_b, float* recv_b, const int64_t* recv_rows_b, int64_t width_b,
+                                          void* stream) {
+  ARG_CHECK(comm != nullptr, "NULL communicator");
+  Comm* c = (Comm*)comm;
+  if (int e = a2a_check(c, send_a, send_rows_a, recv_a, recv_rows_a, width_a)) return e;
+  if (int e = a2a_check(c, send_b, send_rows_b, recv_b, recv_rows_b, width_b)) return e;
+  NCCL_TRY(api().GroupStart());
+  int e = a2a_enqueue(c, send_a, send_rows_a, recv_a, recv_rows_a, width_a, (hipStream_t)stream);
+  if (!e) e = a2a_enqueue(c, send_b, send_rows_b, recv_b, recv_rows_b, width_b, (hipStream_t)stream);
+  const ncclResult_t r = api().GroupEnd();
+  if (e) return e;
+  NCCL_TRY(r);
   return 0;
 }
 

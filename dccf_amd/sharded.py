@@ -271,8 +271,12 @@ class ShardedDCCF(object):
         be.pack_multi(pk)
         mark('pack')
         o8 = 8 * self.G * k              # byte offset of step k in the [nb, G] int64 split arrays
-        self._a2a(p['recv_e'], p['send_e'][:ne], re.recv_splits[k], re.send_splits[k], re.recv_ad + o8, re.send_ad + o8)
-        self._a2a(p['recv_f'], p['send_f'][:nf], rf.recv_splits[k], rf.send_splits[k], rf.recv_ad + o8, rf.send_ad + o8)
+        if self.comm is not None:        # both payloads in one RCCL group
+            self.comm.all_to_all_rows2(p['recv_e'], p['send_e'], re.send_ad + o8, re.recv_ad + o8,
+                                       p['recv_f'], p['send_f'], rf.send_ad + o8, rf.recv_ad + o8)
+        else:
+            self._a2a(p['recv_e'], p['send_e'][:ne], re.recv_splits[k], re.send_splits[k])
+            self._a2a(p['recv_f'], p['send_f'][:nf], rf.recv_splits[k], rf.send_splits[k])
         mark('a2a_rows')
         # compact tables in receive order: ONE table serves users and items (compact id = receive position); the same launch
         # zeroes the step's compact gradient table

@@ -439,6 +439,10 @@ int dccf_comm_create(void** comm, const uint8_t* id128, int32_t world, int32_t r
 int dccf_comm_destroy(void* comm);
 int dccf_comm_all_to_all_rows(void* comm, const float* send, const int64_t* send_rows, float* recv, const int64_t* recv_rows,
                               int64_t width, void* stream);
+/* two payloads of different row widths in ONE group (the sharded forward exchange: embedding-side rows + feature rows) */
+int dccf_comm_all_to_all_rows2(void* comm, const float* send_a, const int64_t* send_rows_a, float* recv_a, const int64_t* recv_rows_a,
+                               int64_t width_a, const float* send_b, const int64_t* send_rows_b, float* recv_b,
+                               const int64_t* recv_rows_b, int64_t width_b, void* stream);
 int dccf_comm_all_reduce_sum(void* comm, float* buf, int64_t n, void* stream);
 
 /* ---- the fused-mode random streams written out (for parity tests: fused == injected on the same draws) ---------- */
