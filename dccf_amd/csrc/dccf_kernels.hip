@@ -160,6 +160,44 @@ extern "C" int dccf_debug_trace_read(long long* out) {
 #define TRACEB(role, slot)
 #endif
 
+// Reductions over groups of GS consecutive lanes (GS a power of two, groups aligned).  Inside a 16-lane row they are DPP
+// operand modifiers of the add / max itself — quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror: after
+// each step every lane of a 2 / 4 / 8 / 16-lane block holds the block's value — instead of ds_bpermute round trips through the
+// LDS crossbar (what __shfl_xor compiles to: ~100 cycles each in a dependent chain; the folded pair epilogue of k_bwd runs 16
+// of them per batch row with nothing to overlap them at one wave per SIMD).
+__device__ __forceinline__ float dpp_quad_1032(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_quad_2301(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_half_mirror(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_mirror(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false));
+}
+template <int GS>
+__device__ __forceinline__ float group_sum(float v) {
+  if (GS >= 2) v += dpp_quad_1032(v);
+  if (GS >= 4) v += dpp_quad_2301(v);
+  if (GS >= 8) v += dpp_half_mirror(v);
+  if (GS >= 16) v += dpp_mirror(v);
+#pragma unroll
+  for (int o = 16; o < GS; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int GS>
+__device__ __forceinline__ float group_max(float v) {
+  if (GS >= 2) v = fmaxf(v, dpp_quad_1032(v));
+  if (GS >= 4) v = fmaxf(v, dpp_quad_2301(v));
+  if (GS >= 8) v = fmaxf(v, dpp_half_mirror(v));
+  if (GS >= 16) v = fmaxf(v, dpp_mirror(v));
+#pragma unroll
+  for (int o = 16; o < GS; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
 // ================================================================================================ K1: forward
 // Workgroup = 8 waves, one 32-row tile per iteration, K split EVENLY over the waves (two waves share a SIMD and the
 // fp32 MFMA shares the VALU pipe with the generator, so an uneven split leaves SIMDs idle: measured 15 us for the two
@@ -377,8 +415,7 @@ __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT,
         if (store_h) *reinterpret_cast<float4*>(&hbuf[lr * DP + dbase + ecol]) = hv;          // the backward's input
         part = uval[0] * hv.x + uval[1] * hv.y + uval[2] * hv.z + uval[3] * hv.w;
       }
-#pragma unroll
-      for (int o = RPL / 2; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+      part = group_sum<RPL>(part);          // (DPP inside the 16-lane row: no LDS round trip)
       if (on && (lane % RPL) == 0) {
         if (gridDim.y == 1) m[lr] = part;
         else atomicAdd(&m[lr], part);
@@ -417,44 +454,6 @@ __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT,
 // ================================================================================================ K2: pair epilogue
 // One lane per candidate: softmax_s(Expo[u, cand[n,s]]) (DCCF.py:98), prediction = mean_a sum_s w m (DCCF.py:100),
 // loss and d loss / d m (DCCF.py:116-125).  A group of GS lanes serves one pair (rank 1) or one row.
-
-// Reductions over groups of GS consecutive lanes (GS a power of two, groups aligned).  Inside a 16-lane row they are DPP
-// operand modifiers of the add / max itself — quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror: after
-// each step every lane of a 2 / 4 / 8 / 16-lane block holds the block's value — instead of ds_bpermute round trips through the
-// LDS crossbar (what __shfl_xor compiles to: ~100 cycles each in a dependent chain; the folded pair epilogue of k_bwd runs 16
-// of them per batch row with nothing to overlap them at one wave per SIMD).
-__device__ __forceinline__ float dpp_quad_1032(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
-}
-__device__ __forceinline__ float dpp_quad_2301(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
-}
-__device__ __forceinline__ float dpp_half_mirror(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));
-}
-__device__ __forceinline__ float dpp_mirror(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false));
-}
-template <int GS>
-__device__ __forceinline__ float group_sum(float v) {
-  if (GS >= 2) v += dpp_quad_1032(v);
-  if (GS >= 4) v += dpp_quad_2301(v);
-  if (GS >= 8) v += dpp_half_mirror(v);
-  if (GS >= 16) v += dpp_mirror(v);
-#pragma unroll
-  for (int o = 16; o < GS; o <<= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-template <int GS>
-__device__ __forceinline__ float group_max(float v) {
-  if (GS >= 2) v = fmaxf(v, dpp_quad_1032(v));
-  if (GS >= 4) v = fmaxf(v, dpp_quad_2301(v));
-  if (GS >= 8) v = fmaxf(v, dpp_half_mirror(v));
-  if (GS >= 16) v = fmaxf(v, dpp_mirror(v));
-#pragma unroll
-  for (int o = 16; o < GS; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
 
 template <int GS>
 __device__ __forceinline__ float row_predict(const float* eg, const float* m, int64_t n, int s, int S1, int A,
