@@ -1053,6 +1053,25 @@ extern "C" int dccf_advance(int64_t* k_dev, void* stream) {
 
 template <int KIND, int IEEE>
 __global__ void k_debug_opt_elem(float* p, float* g, float* s1, float* s2, int64_t n, OptArgs a, int denom_only) {
+  if (denom_only == 2) {         // the four-at-a-time form (opt_elem4) on whole groups of four; the tail like mode 0
+    for (int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i4 < n / 4; i4 += (int64_t)gridDim.x * blockDim.x) {
+      float4 pv = reinterpret_cast<float4*>(p)[i4], gv = reinterpret_cast<float4*>(g)[i4];
+      float4 av = s1 ? reinterpret_cast<float4*>(s1)[i4] : make_float4(0, 0, 0, 0);
+      float4 bv = s2 ? reinterpret_cast<float4*>(s2)[i4] : make_float4(0, 0, 0, 0);
+      opt_elem4<KIND>(pv, gv, av, bv, a);
+      reinterpret_cast<float4*>(p)[i4] = pv; reinterpret_cast<float4*>(g)[i4] = gv;
+      if (s1) reinterpret_cast<float4*>(s1)[i4] = av;
+      if (s2) reinterpret_cast<float4*>(s2)[i4] = bv;
+    }
+    for (int64_t i = n / 4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+      float pv = p[i], gv = g[i], av = s1 ? s1[i] : 0.f, bv = s2 ? s2[i] : 0.f;
+      opt_elem<KIND>(pv, gv, av, bv, a);
+      p[i] = pv; g[i] = gv;
+      if (s1) s1[i] = av;
+      if (s2) s2[i] = bv;
+    }
+    return;
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     float pv = p[i], gv = g[i], av = s1 ? s1[i] : 0.f, bv = s2 ? s2[i] : 0.f;
     if (denom_only) {      // Adam's denominator of the element's second moment AS GIVEN -> g (exhaustive checks of the first division)
@@ -1072,9 +1091,11 @@ extern "C" int dccf_debug_opt_elem(int32_t kind, int32_t ieee, float* p, float* 
   ARG_CHECK(p && g && n >= 0 && step >= 1, "NULL p/g, n < 0 or step < 1");
   ARG_CHECK(kind == DCCF_OPT_GD || kind == DCCF_OPT_ADAGRAD || kind == DCCF_OPT_ADAM, "unknown optimizer kind");
   ARG_CHECK((kind == DCCF_OPT_GD || s1) && (kind != DCCF_OPT_ADAM || s2), "optimizer state is NULL");
-  ARG_CHECK(ieee >= 0 && ieee <= 3 && (ieee < 2 || kind == DCCF_OPT_ADAM), "ieee is 0 / 1 (a step) or 2 / 3 (Adam's denominator only)");
-  const int denom_only = ieee >> 1;
-  ieee &= 1;
+  ARG_CHECK(ieee >= 0 && ieee <= 4 && (ieee < 2 || ieee == 4 || kind == DCCF_OPT_ADAM),
+            "ieee is 0 / 1 (a step), 2 / 3 (Adam's denominator only) or 4 (a step, four elements at a time)");
+  ARG_CHECK(ieee != 4 || (((uintptr_t)p | (uintptr_t)g | (uintptr_t)s1 | (uintptr_t)s2) & 15) == 0, "mode 4 needs 16-byte aligned arrays");
+  const int denom_only = ieee == 4 ? 2 : (ieee >> 1);
+  ieee = ieee == 4 ? 0 : (ieee & 1);
   ARG_CHECK(clip >= 0.f, "clip must be >= 0");
   if (n == 0) return 0;
   OptArgs a;

@@ -452,7 +452,8 @@ int dccf_debug_noise(int64_t L, int32_t F, float std, uint64_t seed, uint64_t st
  * every optimizer kernel of the library uses (Adam: divisions and square root without the range scaling of the compiler's
  * IEEE expansions, see opt_device.hpp), ieee = 1 the same step on __fdiv_rn / __fsqrt_rn.  ieee = 2 / 3 (Adam): nothing is
  * updated; g[i] = sqrt(s2[i]) / sqrt(1 - 0.999^step) + 1e-8 by the library's functions (2) or the IEEE ones (3).  Tests assert
- * that 0 == 1 and 2 == 3 bit for bit. */
+ * that 0 == 1 and 2 == 3 bit for bit.  ieee = 4: the step in the four-elements-at-a-time form the float4 kernels use
+ * (16-byte aligned arrays); 4 == 0 bit for bit. */
 int dccf_debug_opt_elem(int32_t kind, int32_t ieee, float* p, float* g, float* s1, float* s2, int64_t n, float lr, float wd,
                         float l2, float clip, int64_t step, void* stream);
 int dccf_debug_keep(int64_t L, int32_t D, float dropout, uint64_t seed, uint64_t step, uint8_t* out, void* stream);

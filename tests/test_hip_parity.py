@@ -434,6 +434,12 @@ def test_adam_element_function_equals_ieee(L):
         for a, b, nm in zip(outs[0], outs[1], 'pgmv'):
             assert torch.isfinite(a).all()
             assert torch.equal(bits(a), bits(b)), (step, nm, int((bits(a) != bits(b)).sum()))
+        # the four-at-a-time form of the float4 kernels (its l2 head is written on 2-vectors): same bits
+        st = [p0[:n - 3].clone(), g0[:n - 3].clone(), m0[:n - 3].clone(), v0[:n - 3].clone()]       # (n - 3: a scalar tail too)
+        for k in range(3):
+            L.debug_opt_elem('adam', 4, st[0], st[1], st[2], st[3], lr, l2, l2, 50.0, step + k)
+        for a, b, nm in zip(outs[0], st, 'pgmv'):
+            assert torch.equal(bits(a[:n - 3]), bits(b)), (step, nm, 'opt_elem4')
     # the other optimizers share nothing with the change, but go through the same entry
     for kind in ('gd', 'adagrad'):
         outs = []
