@@ -649,7 +649,7 @@ def shard_scatter_add(idx, n, rows, g, flags=None):
 
 
 def rank_eval_topk(pred, label, indptr, rows, ks):
-    """Per-user (ndcg, hit, precision, recall)@k for up to 4 cut-offs k <= 16 -> tensor [n_users, len(ks)+1, 4]."""
+    """Per-user (ndcg, hit, precision, recall)@k for up to 4 cut-offs k <= 1024 -> tensor [n_users, len(ks)+1, 4]."""
     nu = indptr.numel() - 1
     nk = len(ks)
     ks_host = (C.c_int32 * nk)(*[int(k) for k in ks])

@@ -34,7 +34,7 @@ class BaseRunner(object):
                             help='1: train negatives, batches and evaluation negatives are drawn on the GPU (Philox); '
                                  '0: the reference host path (numpy, bit-identical batches for the same seed)')
         parser.add_argument('--device_eval', type=int, default=1,
-                            help='1: predictions, top-k selection and ndcg/hit/precision/recall/f1@k (k <= 16) stay on the '
+                            help='1: predictions, top-k selection and ndcg/hit/precision/recall/f1@k (k <= 1024), rmse, mae and auc stay on the '
                                  'GPU; 0: the reference host path (pandas-free numpy restatement)')
         parser.add_argument('--eval_noise', type=str, default='full',
                             help='DCCF evaluation: full = the 768-d noise of DCCF.predict, op for op; projected = its exact '
@@ -224,13 +224,29 @@ class BaseRunner(object):
     def _device_metrics_ok(metrics):
         ks = set()
         for m in metrics:
-            if m in ('rmse', 'mae'):
+            if m in ('rmse', 'mae', 'auc'):
                 continue
             name, _, k = m.partition('@')
-            if name not in ('ndcg', 'hit', 'precision', 'recall', 'f1') or not k.isdigit() or not 1 <= int(k) <= 16:
+            if name not in ('ndcg', 'hit', 'precision', 'recall', 'f1') or not k.isdigit() or not 1 <= int(k) <= 1024:
                 return False
             ks.add(int(k))
         return len(ks) <= 4
+
+    @staticmethod
+    def _device_auc(p, y):
+        """roc_auc_score(l, p) of src/models/BaseModel.py:72-73 without leaving the GPU: the area under the ROC curve is the
+        Mann-Whitney statistic with tied scores counted half — (sum of the positives' average ranks - n_pos (n_pos + 1) / 2) /
+        (n_pos n_neg) — one device sort of the predictions; twice the average rank is an integer, so the sum is exact."""
+        pos = y > 0
+        n_pos = int(pos.sum())
+        n_neg = int(y.numel()) - n_pos
+        if n_pos == 0 or n_neg == 0:
+            raise ValueError('Only one class present in y_true. ROC AUC score is not defined in that case.')   # sklearn's
+        sp, order = torch.sort(p)
+        _, inv, cnt = torch.unique_consecutive(sp, return_inverse=True, return_counts=True)
+        twice_rank = 2 * torch.cumsum(cnt, 0) - cnt + 1          # 2 x the average 1-based rank of each tie group
+        s2 = int(twice_rank[inv][pos[order]].sum())
+        return (s2 - n_pos * (n_pos + 1)) / (2.0 * n_pos * n_neg)
 
     def predict_device(self, model, data, data_processor):
         """BaseRunner.predict (:134-157) from the resident split: predictions in sample-id order, on the GPU."""
@@ -259,6 +275,8 @@ class BaseRunner(object):
                 out.append(float(torch.sqrt(torch.mean((es.Y.double() - p.double()) ** 2))))
             elif m == 'mae':
                 out.append(float(torch.mean(torch.abs(es.Y.double() - p.double()))))
+            elif m == 'auc':
+                out.append(self._device_auc(p, es.Y))
             else:
                 name, k = m.split('@')
                 j, k = ks.index(int(k)), int(k)

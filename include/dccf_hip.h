@@ -300,7 +300,7 @@ int dccf_sample_eval_negatives(const int64_t* users, int64_t n_users, const int6
 /* ---- ranking metrics on the device: replaces the sort / groupby('uid') / per-group loops of BaseModel.evaluate_method
  * (src/models/BaseModel.py:83-126) with dcg/ndcg(method=1)/precision/recall/hit of src/utils/rank_metrics.py:61-87,130-201.
  * indptr/rows: CSR of each user's rows of the eval split (indices into pred/label).  ks_host (HOST) / ks_dev (device): the
- * cut-offs, 1 <= k <= 16, nk <= 4.  out [n_users, nk+1, 4] fp32: per user and cut-off (ndcg, hit, precision, recall); slot
+ * cut-offs, 1 <= k <= 1024 (16 ranks per walk of a user's rows), nk <= 4.  out [n_users, nk+1, 4] fp32: per user and cut-off (ndcg, hit, precision, recall); slot
  * nk holds the user's number of positives.  The caller averages over users (np.average in the reference). */
 int rank_eval_topk(const float* pred, const float* label, const int64_t* indptr, const int64_t* rows, int64_t n_users,
                    const int32_t* ks_host, const int32_t* ks_dev, int32_t nk, float* out, void* stream);

@@ -78,13 +78,55 @@ def test_small_groups_ties_and_no_positives():
     assert out[2, 0, 0] == 0 and out[2, 0, 1] == 0 and np.isnan(out[2, 0, 3]) and out[2, 2, 0] == 0
 
 
+@pytest.mark.parametrize('ties', [False, True])
+def test_cutoffs_beyond_16_match_oracle(ties):
+    """k > 16 (src/models/BaseModel.py:83-126 takes any k): the kernel continues the ranked list in rounds of 16.  Groups
+    shorter than k, groups whose size is not a multiple of 16, and — `ties` — scores with many equal values, where a round must
+    resume exactly after the last popped (score, position) pair (ties go to the earlier row; the oracle's stable sort agrees)."""
+    rng = np.random.RandomState(11 + ties)
+    sizes = rng.randint(5, 400, size=300)
+    sizes[:4] = [16, 17, 32, 100]
+    uid = np.repeat(np.arange(300), sizes)            # grouped, so "earlier row" = lower index for the oracle's stable sort
+    y = (rng.rand(len(uid)) < 0.1).astype(np.float32)
+    y[np.unique(uid, return_index=True)[1]] = 1.0
+    if ties:
+        p = rng.randint(0, 7, size=len(uid)).astype(np.float32) / 7
+    else:
+        p = rng.permutation(len(uid)).astype(np.float32) / len(uid)
+    for chunk in (['ndcg@20', 'recall@20', 'hit@17', 'f1@100'], ['ndcg@100', 'recall@50', 'ndcg@33', 'recall@400'],
+                  ['ndcg@1000', 'ndcg@5', 'recall@16']):
+        mine, _ = device_metrics(p, uid, y, chunk)
+        want = O.evaluate_method(p.astype(np.float64), uid, y, chunk)
+        np.testing.assert_allclose(mine, want, rtol=5e-6, atol=1e-7)
+
+
+def test_device_auc_rmse_mae_equal_sklearn_definitions():
+    """The runner's device forms of the non-ranking metrics (src/models/BaseModel.py:68-73): auc with heavily tied scores
+    against a direct pair count (ties count half — sklearn's roc_auc_score), and the one-class error."""
+    from dccf_amd.runner import BaseRunner
+    rng = np.random.RandomState(5)
+    for n, levels in ((2000, 0), (3000, 13), (50, 2)):
+        y = (rng.rand(n) < 0.3).astype(np.float32)
+        y[:2] = [0, 1]
+        p = rng.rand(n).astype(np.float32) if not levels else (rng.randint(0, levels, n) / levels).astype(np.float32)
+        pos, neg = p[y > 0].astype(np.float64), p[y == 0].astype(np.float64)
+        want = ((pos[:, None] > neg[None, :]).sum() + 0.5 * (pos[:, None] == neg[None, :]).sum()) / (len(pos) * len(neg))
+        got = BaseRunner._device_auc(torch.as_tensor(p).cuda(), torch.as_tensor(y).cuda())
+        assert got == pytest.approx(want, abs=1e-12)
+    with pytest.raises(ValueError):
+        BaseRunner._device_auc(torch.rand(8).cuda(), torch.ones(8).cuda())
+    assert BaseRunner._device_metrics_ok(['auc', 'rmse', 'ndcg@50']) and not BaseRunner._device_metrics_ok(['f1'])
+
+
 def test_cutoff_validation():
     from dccf_amd import _lib
     z = torch.zeros(4, device='cuda')
     ip = torch.tensor([0, 4], dtype=torch.int64, device='cuda')
     rows = torch.arange(4, dtype=torch.int64, device='cuda')
     with pytest.raises(RuntimeError):
-        _lib.rank_eval_topk(z, z, ip, rows, [17])
+        _lib.rank_eval_topk(z, z, ip, rows, [1025])
+    with pytest.raises(RuntimeError):
+        _lib.rank_eval_topk(z, z, ip, rows, [0])
     with pytest.raises(RuntimeError):
         _lib.rank_eval_topk(z, z, ip, rows, [1, 2, 3, 4, 5])
     assert _lib.rank_eval_topk(z, z, ip[:1], rows, [5]).shape == (0, 2, 4)
