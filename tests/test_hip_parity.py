@@ -1175,3 +1175,39 @@ def test_reference_checkpoint_loads(L):
     last = 's%d/after/' % (int(g['steps']) - 1)
     for k in sd:
         assert np.array_equal(sd[k].numpy(), g[last + k])
+
+
+def test_init_paras_distribution(L):
+    """BaseModel.init_paras through model.apply (src/models/BaseModel.py:130-142, src/main.py:150): every Embedding weight, every
+    Linear weight AND bias ~ N(0, 0.01); a bare Parameter (BiasedMF.global_bias = 0.1, src/models/BiasedMF.py:14) is not a
+    module and keeps its value.  Distribution, not stream: mean / std / excess kurtosis within sampling error."""
+    from dccf_amd.models import DCCF, BiasedMF
+    feat = torch.randn(300, 48, device='cuda')
+    expo = torch.randn(400, 300, device='cuda')
+    m = DCCF(path=None, dataset=None, sentence_model=None, sample_num=4, attribute_num=2, std=0.1, label_min=0, label_max=1,
+             feature_num=0, user_num=400, item_num=300, u_vector_size=64, i_vector_size=64, n_layers=3, random_seed=5,
+             model_path='/tmp/x.pt', feature_embedding=feat, expo_prob=expo)
+    before = {k: v.detach().clone() for k, v in m.named_parameters()}
+    m.apply(m.init_paras)
+    P = dict(m.named_parameters())
+    assert set(P) == {'uid_embeddings.weight', 'iid_embeddings.weight', 'mlp.0.weight', 'mlp.0.bias', 'mlp.1.weight',
+                      'mlp.1.bias', 'mlp.2.weight', 'mlp.2.bias'}
+    for k, v in P.items():
+        x = v.detach().double().flatten()
+        n = x.numel()
+        assert not torch.equal(v.detach(), before[k]), k
+        assert abs(float(x.mean())) < 5 * 0.01 / n ** 0.5 + 1e-12, k
+        if n >= 1000:
+            assert float(x.std()) == pytest.approx(0.01, rel=5 * (0.5 / n) ** 0.5 + 1e-3), k
+            kurt = float(((x - x.mean()) ** 4).mean() / x.var() ** 2) - 3.0
+            assert abs(kurt) < 6 * (24.0 / n) ** 0.5 + 0.02, k
+        else:                      # the 64-element biases: inside 5 sigma, not the torch Linear default U(-1/8, 1/8)
+            assert float(x.abs().max()) < 0.05 and float(x.std()) == pytest.approx(0.01, rel=0.5), k
+    b = BiasedMF(label_min=0, label_max=1, feature_num=0, user_num=400, item_num=300, u_vector_size=16, i_vector_size=16,
+                 random_seed=5, model_path='/tmp/x.pt')
+    b.apply(b.init_paras)
+    Pb = dict(b.named_parameters())
+    assert float(Pb['global_bias']) == pytest.approx(0.1)
+    for k in ('user_bias.weight', 'item_bias.weight', 'uid_embeddings.weight', 'iid_embeddings.weight'):
+        x = Pb[k].detach().double().flatten()
+        assert float(x.std()) == pytest.approx(0.01, rel=0.25) and abs(float(x.mean())) < 0.003, k
