@@ -84,10 +84,18 @@ def main(argv=None):
         args.model_path = '../model/%s/%s.pt' % (init_args.model_name, name)
     utils.check_dir_and_mkdir(args.model_path)
 
+    # several GPUs (python -m torch.distributed.run --nproc-per-node G -m dccf_amd.main ...; new capability, src/main.py:106 is
+    # single-GPU): one process per GPU, identical replicas, rank 0 owns the log, the checkpoint, rank.csv and the result file
+    rank, world = utils.init_distributed()
     for h in logging.root.handlers[:]:
         logging.root.removeHandler(h)
-    logging.basicConfig(filename=args.log_file, level=args.verbose)
-    logging.getLogger().addHandler(logging.StreamHandler(sys.stdout))
+    if rank == 0:
+        logging.basicConfig(filename=args.log_file, level=args.verbose)
+        logging.getLogger().addHandler(logging.StreamHandler(sys.stdout))
+    else:
+        logging.basicConfig(filename=os.devnull, level=logging.WARNING)
+    if world > 1:
+        logging.info('# ranks: %d (one process per GPU, replicated data-parallel training)' % world)
     logging.info(vars(init_args))
     logging.info(vars(args))
     for what, v in (('DataLoader', init_args.data_loader), ('Model', init_args.model_name),
@@ -96,11 +104,15 @@ def main(argv=None):
 
     torch.manual_seed(args.random_seed)
     np.random.seed(args.random_seed)
-    if 'HIP_VISIBLE_DEVICES' not in os.environ and 'CUDA_VISIBLE_DEVICES' not in os.environ:
+    if world == 1 and 'HIP_VISIBLE_DEVICES' not in os.environ and 'CUDA_VISIBLE_DEVICES' not in os.environ:
         os.environ['CUDA_VISIBLE_DEVICES'] = args.gpu     # src/main.py:106
     logging.info('# cuda devices: %d' % torch.cuda.device_count())
 
+    if world > 1 and rank != 0:
+        utils.barrier()             # rank 0 loads first: it writes the info / history cache files the others then find
     data_loader = data_loader_cls(path=args.path, dataset=args.dataset, label=args.label, sep=args.sep)
+    if world > 1 and rank == 0:
+        utils.barrier()
     data_loader.feature_info(include_id=model_cls.include_id, include_item_features=model_cls.include_item_features,
                              include_user_features=model_cls.include_user_features)
     model = build_model(init_args.model_name, model_cls, args, data_loader)
@@ -131,8 +143,10 @@ def main(argv=None):
         result = runner.predict_device(model, data_processor.get_test_data(), data_processor).cpu().numpy()
     else:
         result = runner.predict(model, data_processor.get_test_data(), data_processor)
-    np.save(args.result_file, result)
-    logging.info('Save Test Results to ' + args.result_file)
+    if rank == 0:
+        np.save(args.result_file, result)
+        logging.info('Save Test Results to ' + args.result_file)
+    utils.barrier()
     runner.model, runner.data_processor = model, data_processor      # for callers that keep working with the trained model
     return runner
 

@@ -181,11 +181,14 @@ class BaseModel(object):
     def save_model(self, model_path=None):
         """src/models/BaseModel.py:224-236."""
         model_path = model_path or self.model_path
-        d = os.path.dirname(model_path)
-        if d and not os.path.exists(d):
-            os.makedirs(d)
-        torch.save(OrderedDict((k, v.cpu()) for k, v in self.state_dict().items()), model_path)
-        logging.info('Save model to ' + model_path)
+        sd = self.state_dict()
+        if utils.is_rank0():             # (several GPUs: the replicas are bit-identical, rank 0 writes, the others wait for the file)
+            d = os.path.dirname(model_path)
+            if d and not os.path.exists(d):
+                os.makedirs(d)
+            torch.save(OrderedDict((k, v.cpu()) for k, v in sd.items()), model_path)
+            logging.info('Save model to ' + model_path)
+        utils.barrier()
 
     def load_model(self, model_path=None):
         """src/models/BaseModel.py:238-248."""

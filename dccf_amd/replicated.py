@@ -113,7 +113,7 @@ class HipBackend(object):
         X_next, X_all_next = nxt
         nx = self.nx
         nx.X_next, nx.X_all_next = self.L.ptr(X_next, torch.int64), self.L.ptr(X_all_next, torch.int64)
-        nx.N, nx.step0_next = X_next.shape[0], tr.t * tr.G          # tr.t was already advanced: rank 0's next Philox step
+        nx.N, nx.step0_next = X_next.shape[0], tr.word_base + tr.t * tr.G   # tr.t was already advanced: rank 0's next Philox step
         return self.nxp
 
     def overlap(self, tr, t):
@@ -145,9 +145,11 @@ class ReplicatedDCCF(object):
             self.be.flush(self)
 
     def __init__(self, rank, world, user_num, item_num, D, S, A, std, dropout, lr, l2, seed, backend, device, feat,
-                 expo=None, ips=None, max_rows=256, group=None, overlap=True):
+                 expo=None, ips=None, max_rows=256, group=None, overlap=True, flat_p=None, s1=None, s2=None):
         """feat [item_num, F]; expo [user_num, item_num] or ips (dict of IPSBiasedMF factors) — full tables, identical on
-        every rank.  max_rows: the largest 2B a step will see (sizes the all-gather buffer)."""
+        every rank.  max_rows: the largest 2B a step will see (sizes the all-gather buffer).  flat_p / s1 / s2: train THESE
+        buffers (a models.DCCF's flat parameter buffer and its optimizer's Adam state: same [U | V | W | b] layout, every
+        block on a 256-float boundary) instead of allocating — how runner.fit puts a CLI model on G GPUs."""
         self.rank, self.G, self.group, self.dev, self.be = rank, world, group, device, backend
         self.user_num, self.item_num, self.D, self.S, self.A = user_num, item_num, D, S, A
         self.std, self.dropout, self.lr, self.l2, self.seed = std, dropout, lr, l2, seed
@@ -156,9 +158,16 @@ class ReplicatedDCCF(object):
         sizes = [user_num * D, item_num * D, D * (D + F), D]
         pads = [(n + 255) // 256 * 256 for n in sizes]
         f32 = torch.float32
-        self.flat_p = torch.zeros(sum(pads), dtype=f32, device=device)
+        for name, t in (('flat_p', flat_p), ('s1', s1), ('s2', s2)):
+            if t is not None and (t.numel() != sum(pads) or t.dtype != f32 or not t.is_contiguous() or t.device != torch.device(device)):
+                raise ValueError('%s does not have the [U | V | W | b] layout of this model (%d floats)' % (name, sum(pads)))
+        self.flat_p = flat_p if flat_p is not None else torch.zeros(sum(pads), dtype=f32, device=device)
         self.flat_g = torch.zeros_like(self.flat_p)
-        self.s1, self.s2 = torch.zeros_like(self.flat_p), torch.zeros_like(self.flat_p)
+        self.s1 = s1 if s1 is not None else torch.zeros_like(self.flat_p)
+        self.s2 = s2 if s2 is not None else torch.zeros_like(self.flat_p)
+        # Philox step word of rank r at optimizer step t (0-based) = word_base + t * G + r.  A caller that also draws from the
+        # model's own call counter between steps (evaluation passes of the CLI) moves the base so that no word is used twice
+        self.word_base = 0
         o, views, gviews, offs = 0, [], [], []
         for n, pd, shp in zip(sizes, pads, [(user_num, D), (item_num, D), (D, D + F), (D,)]):
             views.append(self.flat_p[o:o + n].view(shp))
@@ -223,7 +232,7 @@ class ReplicatedDCCF(object):
         self.next = None
         if ov and X_all_next is not None and tuple(X_all_next.shape) == tuple(X_all.shape):
             self.next = (X_all_next[self.rank], X_all_next)
-        step0, t = self.t * self.G, self.t + 1
+        step0, t = self.word_base + self.t * self.G, self.t + 1
         pred = be.local(self, X, Y, step0 + self.rank, pred, X_all if ov else None, step0)
         work = None
         if self.G > 1 or _FORCE_COLLECTIVE:                        # the step's only collective

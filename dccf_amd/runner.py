@@ -103,6 +103,8 @@ class BaseRunner(object):
         every batch in the reference, :172-188)."""
         if model.optimizer is None:
             model.optimizer = self._build_optimizer(model)
+        if utils.world_size() > 1:
+            return self._fit_replicated(model, data_processor, epoch)
         model.train()
         out = None
         if self.fused_sampling and data_processor.rank == 1:
@@ -143,6 +145,78 @@ class BaseRunner(object):
                 out = self._step(model, batch)
         model.eval()
         return out
+
+    def _fit_replicated(self, model, data_processor, epoch):
+        """One epoch on the G GPUs of a node (launched with torch.distributed.run, one process per GPU; no reference counterpart:
+        src/main.py:106,153-155 is single-GPU).  Every rank holds the whole model and the whole train set and draws the SAME
+        epoch (negatives, permutation: counter-based in (seed, epoch)); optimizer step j trains the G consecutive batches
+        j G .. j G + G - 1 of the epoch's schedule, rank r the r-th of them, as ONE step on their union — the reference's
+        step at batch size G x --batch_size (its loss is a sum, src/models/DCCF.py:116-120) — through dccf_amd.replicated
+        on THIS model's parameter buffer and this optimizer's Adam state.  What is left when the batches do not divide by G
+        (< G batches + the epoch's short last batch) is one more step on equal shares per rank, the shares completed with the
+        epoch's first pairs (at most G - 1 of them: what DistributedSampler does).  The replicas stay bit-identical, so every
+        rank evaluates for itself and takes the same early-stopping decisions; rank 0 alone writes files."""
+        import torch.distributed as dist
+        from dccf_amd import replicated
+        G, rank, B = dist.get_world_size(), dist.get_rank(), self.batch_size
+        o = model.optimizer
+        tr = getattr(model, '_replicated', None)
+        if tr is None:
+            D = getattr(model, 'ui_vector_size', 0)
+            if (getattr(model, 'kind', '') != 'DCCF' or model.n_layers != 1 or o.name != 'adam' or D not in (16, 32, 64, 128)
+                    or not self.fused_sampling or data_processor.rank != 1):
+                raise RuntimeError('training on several GPUs covers --model_name DCCF --n_layers 1 --optimizer Adam --rank 1 '
+                                   '--fused_sampling 1 with an embedding size of 16, 32, 64 or 128')
+            o.flush()
+            tr = replicated.ReplicatedDCCF(rank, G, model.user_num, model.item_num, D, model.sample_num, model.attribute_num,
+                                           model.std, self.dropout, o.lr, o.l2, model.random_seed,
+                                           replicated.HipBackend(model.device), model.device, model.feature_embedding,
+                                           expo=model.expo_prob, ips=model.ips_factors, max_rows=2 * B, overlap=True,
+                                           flat_p=model.flat_p, s1=o.s1, s2=o.s2)
+            tr.t = o.t
+            model._replicated = tr
+            o.lazy = None                   # the trainer owns the lazy regularisation of these buffers from here on
+            _flush0 = o.flush
+            o.flush = lambda: (tr.flush(), _flush0())[1]          # evaluation / checkpoints read every row
+        model.train()
+        full, tail = data_processor.device_epoch(max(epoch, 0), B)
+        dev = full.device
+        nb = full.shape[0]
+        ns = nb // G
+        sched = full[:ns * G].view(ns, G, 2 * B, 2)
+        y = torch.cat([torch.ones(B, device=dev), torch.zeros(B, device=dev)])
+        pred = torch.empty(2 * B, dtype=torch.float32, device=dev)
+        # no Philox word twice: the trainer's words of this epoch start after everything the model's call counter handed out
+        tr.word_base = model._call + 1 - tr.t * G
+        loss = None
+        for j in range(ns):
+            _, loss = tr.train_step(sched[j, rank], y, pred, X_all=sched[j], X_all_next=sched[j + 1] if j + 1 < ns else None)
+        # the rest of the epoch: batches ns G .. nb - 1 and the short last batch, as one step of equal shares
+        pos, neg = [full[ns * G:, :B].reshape(-1, 2)], [full[ns * G:, B:].reshape(-1, 2)]
+        if tail is not None:
+            r = tail.shape[0] // 2
+            pos.append(tail[:r])
+            neg.append(tail[r:])
+        pos, neg = torch.cat(pos), torch.cat(neg)
+        n_left = pos.shape[0]
+        if n_left > 0:
+            b = (n_left + G - 1) // G
+            pad = b * G - n_left
+            if pad:
+                src = full[0] if nb > 0 else torch.cat([pos, neg])
+                h = src.shape[0] // 2
+                take = torch.arange(pad, device=dev) % h
+                pos, neg = torch.cat([pos, src[:h][take]]), torch.cat([neg, src[h:][take]])
+            X_all = torch.cat([pos.view(G, b, 2), neg.view(G, b, 2)], dim=1).contiguous()
+            yl = torch.cat([torch.ones(b, device=dev), torch.zeros(b, device=dev)])
+            pred = torch.empty(2 * b, dtype=torch.float32, device=dev)
+            _, loss = tr.train_step(X_all[rank], yl, pred, X_all=X_all)
+        tr.flush()
+        o.t = tr.t
+        model._call = tr.word_base + tr.t * G        # every word below is used
+        data_processor._dev.check_negatives()
+        model.eval()
+        return {'prediction': pred, 'check': [('prediction', pred)], 'loss': loss[0] if loss is not None else model._loss[0]}
 
     def _step(self, model, batch, X_next=None):
         """The body of the reference's batch loop (src/runners/BaseRunner.py:172-188)."""
@@ -308,6 +382,8 @@ class BaseRunner(object):
         """rank.csv of src/runners/BaseRunner.py:315-323: tab-separated uid, iid, score, label sorted by uid.  With
         --test_neg_n 1000 the test split of an Electronics-size dataset is ~2e8 rows: pandas needs minutes for the sort
         and the text conversion, so large frames go through a stable numpy argsort and pyarrow's CSV writer."""
+        if not utils.is_rank0():
+            return
         n = len(predictions)
         if n >= 2000000:
             try:

@@ -73,6 +73,45 @@ def strictly_decreasing(l):
     return all(x > y for x, y in zip(l, l[1:]))
 
 
+def world_size():
+    """Ranks of the torch.distributed job this process belongs to (1: the reference's single-GPU run)."""
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def is_rank0():
+    import torch.distributed as dist
+    return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+
+
+def barrier():
+    """No-op in a single-process run; with several ranks: all of them have reached this point (a file rank 0 wrote is there)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        torch.cuda.synchronize()
+        dist.barrier()
+
+
+def init_distributed():
+    """One process per GPU under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment): binds this
+    process to its GPU and creates the process group — backend "nccl" = RCCL over xGMI; DCCF_DIST_BACKEND=gloo rehearses on a
+    box with fewer GPUs than ranks (the ranks then share the visible devices).  Returns (rank, world size)."""
+    import os
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world <= 1:
+        return 0, 1
+    if dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    backend = os.environ.get('DCCF_DIST_BACKEND', 'nccl')
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if backend != 'nccl':
+        local = local % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local)
+    dist.init_process_group(backend, **({'device_id': torch.device('cuda', local)} if backend == 'nccl' else {}))
+    return dist.get_rank(), dist.get_world_size()
+
+
 def device():
     if not torch.cuda.is_available():
         raise RuntimeError('dccf_amd needs an MI355X (no CPU fallback): torch.cuda.is_available() is False')
@@ -91,4 +130,4 @@ def check_dir_and_mkdir(path):
     else:
         dirname = os.path.dirname(path)
     if dirname and not os.path.exists(dirname):
-        os.makedirs(dirname)
+        os.makedirs(dirname, exist_ok=True)

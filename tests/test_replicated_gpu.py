@@ -336,3 +336,73 @@ def test_two_ranks_hip_backend_row_sharded_equals_union_batch(tmp_path, lazy_K):
             # Adam turns the last-bit differences of float-atomic sums into fractions of lr on a few elements
             assert d.max() <= steps * lr and (d > steps * 5e-3 * lr).mean() <= 0.02, (d.max(), (d > steps * 5e-3 * lr).mean())
     assert np.array_equal(res[0]['W'], res[1]['W']) and np.array_equal(res[0]['b'], res[1]['b'])     # replicas stay identical
+
+
+# ------------------------------------------------------------------------------------------------ the CLI on two ranks
+CLI_SEEDS = [2019, 2020, 2021, 2022, 2023, 2024]
+
+
+def _cli_rank_main(rank, world, port, tmp, cfg):
+    """One rank of `python -m torch.distributed.run --nproc-per-node 2 -m dccf_amd.main ...` (the environment the launcher
+    sets, gloo as the transport: both ranks share this box's one GPU), once per seed."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world), DCCF_DIST_BACKEND='gloo')
+    from dccf_amd import main as M
+    os.makedirs(os.path.join(tmp, 'src'), exist_ok=True)
+    os.chdir(os.path.join(tmp, 'src'))
+    valid, init, out = [], [], {}
+    for seed in CLI_SEEDS:
+        runner = M.main(['--rank', '1', '--model_name', 'DCCF', '--optimizer', 'Adam', '--lr', str(cfg['lr']), '--dataset', 'toy',
+                         '--path', '../dataset/', '--metric', 'ndcg@5,recall@5,auc', '--epoch', str(cfg['epochs']),
+                         '--test_neg_n', str(cfg['test_neg_n']), '--u_vector_size', str(cfg['D']), '--i_vector_size', str(cfg['D']),
+                         '--batch_size', str(cfg['batch_size'] // world), '--check_epoch', '0', '--random_seed', str(seed),
+                         '--verbose', '30', '--model_path', '../model/DCCF/two.pt'])
+        valid.append(np.array(runner.valid_results))
+        init.append(np.array(runner.init_results[1]))
+        m = runner.model
+        out = dict(t=m.optimizer.t, call=m._call, **{k: v.cpu().numpy() for k, v in m.state_dict().items()})
+    torch.cuda.synchronize()
+    np.savez(os.path.join(tmp, 'cli%d.npz' % rank), valid=np.stack(valid), init=np.stack(init), **out)
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_cli_on_two_ranks(tmp_path):
+    """dccf_amd.main under a two-rank launch (src/main.py:24-195 is single-GPU: new capability behind the same flags), on the
+    dataset and hyper-parameters of the reference's own main.py runs (tests/golden/e2e.npz) with --batch_size halved: every
+    optimizer step trains the two ranks' batches as ONE step, i.e. the reference's step at its batch size — the seed-averaged
+    validation NDCG@5 of every epoch must agree with the reference's runs like the single-GPU CLI does.  The replicas —
+    parameters, metrics of every epoch, step and Philox counters — are identical, rank 0 alone wrote the checkpoint / rank.csv /
+    result files, and an epoch whose batches do not divide by the world size ends in one step of equal shares."""
+    import torch.multiprocessing as mp
+    import pandas as pd
+    from conftest import load_golden
+    from dccf_amd import synth
+    g = load_golden('e2e')
+    tmp = str(tmp_path)
+    synth.write_dataset(os.path.join(tmp, 'dataset'), 'toy', int(g['user_num']), int(g['item_num']), int(g['n_draws']),
+                        feat_dim=int(g['feat_dim']), seed=int(g['data_seed']))
+    cfg = dict(lr=float(g['lr']), epochs=int(g['epochs']), test_neg_n=int(g['test_neg_n']), D=int(g['D']),
+               batch_size=int(g['batch_size']))
+    port = 35000 + os.getpid() % 2000
+    mp.spawn(_cli_rank_main, args=(2, port, tmp, cfg), nprocs=2, join=True)
+    r0, r1 = (dict(np.load(os.path.join(tmp, 'cli%d.npz' % r))) for r in range(2))
+    for k in r0:
+        assert np.array_equal(r0[k], r1[k], equal_nan=True), k
+    n_pairs = len(pd.read_csv(os.path.join(tmp, 'dataset', 'toy', 'toy.train.csv'), header=None))
+    B = cfg['batch_size']
+    assert n_pairs % B != 0 and int(r0['t']) == cfg['epochs'] * ((n_pairs + B - 1) // B)
+    files = [os.path.join(r, f) for r, _, fs in os.walk(tmp) for f in fs]
+    assert sum(f.endswith('two.pt') for f in files) == 1 and sum(f.endswith('rank.csv') for f in files) == 1
+    assert sum(f.endswith('.npy') and os.sep + 'result' + os.sep in f for f in files) == len(CLI_SEEDS)
+    sd = torch.load(os.path.join(tmp, 'model', 'DCCF', 'two.pt'), map_location='cpu')
+    assert set(sd) == {'uid_embeddings.weight', 'iid_embeddings.weight', 'mlp.0.weight', 'mlp.0.bias'}
+    # statistical parity with the reference's runs (same test as tests/test_e2e_gpu.py, fewer seeds on this side)
+    seeds = [int(s) for s in g['seeds']]
+    ref = np.stack([g['seed%d/valid' % s][:, 0] for s in seeds])
+    mine = r0['valid'][:, :, 0]
+    assert mine.shape == (len(CLI_SEEDS), cfg['epochs']) and np.isfinite(r0['valid']).all()
+    for e in range(cfg['epochs']):
+        se = np.sqrt(ref[:, e].var(ddof=1) / len(seeds) + mine[:, e].var(ddof=1) / len(CLI_SEEDS))
+        assert abs(mine[:, e].mean() - ref[:, e].mean()) <= 3 * se + 2e-3, \
+            'epoch %d: two ranks %.4f vs reference %.4f (se %.4f)' % (e + 1, mine[:, e].mean(), ref[:, e].mean(), se)
