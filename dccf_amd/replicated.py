@@ -55,7 +55,7 @@ class HipBackend(object):
         self.m = L.model_struct(tr.U, tr.V, tr.W, tr.b, tr.feat, tr.expo, tr.S, tr.A, tr.std, ips=tr.ips)
         self.r = L.rand_struct(seed=tr.seed, step=0)
         self.g = L.GradsT(L.ptr(tr.gU), L.ptr(tr.gV), L.ptr(tr.gW), L.ptr(tr.gb), L.ptr(tr.tU, u8), L.ptr(tr.tV, u8))
-        self.opt = L.opt_struct('adam', tr.flat_p, tr.flat_g, tr.s1, tr.s2, tr.lr, tr.l2, tr.l2, 50.0, tr.segments, 0)
+        self.opt = L.opt_struct(tr.opt_name, tr.flat_p, tr.flat_g, tr.s1, tr.s2, tr.lr, tr.l2, tr.l2, 50.0, tr.segments, 0)
         # windowed lazy regularisation in the overlapped form of the step: phase 1 advances one K-th of the
         # rows no rank touches by K steps instead of streaming all of them every step
         self.lazy = None
@@ -145,11 +145,15 @@ class ReplicatedDCCF(object):
             self.be.flush(self)
 
     def __init__(self, rank, world, user_num, item_num, D, S, A, std, dropout, lr, l2, seed, backend, device, feat,
-                 expo=None, ips=None, max_rows=256, group=None, overlap=True, flat_p=None, s1=None, s2=None):
+                 expo=None, ips=None, max_rows=256, group=None, overlap=True, flat_p=None, s1=None, s2=None, opt_name='adam'):
         """feat [item_num, F]; expo [user_num, item_num] or ips (dict of IPSBiasedMF factors) — full tables, identical on
         every rank.  max_rows: the largest 2B a step will see (sizes the all-gather buffer).  flat_p / s1 / s2: train THESE
         buffers (a models.DCCF's flat parameter buffer and its optimizer's Adam state: same [U | V | W | b] layout, every
-        block on a 256-float boundary) instead of allocating — how runner.fit puts a CLI model on G GPUs."""
+        block on a 256-float boundary) instead of allocating — how runner.fit puts a CLI model on G GPUs.  opt_name: 'adam' |
+        'adagrad' | 'gd' (src/runners/BaseRunner.py:83-107; s1 = Adam's m / Adagrad's sum, s2 = Adam's v)."""
+        self.opt_name = opt_name.lower()
+        if self.opt_name not in ('adam', 'adagrad', 'gd'):
+            raise ValueError('unknown optimizer ' + opt_name)
         self.rank, self.G, self.group, self.dev, self.be = rank, world, group, device, backend
         self.user_num, self.item_num, self.D, self.S, self.A = user_num, item_num, D, S, A
         self.std, self.dropout, self.lr, self.l2, self.seed = std, dropout, lr, l2, seed
@@ -163,8 +167,8 @@ class ReplicatedDCCF(object):
                 raise ValueError('%s does not have the [U | V | W | b] layout of this model (%d floats)' % (name, sum(pads)))
         self.flat_p = flat_p if flat_p is not None else torch.zeros(sum(pads), dtype=f32, device=device)
         self.flat_g = torch.zeros_like(self.flat_p)
-        self.s1 = s1 if s1 is not None else torch.zeros_like(self.flat_p)
-        self.s2 = s2 if s2 is not None else torch.zeros_like(self.flat_p)
+        self.s1 = s1 if s1 is not None else (torch.zeros_like(self.flat_p) if self.opt_name != 'gd' else None)
+        self.s2 = s2 if s2 is not None else (torch.zeros_like(self.flat_p) if self.opt_name == 'adam' else None)
         # Philox step word of rank r at optimizer step t (0-based) = word_base + t * G + r.  A caller that also draws from the
         # model's own call counter between steps (evaluation passes of the CLI) moves the base so that no word is used twice
         self.word_base = 0

@@ -152,7 +152,7 @@ class BaseRunner(object):
         epoch (negatives, permutation: counter-based in (seed, epoch)); optimizer step j trains the G consecutive batches
         j G .. j G + G - 1 of the epoch's schedule, rank r the r-th of them, as ONE step on their union — the reference's
         step at batch size G x --batch_size (its loss is a sum, src/models/DCCF.py:116-120) — through dccf_amd.replicated
-        on THIS model's parameter buffer and this optimizer's Adam state.  What is left when the batches do not divide by G
+        on THIS model's parameter buffer and this optimizer's state.  What is left when the batches do not divide by G
         (< G batches + the epoch's short last batch) is one more step on equal shares per rank, the shares completed with the
         epoch's first pairs (at most G - 1 of them: what DistributedSampler does).  The replicas stay bit-identical, so every
         rank evaluates for itself and takes the same early-stopping decisions; rank 0 alone writes files."""
@@ -163,16 +163,16 @@ class BaseRunner(object):
         tr = getattr(model, '_replicated', None)
         if tr is None:
             D = getattr(model, 'ui_vector_size', 0)
-            if (getattr(model, 'kind', '') != 'DCCF' or model.n_layers != 1 or o.name != 'adam' or D not in (16, 32, 64, 128)
+            if (getattr(model, 'kind', '') != 'DCCF' or model.n_layers != 1 or D not in (16, 32, 64, 128)
                     or not self.fused_sampling or data_processor.rank != 1):
-                raise RuntimeError('training on several GPUs covers --model_name DCCF --n_layers 1 --optimizer Adam --rank 1 '
-                                   '--fused_sampling 1 with an embedding size of 16, 32, 64 or 128')
+                raise RuntimeError('training on several GPUs covers --model_name DCCF --n_layers 1 --rank 1 --fused_sampling 1 '
+                                   'with an embedding size of 16, 32, 64 or 128')
             o.flush()
             tr = replicated.ReplicatedDCCF(rank, G, model.user_num, model.item_num, D, model.sample_num, model.attribute_num,
                                            model.std, self.dropout, o.lr, o.l2, model.random_seed,
                                            replicated.HipBackend(model.device), model.device, model.feature_embedding,
                                            expo=model.expo_prob, ips=model.ips_factors, max_rows=2 * B, overlap=True,
-                                           flat_p=model.flat_p, s1=o.s1, s2=o.s2)
+                                           flat_p=model.flat_p, s1=o.s1, s2=o.s2, opt_name=o.name)
             tr.t = o.t
             model._replicated = tr
             o.lazy = None                   # the trainer owns the lazy regularisation of these buffers from here on

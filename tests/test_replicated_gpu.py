@@ -169,7 +169,7 @@ def test_replicated_trainer_world1_equals_single_gpu_step(overlap):
     torch.cuda.synchronize()
 
 
-def _rank_main(rank, world, port, out, overlap):
+def _rank_main(rank, world, port, out, overlap, opt_name='adam'):
     import torch.distributed as dist
     tag = str(overlap)
     prep, overlap = overlap == 'prep', bool(overlap)
@@ -184,7 +184,8 @@ def _rank_main(rank, world, port, out, overlap):
     feat = torch.randn(c['I'], c['F'], generator=g, device='cuda') * 0.3
     expo = torch.randn(c['U'], c['I'], generator=g, device='cuda')
     tr = replicated.ReplicatedDCCF(rank, world, c['U'], c['I'], c['D'], c['S'], c['A'], 0.1, 0.2, 1e-2, 1e-4, 5,
-                                   replicated.HipBackend(dev), dev, feat, expo=expo, max_rows=2 * c['B'], overlap=overlap)
+                                   replicated.HipBackend(dev), dev, feat, expo=expo, max_rows=2 * c['B'], overlap=overlap,
+                                   opt_name=opt_name)
     tr.init_params(0.1)
     y = torch.cat([torch.ones(c['B'], device='cuda'), torch.zeros(c['B'], device='cuda')])
     gen = torch.Generator(device='cuda').manual_seed(2)
@@ -209,15 +210,16 @@ def _rank_main(rank, world, port, out, overlap):
 W2 = dict(U=700, I=450, D=64, F=96, S=10, A=2, B=40, steps=5)
 
 
-@pytest.mark.parametrize('overlap,world', [(False, 2), (True, 2), ('prep', 2), ('prep', 3)])
-def test_two_ranks_hip_backend_replicas_bit_identical(tmp_path, overlap, world):
+@pytest.mark.parametrize('overlap,world,opt_name', [(False, 2, 'adam'), (True, 2, 'adam'), ('prep', 2, 'adam'), ('prep', 3, 'adam'),
+                                                   ('prep', 2, 'adagrad'), ('prep', 2, 'gd'), (False, 2, 'gd')])
+def test_two_ranks_hip_backend_replicas_bit_identical(tmp_path, overlap, world, opt_name):
     """World size 2 (and 3) with the HIP backend (the ranks share this box's one GPU, gloo as the transport): the replicas
     end bit-identical, nothing is left in the gradient buffer, the flags or the tables, and the result equals the same
     batches accumulated into one gradient on one GPU, to the float-atomic tolerance."""
     import torch.multiprocessing as mp
     from dccf_amd import _lib as L
-    port = 33000 + os.getpid() % 2000 + {False: 0, True: 11, 'prep': 23}[overlap] + 7 * world
-    mp.spawn(_rank_main, args=(world, port, str(tmp_path), overlap), nprocs=world, join=True)
+    port = 33000 + os.getpid() % 2000 + {False: 0, True: 11, 'prep': 23}[overlap] + 7 * world + {'adam': 0, 'adagrad': 41, 'gd': 57}[opt_name]
+    mp.spawn(_rank_main, args=(world, port, str(tmp_path), overlap, opt_name), nprocs=world, join=True)
     rs = [dict(np.load(os.path.join(str(tmp_path), 'r%d_%s.npz' % (r, str(overlap))))) for r in range(world)]
     r0 = rs[0]
     for r1 in rs[1:]:
@@ -237,7 +239,8 @@ def test_two_ranks_hip_backend_replicas_bit_identical(tmp_path, overlap, world):
     ctx = L.Context(0)
     y = torch.cat([torch.ones(c['B'], device='cuda'), torch.zeros(c['B'], device='cuda')])
     gen = torch.Generator(device='cuda').manual_seed(2)
-    s1, s2 = torch.zeros_like(tr.flat_p), torch.zeros_like(tr.flat_p)
+    s1 = torch.zeros_like(tr.flat_p) if opt_name != 'gd' else None
+    s2 = torch.zeros_like(tr.flat_p) if opt_name == 'adam' else None
     for t in range(c['steps']):
         X_all = torch.stack([torch.stack([torch.randint(0, c['U'], (2 * c['B'],), generator=gen, device='cuda'),
                                           torch.randint(0, c['I'], (2 * c['B'],), generator=gen, device='cuda')], 1)
@@ -249,7 +252,7 @@ def test_two_ranks_hip_backend_replicas_bit_identical(tmp_path, overlap, world):
                                           tr.gU, tr.gV, tr.gW, tr.gb)
             total += float(loss)
         assert total == pytest.approx(float(r0['losses'][t]), rel=1e-4)
-        L.dense_opt_step('adam', tr.flat_p, tr.flat_g, s1, s2, 1e-2, 1e-4, 1e-4, 50.0, t + 1)
+        L.dense_opt_step(opt_name, tr.flat_p, tr.flat_g, s1, s2, 1e-2, 1e-4, 1e-4, 50.0, t + 1)
     d = np.abs(tr.flat_p.cpu().numpy() - r0['p'])
     assert d.max() <= c['steps'] * 1e-2 and (d > c['steps'] * 5e-3 * 1e-2).sum() <= 4 * c['D'] + 8
 
