@@ -658,6 +658,13 @@ extern "C" int dccf_dp_local(dccf_ctx* ctx, const dccf_model_t* model, const dcc
     dccf_grads_t gs = *grads;
     gs.gW = dp->buf + y.dense_off + (oW - dp->dense_begin);
     gs.gb = dp->buf + y.dense_off + (ob - dp->dense_begin);
+    for (int k = 0; k < model->n_extra; ++k) {        // --n_layers > 1: the extra layers' gradients are part of the dense tail
+      const int64_t oWk = grads->gWl[k] - opt->g, obk = grads->gbl[k] - opt->g;
+      ARG_CHECK(grads->gWl[k] && grads->gbl[k] && oWk >= dp->dense_begin && obk >= dp->dense_begin && oWk < opt->n && obk < opt->n,
+                "the gradients of the extra mlp layers must lie in the dense tail of g");
+      gs.gWl[k] = dp->buf + y.dense_off + (oWk - dp->dense_begin);
+      gs.gbl[k] = dp->buf + y.dense_off + (obk - dp->dense_begin);
+    }
     gs.touchedU = gs.touchedV = nullptr;
     ctx->slot_where = dp->pwhere + ((int64_t)parity * dp->G + dp->rank) * R;
     ctx->slot_rows = dp->buf + y.rows_off;

@@ -52,9 +52,9 @@ class HipBackend(object):
         L = self.L
         lib = L.load()
         f32, u8, i32, i64 = torch.float32, torch.uint8, torch.int32, torch.int64
-        self.m = L.model_struct(tr.U, tr.V, tr.W, tr.b, tr.feat, tr.expo, tr.S, tr.A, tr.std, ips=tr.ips)
+        self.m = L.model_struct(tr.U, tr.V, tr.W, tr.b, tr.feat, tr.expo, tr.S, tr.A, tr.std, ips=tr.ips, extra=tr.extra)
         self.r = L.rand_struct(seed=tr.seed, step=0)
-        self.g = L.GradsT(L.ptr(tr.gU), L.ptr(tr.gV), L.ptr(tr.gW), L.ptr(tr.gb), L.ptr(tr.tU, u8), L.ptr(tr.tV, u8))
+        self.g = L.grads_struct(tr.gU, tr.gV, tr.gW, tr.gb, tr.tU, tr.tV, tr.gextra)
         self.opt = L.opt_struct(tr.opt_name, tr.flat_p, tr.flat_g, tr.s1, tr.s2, tr.lr, tr.l2, tr.l2, 50.0, tr.segments, 0)
         # windowed lazy regularisation in the overlapped form of the step: phase 1 advances one K-th of the
         # rows no rank touches by K steps instead of streaming all of them every step
@@ -145,12 +145,15 @@ class ReplicatedDCCF(object):
             self.be.flush(self)
 
     def __init__(self, rank, world, user_num, item_num, D, S, A, std, dropout, lr, l2, seed, backend, device, feat,
-                 expo=None, ips=None, max_rows=256, group=None, overlap=True, flat_p=None, s1=None, s2=None, opt_name='adam'):
+                 expo=None, ips=None, max_rows=256, group=None, overlap=True, flat_p=None, s1=None, s2=None, opt_name='adam', n_layers=1):
         """feat [item_num, F]; expo [user_num, item_num] or ips (dict of IPSBiasedMF factors) — full tables, identical on
         every rank.  max_rows: the largest 2B a step will see (sizes the all-gather buffer).  flat_p / s1 / s2: train THESE
         buffers (a models.DCCF's flat parameter buffer and its optimizer's Adam state: same [U | V | W | b] layout, every
         block on a 256-float boundary) instead of allocating — how runner.fit puts a CLI model on G GPUs.  opt_name: 'adam' |
-        'adagrad' | 'gd' (src/runners/BaseRunner.py:83-107; s1 = Adam's m / Adagrad's sum, s2 = Adam's v)."""
+        'adagrad' | 'gd' (src/runners/BaseRunner.py:83-107; s1 = Adam's m / Adagrad's sum, s2 = Adam's v).  n_layers: the
+        extra Linear(D, D) layers of --n_layers > 1 (src/models/DCCF.py:61-62) follow b in the buffer, weight then bias per
+        layer: they are part of the dense tail that travels and is summed with [dW | db]."""
+        self.n_layers = int(n_layers)
         self.opt_name = opt_name.lower()
         if self.opt_name not in ('adam', 'adagrad', 'gd'):
             raise ValueError('unknown optimizer ' + opt_name)
@@ -159,7 +162,8 @@ class ReplicatedDCCF(object):
         self.std, self.dropout, self.lr, self.l2, self.seed = std, dropout, lr, l2, seed
         self.feat, self.expo, self.ips = feat, expo, ips
         F = feat.shape[1]
-        sizes = [user_num * D, item_num * D, D * (D + F), D]
+        sizes = [user_num * D, item_num * D, D * (D + F), D] + [D * D, D] * (self.n_layers - 1)
+        shapes = [(user_num, D), (item_num, D), (D, D + F), (D,)] + [(D, D), (D,)] * (self.n_layers - 1)
         pads = [(n + 255) // 256 * 256 for n in sizes]
         f32 = torch.float32
         for name, t in (('flat_p', flat_p), ('s1', s1), ('s2', s2)):
@@ -173,13 +177,15 @@ class ReplicatedDCCF(object):
         # model's own call counter between steps (evaluation passes of the CLI) moves the base so that no word is used twice
         self.word_base = 0
         o, views, gviews, offs = 0, [], [], []
-        for n, pd, shp in zip(sizes, pads, [(user_num, D), (item_num, D), (D, D + F), (D,)]):
+        for n, pd, shp in zip(sizes, pads, shapes):
             views.append(self.flat_p[o:o + n].view(shp))
             gviews.append(self.flat_g[o:o + n].view(shp))
             offs.append(o)
             o += pd
-        self.U, self.V, self.W, self.b = views
-        self.gU, self.gV, self.gW, self.gb = gviews
+        self.U, self.V, self.W, self.b = views[:4]
+        self.gU, self.gV, self.gW, self.gb = gviews[:4]
+        self.extra = [(views[4 + 2 * k], views[5 + 2 * k]) for k in range(self.n_layers - 1)]
+        self.gextra = [(gviews[4 + 2 * k], gviews[5 + 2 * k]) for k in range(self.n_layers - 1)]
         u8 = torch.uint8
         self.tU = torch.zeros((user_num + 3) // 4 * 4, dtype=u8, device=device)[:user_num]     # whole 32-bit words
         self.tV = torch.zeros((item_num + 3) // 4 * 4, dtype=u8, device=device)[:item_num]
@@ -218,7 +224,7 @@ class ReplicatedDCCF(object):
     def init_params(self, std=0.01):
         """BaseModel.init_paras (src/models/BaseModel.py:130-142): N(0, 0.01); the SAME values on every rank."""
         g = torch.Generator(device=self.dev).manual_seed(self.seed * 7919 + 7)
-        for t in (self.U, self.V, self.W, self.b):
+        for t in (self.U, self.V, self.W, self.b) + tuple(x for wb in self.extra for x in wb):
             t.normal_(0.0, std, generator=g)
 
     def set_params(self, U, V, W, b):

@@ -163,16 +163,16 @@ class BaseRunner(object):
         tr = getattr(model, '_replicated', None)
         if tr is None:
             D = getattr(model, 'ui_vector_size', 0)
-            if (getattr(model, 'kind', '') != 'DCCF' or model.n_layers != 1 or D not in (16, 32, 64, 128)
-                    or not self.fused_sampling or data_processor.rank != 1):
-                raise RuntimeError('training on several GPUs covers --model_name DCCF --n_layers 1 --rank 1 --fused_sampling 1 '
-                                   'with an embedding size of 16, 32, 64 or 128')
+            if (getattr(model, 'kind', '') != 'DCCF' or D not in (16, 32, 64, 128) or not self.fused_sampling
+                    or data_processor.rank != 1):
+                raise RuntimeError('training on several GPUs covers --model_name DCCF --rank 1 --fused_sampling 1 with an '
+                                   'embedding size of 16, 32, 64 or 128')
             o.flush()
             tr = replicated.ReplicatedDCCF(rank, G, model.user_num, model.item_num, D, model.sample_num, model.attribute_num,
                                            model.std, self.dropout, o.lr, o.l2, model.random_seed,
                                            replicated.HipBackend(model.device), model.device, model.feature_embedding,
                                            expo=model.expo_prob, ips=model.ips_factors, max_rows=2 * B, overlap=True,
-                                           flat_p=model.flat_p, s1=o.s1, s2=o.s2, opt_name=o.name)
+                                           flat_p=model.flat_p, s1=o.s1, s2=o.s2, opt_name=o.name, n_layers=model.n_layers)
             tr.t = o.t
             model._replicated = tr
             o.lazy = None                   # the trainer owns the lazy regularisation of these buffers from here on

@@ -169,7 +169,7 @@ def test_replicated_trainer_world1_equals_single_gpu_step(overlap):
     torch.cuda.synchronize()
 
 
-def _rank_main(rank, world, port, out, overlap, opt_name='adam'):
+def _rank_main(rank, world, port, out, overlap, opt_name='adam', n_layers=1):
     import torch.distributed as dist
     tag = str(overlap)
     prep, overlap = overlap == 'prep', bool(overlap)
@@ -185,7 +185,7 @@ def _rank_main(rank, world, port, out, overlap, opt_name='adam'):
     expo = torch.randn(c['U'], c['I'], generator=g, device='cuda')
     tr = replicated.ReplicatedDCCF(rank, world, c['U'], c['I'], c['D'], c['S'], c['A'], 0.1, 0.2, 1e-2, 1e-4, 5,
                                    replicated.HipBackend(dev), dev, feat, expo=expo, max_rows=2 * c['B'], overlap=overlap,
-                                   opt_name=opt_name)
+                                   opt_name=opt_name, n_layers=n_layers)
     tr.init_params(0.1)
     y = torch.cat([torch.ones(c['B'], device='cuda'), torch.zeros(c['B'], device='cuda')])
     gen = torch.Generator(device='cuda').manual_seed(2)
@@ -210,16 +210,17 @@ def _rank_main(rank, world, port, out, overlap, opt_name='adam'):
 W2 = dict(U=700, I=450, D=64, F=96, S=10, A=2, B=40, steps=5)
 
 
-@pytest.mark.parametrize('overlap,world,opt_name', [(False, 2, 'adam'), (True, 2, 'adam'), ('prep', 2, 'adam'), ('prep', 3, 'adam'),
-                                                   ('prep', 2, 'adagrad'), ('prep', 2, 'gd'), (False, 2, 'gd')])
-def test_two_ranks_hip_backend_replicas_bit_identical(tmp_path, overlap, world, opt_name):
+@pytest.mark.parametrize('overlap,world,opt_name,n_layers', [
+    (False, 2, 'adam', 1), (True, 2, 'adam', 1), ('prep', 2, 'adam', 1), ('prep', 3, 'adam', 1), ('prep', 2, 'adagrad', 1),
+    ('prep', 2, 'gd', 1), (False, 2, 'gd', 1), ('prep', 2, 'adam', 2), (True, 2, 'adam', 3), (False, 2, 'adagrad', 2)])
+def test_two_ranks_hip_backend_replicas_bit_identical(tmp_path, overlap, world, opt_name, n_layers):
     """World size 2 (and 3) with the HIP backend (the ranks share this box's one GPU, gloo as the transport): the replicas
     end bit-identical, nothing is left in the gradient buffer, the flags or the tables, and the result equals the same
     batches accumulated into one gradient on one GPU, to the float-atomic tolerance."""
     import torch.multiprocessing as mp
     from dccf_amd import _lib as L
-    port = 33000 + os.getpid() % 2000 + {False: 0, True: 11, 'prep': 23}[overlap] + 7 * world + {'adam': 0, 'adagrad': 41, 'gd': 57}[opt_name]
-    mp.spawn(_rank_main, args=(world, port, str(tmp_path), overlap, opt_name), nprocs=world, join=True)
+    port = 33000 + os.getpid() % 2000 + {False: 0, True: 11, 'prep': 23}[overlap] + 7 * world + {'adam': 0, 'adagrad': 41, 'gd': 57}[opt_name] + 101 * n_layers
+    mp.spawn(_rank_main, args=(world, port, str(tmp_path), overlap, opt_name, n_layers), nprocs=world, join=True)
     rs = [dict(np.load(os.path.join(str(tmp_path), 'r%d_%s.npz' % (r, str(overlap))))) for r in range(world)]
     r0 = rs[0]
     for r1 in rs[1:]:
@@ -234,7 +235,7 @@ def test_two_ranks_hip_backend_replicas_bit_identical(tmp_path, overlap, world, 
     feat = torch.randn(c['I'], c['F'], generator=g, device='cuda') * 0.3
     expo = torch.randn(c['U'], c['I'], generator=g, device='cuda')
     tr = replicated.ReplicatedDCCF(0, 1, c['U'], c['I'], c['D'], c['S'], c['A'], 0.1, 0.2, 1e-2, 1e-4, 5,
-                                   replicated.HipBackend(dev), dev, feat, expo=expo, max_rows=2 * c['B'])
+                                   replicated.HipBackend(dev), dev, feat, expo=expo, max_rows=2 * c['B'], n_layers=n_layers)
     tr.init_params(0.1)
     ctx = L.Context(0)
     y = torch.cat([torch.ones(c['B'], device='cuda'), torch.zeros(c['B'], device='cuda')])
@@ -247,9 +248,9 @@ def test_two_ranks_hip_backend_replicas_bit_identical(tmp_path, overlap, world, 
                              for _ in range(world)])
         total = 0.0
         for r in range(world):
-            m = L.model_struct(tr.U, tr.V, tr.W, tr.b, feat, expo, c['S'], c['A'], 0.1)
+            m = L.model_struct(tr.U, tr.V, tr.W, tr.b, feat, expo, c['S'], c['A'], 0.1, extra=tr.extra)
             _, loss = L.dccf_train_fwdbwd(ctx, m, L.rand_struct(seed=5, step=t * world + r), X_all[r].contiguous(), y, 1, 0.2,
-                                          tr.gU, tr.gV, tr.gW, tr.gb)
+                                          tr.gU, tr.gV, tr.gW, tr.gb, gextra=tr.gextra)
             total += float(loss)
         assert total == pytest.approx(float(r0['losses'][t]), rel=1e-4)
         L.dense_opt_step(opt_name, tr.flat_p, tr.flat_g, s1, s2, 1e-2, 1e-4, 1e-4, 50.0, t + 1)
@@ -354,12 +355,12 @@ def _cli_rank_main(rank, world, port, tmp, cfg):
     os.makedirs(os.path.join(tmp, 'src'), exist_ok=True)
     os.chdir(os.path.join(tmp, 'src'))
     valid, init, out = [], [], {}
-    for seed in CLI_SEEDS:
-        runner = M.main(['--rank', '1', '--model_name', 'DCCF', '--optimizer', 'Adam', '--lr', str(cfg['lr']), '--dataset', 'toy',
+    for seed in cfg.get('seeds', CLI_SEEDS):
+        runner = M.main(['--rank', '1', '--model_name', 'DCCF', '--optimizer', cfg.get('optimizer', 'Adam'), '--lr', str(cfg['lr']), '--dataset', 'toy',
                          '--path', '../dataset/', '--metric', 'ndcg@5,recall@5,auc', '--epoch', str(cfg['epochs']),
                          '--test_neg_n', str(cfg['test_neg_n']), '--u_vector_size', str(cfg['D']), '--i_vector_size', str(cfg['D']),
                          '--batch_size', str(cfg['batch_size'] // world), '--check_epoch', '0', '--random_seed', str(seed),
-                         '--verbose', '30', '--model_path', '../model/DCCF/two.pt'])
+                         '--verbose', '30', '--model_path', '../model/DCCF/two.pt'] + cfg.get('more', []))
         valid.append(np.array(runner.valid_results))
         init.append(np.array(runner.init_results[1]))
         m = runner.model
@@ -409,3 +410,22 @@ def test_cli_on_two_ranks(tmp_path):
         se = np.sqrt(ref[:, e].var(ddof=1) / len(seeds) + mine[:, e].var(ddof=1) / len(CLI_SEEDS))
         assert abs(mine[:, e].mean() - ref[:, e].mean()) <= 3 * se + 2e-3, \
             'epoch %d: two ranks %.4f vs reference %.4f (se %.4f)' % (e + 1, mine[:, e].mean(), ref[:, e].mean(), se)
+
+
+def test_cli_on_two_ranks_extra_layers_adagrad(tmp_path):
+    """The same launch with --n_layers 2 --optimizer Adagrad and a batch size that leaves the epoch's schedule uneven: the extra
+    layers travel in the dense tail of the exchange, the replicas stay identical and the checkpoint holds all six tensors."""
+    import torch.multiprocessing as mp
+    from dccf_amd import synth
+    tmp = str(tmp_path)
+    synth.write_dataset(os.path.join(tmp, 'dataset'), 'toy', 300, 200, 5000, feat_dim=32, seed=3)
+    cfg = dict(lr=0.01, epochs=2, test_neg_n=50, D=16, batch_size=96, seeds=[7], optimizer='Adagrad', more=['--n_layers', '2'])
+    mp.spawn(_cli_rank_main, args=(2, 37000 + os.getpid() % 2000, tmp, cfg), nprocs=2, join=True)
+    r0, r1 = (dict(np.load(os.path.join(tmp, 'cli%d.npz' % r))) for r in range(2))
+    for k in r0:
+        assert np.array_equal(r0[k], r1[k], equal_nan=True), k
+    assert {'mlp.1.weight', 'mlp.1.bias'} <= set(r0) and r0['mlp.1.weight'].shape == (16, 16)
+    sd = torch.load(os.path.join(tmp, 'model', 'DCCF', 'two.pt'), map_location='cpu')
+    assert len(sd) == 6
+    # the extra layer was trained: N(0, 0.01) at the start, Adagrad's first steps move every touched element by ~lr
+    assert np.abs(r0['mlp.1.weight']).max() > 0.02 and np.isfinite(r0['valid']).all()
