@@ -260,6 +260,35 @@ class ReplicatedDCCF(object):
         return pred, self.loss_sum
 
 
+def epoch_schedule(full, tail, G):
+    """An epoch's batches (DeviceTrainSet.epoch_batches: full [nb, 2B, 2] = [positives ; negatives] per batch, tail [2r, 2] or
+    None) as the steps of a G-rank job: (sched [ns, G, 2B, 2], last [G, 2b, 2] or None).  Step j < ns trains batches
+    j G .. j G + G - 1, rank r the r-th of them.  What is left — fewer than G batches and the short last batch — becomes ONE more
+    step of b = ceil(left / G) pairs per rank; the G b - left missing pairs (< G) are the epoch's first pairs again, as
+    torch.utils.data.DistributedSampler completes an uneven epoch.  Every share keeps the batch layout: row k and row b + k are
+    the positive and the negative of one pair (same uid, src/data_processor/DataProcessor.py:160-207)."""
+    nb, B = full.shape[0], full.shape[1] // 2
+    ns = nb // G
+    sched = full[:ns * G].view(ns, G, 2 * B, 2)
+    pos, neg = [full[ns * G:, :B].reshape(-1, 2)], [full[ns * G:, B:].reshape(-1, 2)]
+    if tail is not None:
+        r = tail.shape[0] // 2
+        pos.append(tail[:r])
+        neg.append(tail[r:])
+    pos, neg = torch.cat(pos), torch.cat(neg)
+    left = pos.shape[0]
+    if left == 0:
+        return sched, None
+    b = (left + G - 1) // G
+    pad = b * G - left
+    if pad:
+        src = full[0] if nb > 0 else torch.cat([pos, neg])
+        h = src.shape[0] // 2
+        take = torch.arange(pad, device=full.device) % h
+        pos, neg = torch.cat([pos, src[:h][take]]), torch.cat([neg, src[h:][take]])
+    return sched, torch.cat([pos.view(G, b, 2), neg.view(G, b, 2)], dim=1).contiguous()
+
+
 # ------------------------------------------------------------------------------------------------------ bench entry
 def bench_main(args, rank, world, dev):
     """bench.py --gpus N (N > 1): weak scaling — every rank trains `batch_size` pairs per step on a full replica."""

@@ -181,9 +181,8 @@ class BaseRunner(object):
         model.train()
         full, tail = data_processor.device_epoch(max(epoch, 0), B)
         dev = full.device
-        nb = full.shape[0]
-        ns = nb // G
-        sched = full[:ns * G].view(ns, G, 2 * B, 2)
+        sched, last = replicated.epoch_schedule(full, tail, G)
+        ns = sched.shape[0]
         y = torch.cat([torch.ones(B, device=dev), torch.zeros(B, device=dev)])
         pred = torch.empty(2 * B, dtype=torch.float32, device=dev)
         # no Philox word twice: the trainer's words of this epoch start after everything the model's call counter handed out
@@ -191,26 +190,11 @@ class BaseRunner(object):
         loss = None
         for j in range(ns):
             _, loss = tr.train_step(sched[j, rank], y, pred, X_all=sched[j], X_all_next=sched[j + 1] if j + 1 < ns else None)
-        # the rest of the epoch: batches ns G .. nb - 1 and the short last batch, as one step of equal shares
-        pos, neg = [full[ns * G:, :B].reshape(-1, 2)], [full[ns * G:, B:].reshape(-1, 2)]
-        if tail is not None:
-            r = tail.shape[0] // 2
-            pos.append(tail[:r])
-            neg.append(tail[r:])
-        pos, neg = torch.cat(pos), torch.cat(neg)
-        n_left = pos.shape[0]
-        if n_left > 0:
-            b = (n_left + G - 1) // G
-            pad = b * G - n_left
-            if pad:
-                src = full[0] if nb > 0 else torch.cat([pos, neg])
-                h = src.shape[0] // 2
-                take = torch.arange(pad, device=dev) % h
-                pos, neg = torch.cat([pos, src[:h][take]]), torch.cat([neg, src[h:][take]])
-            X_all = torch.cat([pos.view(G, b, 2), neg.view(G, b, 2)], dim=1).contiguous()
+        if last is not None:         # the rest of the epoch: one step of equal shares
+            b = last.shape[1] // 2
             yl = torch.cat([torch.ones(b, device=dev), torch.zeros(b, device=dev)])
             pred = torch.empty(2 * b, dtype=torch.float32, device=dev)
-            _, loss = tr.train_step(X_all[rank], yl, pred, X_all=X_all)
+            _, loss = tr.train_step(last[rank], yl, pred, X_all=last)
         tr.flush()
         o.t = tr.t
         model._call = tr.word_base + tr.t * G        # every word below is used

@@ -206,3 +206,38 @@ def test_replicated_step_equals_union_batch(tmp_path, overlap):
         for k, name in zip(KEYS, 'UVWb'):
             assert np.allclose(res[r][name], P[k], rtol=1e-5, atol=1e-6), name
     assert np.array_equal(res[0]['p'], res[1]['p'])        # replicas are bit-identical
+
+
+@pytest.mark.parametrize('n,B,G', [(1000, 64, 2), (1000, 64, 8), (640, 64, 2), (130, 64, 4), (50, 64, 4), (7, 64, 8), (1024, 128, 8)])
+def test_epoch_schedule_covers_every_pair_once(n, B, G):
+    """replicated.epoch_schedule (what runner._fit_replicated trains under a multi-rank launch): every pair of the epoch is in
+    exactly one (step, rank) share, at most G - 1 pairs (the epoch's first) a second time, the shares of a step have equal
+    size, and every share keeps the [positives ; negatives] layout with the pair's uid in rows k and b + k
+    (src/data_processor/DataProcessor.py:160-207)."""
+    from dccf_amd.replicated import epoch_schedule
+    rng = np.random.RandomState(n + G)
+    uid = rng.randint(0, 500, n)
+    pos = np.stack([uid, np.arange(n)], 1)                     # iid = the pair's index: identifies it
+    neg = np.stack([uid, 100000 + np.arange(n)], 1)
+    nb, r = n // B, n % B
+    full = torch.from_numpy(np.stack([np.concatenate([pos[k * B:(k + 1) * B], neg[k * B:(k + 1) * B]]) for k in range(nb)])
+                            if nb else np.zeros((0, 2 * B, 2), np.int64))
+    tail = torch.from_numpy(np.concatenate([pos[nb * B:], neg[nb * B:]])) if r else None
+    sched, last = epoch_schedule(full, tail, G)
+    assert sched.shape == (nb // G, G, 2 * B, 2)
+    seen = []
+    shares = [sched[j, g] for j in range(sched.shape[0]) for g in range(G)]
+    if last is not None:
+        assert last.shape[0] == G and last.shape[1] % 2 == 0 and last.shape[1] // 2 <= B
+        shares += [last[g] for g in range(G)]
+    else:
+        assert n % (G * B) == 0
+    for sh in shares:
+        b = sh.shape[0] // 2
+        assert torch.equal(sh[:b, 0], sh[b:, 0])                            # the pair shares its uid
+        assert torch.equal(sh[b:, 1], sh[:b, 1] + 100000)                   # negative k belongs to positive k
+        seen.append(sh[:b, 1].numpy())
+    seen = np.concatenate(seen)
+    cnt = np.bincount(seen, minlength=n)
+    assert cnt.min() == 1 and cnt.sum() - n < G and (cnt[min(B, n):] == 1).all()
+    assert len(shares) // G == -(-n // (G * B))
