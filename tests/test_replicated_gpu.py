@@ -343,7 +343,7 @@ def test_two_ranks_hip_backend_row_sharded_equals_union_batch(tmp_path, lazy_K):
 
 
 # ------------------------------------------------------------------------------------------------ the CLI on two ranks
-CLI_SEEDS = [2019, 2020, 2021, 2022, 2023, 2024]
+CLI_SEEDS = [2019 + i for i in range(int(os.environ.get('DCCF_TEST_CLI_SEEDS', '6')))]      # (41 = every seed the reference was run with)
 
 
 def _cli_rank_main(rank, world, port, tmp, cfg):
@@ -406,6 +406,12 @@ def test_cli_on_two_ranks(tmp_path):
     ref = np.stack([g['seed%d/valid' % s][:, 0] for s in seeds])
     mine = r0['valid'][:, :, 0]
     assert mine.shape == (len(CLI_SEEDS), cfg['epochs']) and np.isfinite(r0['valid']).all()
+    if os.environ.get('DCCF_TEST_DUMP'):
+        import json
+        with open(os.environ['DCCF_TEST_DUMP'], 'w') as f:
+            json.dump({'two_ranks_seeds': len(CLI_SEEDS), 'reference_seeds': len(seeds), 'batch_size_per_rank': B // 2,
+                       'two_ranks_mean': mine.mean(0).tolist(), 'two_ranks_se': (mine.std(0, ddof=1) / len(CLI_SEEDS) ** 0.5).tolist(),
+                       'reference_mean': ref.mean(0).tolist(), 'reference_se': (ref.std(0, ddof=1) / len(seeds) ** 0.5).tolist()}, f)
     for e in range(cfg['epochs']):
         se = np.sqrt(ref[:, e].var(ddof=1) / len(seeds) + mine[:, e].var(ddof=1) / len(CLI_SEEDS))
         assert abs(mine[:, e].mean() - ref[:, e].mean()) <= 3 * se + 2e-3, \
