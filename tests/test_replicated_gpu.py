@@ -169,7 +169,7 @@ def test_replicated_trainer_world1_equals_single_gpu_step(overlap):
     torch.cuda.synchronize()
 
 
-def _rank_main(rank, world, port, out, overlap, opt_name='adam', n_layers=1):
+def _rank_main(rank, world, port, out, overlap, opt_name='adam', n_layers=1, D=64):
     import torch.distributed as dist
     tag = str(overlap)
     prep, overlap = overlap == 'prep', bool(overlap)
@@ -179,7 +179,7 @@ def _rank_main(rank, world, port, out, overlap, opt_name='adam', n_layers=1):
     dist.init_process_group('gloo', rank=rank, world_size=world)       # two ranks share the one GPU of the test box
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(dev)
-    c = W2
+    c = dict(W2, D=D)
     g = torch.Generator(device='cuda').manual_seed(1)
     feat = torch.randn(c['I'], c['F'], generator=g, device='cuda') * 0.3
     expo = torch.randn(c['U'], c['I'], generator=g, device='cuda')
@@ -210,17 +210,18 @@ def _rank_main(rank, world, port, out, overlap, opt_name='adam', n_layers=1):
 W2 = dict(U=700, I=450, D=64, F=96, S=10, A=2, B=40, steps=5)
 
 
-@pytest.mark.parametrize('overlap,world,opt_name,n_layers', [
-    (False, 2, 'adam', 1), (True, 2, 'adam', 1), ('prep', 2, 'adam', 1), ('prep', 3, 'adam', 1), ('prep', 2, 'adagrad', 1),
-    ('prep', 2, 'gd', 1), (False, 2, 'gd', 1), ('prep', 2, 'adam', 2), (True, 2, 'adam', 3), (False, 2, 'adagrad', 2)])
-def test_two_ranks_hip_backend_replicas_bit_identical(tmp_path, overlap, world, opt_name, n_layers):
+@pytest.mark.parametrize('overlap,world,opt_name,n_layers,D', [
+    (False, 2, 'adam', 1, 64), (True, 2, 'adam', 1, 64), ('prep', 2, 'adam', 1, 64), ('prep', 3, 'adam', 1, 64),
+    ('prep', 2, 'adagrad', 1, 64), ('prep', 2, 'gd', 1, 64), (False, 2, 'gd', 1, 64), ('prep', 2, 'adam', 2, 64),
+    (True, 2, 'adam', 3, 64), (False, 2, 'adagrad', 2, 64), ('prep', 2, 'adam', 1, 16), ('prep', 2, 'adam', 1, 128)])
+def test_two_ranks_hip_backend_replicas_bit_identical(tmp_path, overlap, world, opt_name, n_layers, D):
     """World size 2 (and 3) with the HIP backend (the ranks share this box's one GPU, gloo as the transport): the replicas
     end bit-identical, nothing is left in the gradient buffer, the flags or the tables, and the result equals the same
     batches accumulated into one gradient on one GPU, to the float-atomic tolerance."""
     import torch.multiprocessing as mp
     from dccf_amd import _lib as L
-    port = 33000 + os.getpid() % 2000 + {False: 0, True: 11, 'prep': 23}[overlap] + 7 * world + {'adam': 0, 'adagrad': 41, 'gd': 57}[opt_name] + 101 * n_layers
-    mp.spawn(_rank_main, args=(world, port, str(tmp_path), overlap, opt_name, n_layers), nprocs=world, join=True)
+    port = 33000 + os.getpid() % 2000 + {False: 0, True: 11, 'prep': 23}[overlap] + 7 * world + {'adam': 0, 'adagrad': 41, 'gd': 57}[opt_name] + 101 * n_layers + D
+    mp.spawn(_rank_main, args=(world, port, str(tmp_path), overlap, opt_name, n_layers, D), nprocs=world, join=True)
     rs = [dict(np.load(os.path.join(str(tmp_path), 'r%d_%s.npz' % (r, str(overlap))))) for r in range(world)]
     r0 = rs[0]
     for r1 in rs[1:]:
@@ -228,7 +229,7 @@ def test_two_ranks_hip_backend_replicas_bit_identical(tmp_path, overlap, world, 
         assert np.array_equal(r0['losses'], r1['losses'])
     assert all(r['flags'].sum() == 0 and r['gmax'] == 0 for r in rs)
     # one GPU, both batches into one gradient, one optimizer step
-    c = W2
+    c = dict(W2, D=D)
     from dccf_amd import replicated
     dev = torch.device('cuda', 0)
     g = torch.Generator(device='cuda').manual_seed(1)
