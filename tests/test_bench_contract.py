@@ -47,7 +47,10 @@ def test_replicated_pipeline_line():
     for k in KEYS:
         assert k in d, k
     assert d['n_gpus'] == 1 and d['config']['replicas_bit_identical'] is True
-    assert d['roofline']['bound'] == 'hbm' and 0 < d['roofline']['frac'] < 1
+    r = d['roofline']            # the dominant kernel of the timed launch structure, measured in the run (not the dense pass)
+    assert r['kernel'] == 'k_bwd' and r['bound'] == 'mfma' and 0 < r['frac'] < 1
+    assert r['frac'] == pytest.approx(r['achieved'] / r['peak'], rel=1e-3) and 0 < r['noise_fwd']['frac'] < 1
+    assert r['dense_adam_whole_pass']['bound'] == 'hbm' and 0 < r['dense_adam_whole_pass']['frac'] < 1.2
 
 
 def test_single_gpu_line_is_honest_about_caches_and_mfma():
