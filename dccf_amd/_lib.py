@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libdccf_hip.so')
 
 EXPORTS = ['dccf_ctx_create', 'dccf_ctx_destroy', 'dccf_ctx_reserve', 'dccf_last_error', 'dccf_abi_version',
-           'dccf_predict', 'dccf_train_fwdbwd', 'dccf_dense_opt_step', 'dccf_sumsq', 'mf_predict', 'mf_train_fwdbwd',
+           'dccf_predict', 'dccf_train_fwdbwd', 'dccf_dense_opt_step', 'dccf_sumsq', 'mf_predict', 'mf_train_fwdbwd', 'mf_train_step',
            'mf_predict_full', 'dccf_sample_train_negatives', 'dccf_debug_candidates', 'dccf_debug_noise',
            'dccf_debug_keep', 'dccf_debug_keep_layer', 'dccf_debug_opt_elem', 'dccf_debug_workspace', 'dccf_profile', 'dccf_profile_read',
            'shard_pack_rows', 'shard_unpack_rows', 'shard_scatter_add', 'dccf_dense_opt_step_rows', 'dccf_dense_opt_step_dev', 'dccf_advance', 'rank_eval_topk', 'dccf_train_step', 'dp_buffer_words',
@@ -138,6 +138,7 @@ def load():
         'mf_predict': [C.POINTER(MFModelT), vp, i64, vp, vp],
         'mf_train_fwdbwd': [vp, C.POINTER(MFModelT), vp, vp, i64, i32, C.POINTER(MFGradsT), vp, vp, vp],
         'mf_predict_full': [C.POINTER(MFModelT), vp, vp],
+        'mf_train_step': [vp, C.POINTER(MFModelT), vp, vp, i64, i32, C.POINTER(MFGradsT), C.POINTER(OptT), vp, vp, vp, vp],
         'dccf_sample_train_negatives': [vp, vp, vp, vp, i64, i64, u64, u64, vp, vp],
         'dccf_ctx_prepared_steps': [vp, C.POINTER(C.c_int64)],
         'dccf_ctx_hosted_rows': [vp, C.POINTER(C.c_int64)],
@@ -531,6 +532,21 @@ def mf_train_fwdbwd(ctx, m, X, Y, rank, gP, gQ, gbu=None, gbi=None, gb0=None, pr
     g = MFGradsT(ptr(gP), ptr(gQ), ptr(gbu), ptr(gbi), ptr(gb0), ptr(touchedP, torch.uint8), ptr(touchedQ, torch.uint8))
     check(load().mf_train_fwdbwd(ctx.h if ctx is not None else None, C.byref(m), ptr(X, torch.int64), ptr(Y), N,
                                  int(rank), C.byref(g), ptr(pred), ptr(loss), stream()))
+    return pred, loss
+
+
+def mf_train_step(ctx, m, X, Y, rank, gP, gQ, gbu, gbi, gb0, opt, step, ids, pred=None, loss=None):
+    """One MF train step under the lazy optimizer (mf_train_step): catch-up of the batch's rows, forward + loss + backward, the
+    optimizer launch of step `step`.  ids: int32 scratch [2 N]."""
+    N = X.shape[0]
+    if pred is None:
+        pred = torch.empty(N, dtype=torch.float32, device=X.device)
+    if loss is None:
+        loss = torch.empty(1, dtype=torch.float32, device=X.device)
+    g = MFGradsT(ptr(gP), ptr(gQ), ptr(gbu), ptr(gbi), ptr(gb0), None, None)
+    opt.step = int(step)
+    check(load().mf_train_step(ctx.h if ctx is not None else None, C.byref(m), ptr(X, torch.int64), ptr(Y), N, int(rank),
+                               C.byref(g), C.byref(opt), ptr(ids, torch.int32), ptr(pred), ptr(loss), stream()))
     return pred, loss
 
 

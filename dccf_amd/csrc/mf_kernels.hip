@@ -316,6 +316,40 @@ extern "C" int mf_train_fwdbwd(dccf_ctx* ctx, const mf_model_t* M, const int64_t
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ one call per MF train step
+// The body of the reference's batch loop for the MF family (src/runners/BaseRunner.py:172-188 around BaseModel.forward,
+// src/models/BaseModel.py:203-219) under the windowed lazy regularisation of DESIGN.md section 4b: the rows of the batch are
+// claimed and brought up to step - 1 (dccf_lazy_catchup_rows), forward + loss + backward accumulate their gradient rows
+// (mf_train_fwdbwd), and ONE optimizer launch updates those rows with their gradient, everything outside the two row segments
+// (bias vectors, global bias) densely, and this step's window of the other rows (dccf_lazy_opt_step) — the dense pass over all
+// (user_num + item_num) x D parameters, 80 % of an IPSBiasedMF step at batch 128, shrinks to one K-th.  Same results as the dense
+// step: untouched rows bit-identical.
+__global__ __launch_bounds__(256) void k_split_ids(const int64_t* __restrict__ X, int64_t N, int32_t* __restrict__ ids) {
+  for (int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+    ids[n] = (int32_t)X[2 * n];
+    ids[N + n] = (int32_t)X[2 * n + 1];
+  }
+}
+
+extern "C" int mf_train_step(dccf_ctx* ctx, const mf_model_t* M, const int64_t* X, const float* Y, int64_t N, int32_t rank,
+                             const mf_grads_t* G, const dccf_opt_t* opt, int32_t* ids, float* prediction, float* loss,
+                             void* stream) {
+  ARG_CHECK(M && X && G && opt && ids && prediction && loss && N >= 1, "NULL argument / empty batch");
+  ARG_CHECK(opt->lazy_K > 0 && opt->nseg == 2 && opt->seg_rows[0] == M->user_num && opt->seg_rows[1] == M->item_num &&
+                opt->seg_width[0] == M->D && opt->seg_width[1] == M->D,
+            "mf_train_step needs the lazy optimizer over the two row segments (P, Q) of this model");
+  ARG_CHECK(2 * N <= opt->lazy_list_cap, "batch too large for the lazy row list");
+  ARG_CHECK(M->user_num < 2147483647LL && M->item_num < 2147483647LL, "row ids must fit 32 bits");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_split_ids, dim3((unsigned)min((int64_t)256, (N + 255) / 256)), dim3(256), 0, st, X, N, ids);
+  HIP_TRY(hipGetLastError());
+  if (int e = dccf_lazy_catchup_rows(opt, ids, N, 0, ids + N, N, 1, stream)) return e;
+  mf_grads_t g = *G;
+  g.touchedP = g.touchedQ = nullptr;          // the step's rows are on the lazy list: no bytes to keep
+  if (int e = mf_train_fwdbwd(ctx, M, X, Y, N, rank, &g, prediction, loss, stream)) return e;
+  return dccf_lazy_opt_step(opt, 2 * N, stream);
+}
+
 // ------------------------------------------------------------------------------------------------ full U x I matrix
 // out[u][i] = (P[u].Q[i] + bu[u] + bi[i] + b0) / max(prop[i], M): 128 x 128 tile per block, 4 waves x (64 x 64),
 // fp32 MFMA 32x32x2 over K = D, operands staged in LDS with a one-float row pad (conflict-free ds_read_b32).

@@ -1211,3 +1211,54 @@ def test_init_paras_distribution(L):
     for k in ('user_bias.weight', 'item_bias.weight', 'uid_embeddings.weight', 'iid_embeddings.weight'):
         x = Pb[k].detach().double().flatten()
         assert float(x.std()) == pytest.approx(0.01, rel=0.25) and abs(float(x.mean())) < 0.003, k
+
+
+@pytest.mark.parametrize('kind,opt_name,rank', [('BiasedMF', 'adam', 1), ('RecModel', 'adagrad', 1), ('IPSBiasedMF', 'gd', 0),
+                                                ('IPSBiasedMF', 'adam', 1)])
+def test_mf_lazy_train_step_equals_dense_step(L, kind, opt_name, rank):
+    """MF family: train_step (mf_train_step: catch-up of the batch's rows, forward + backward, one lazy optimizer launch; window
+    K = 4 so that it cycles several times) against forward + the dense optimizer step (src/runners/BaseRunner.py:172-188), a
+    mid-run evaluation (flush) included: rows no batch touched are bit-identical, the others agree to the float-atomic tolerance,
+    predictions of the steps agree, nothing is left in the gradient buffer."""
+    from dccf_amd import models
+    U, I, D, B, steps = 2203, 1877, 64, 48, 23
+    runs, preds, seen_u = [], [], []
+    for lazy in (True, False):
+        cls = models.BiasedMF if kind != 'RecModel' else models.RecModel
+        m = cls(label_min=0, label_max=1, feature_num=0, user_num=U, item_num=I, u_vector_size=D, i_vector_size=D, random_seed=4,
+                model_path='/tmp/mf.pt')
+        if kind == 'IPSBiasedMF':
+            m.kind, m.M = 'IPSBiasedMF', 0.1
+            m.propensity = torch.rand(I, generator=torch.Generator(device='cuda').manual_seed(9), device='cuda')
+        torch.manual_seed(1)
+        m.apply(m.init_paras)
+        m.lazy_K = 4 if lazy else 0
+        m.optimizer = models.FusedOptimizer(m, opt_name, 0.01, 1e-3)
+        m.train()
+        gen = torch.Generator(device='cuda').manual_seed(2)
+        y = torch.cat([torch.ones(B, device='cuda'), torch.zeros(B, device='cuda')]) if rank == 1 else \
+            torch.rand(2 * B, generator=torch.Generator(device='cuda').manual_seed(3), device='cuda')
+        ps = []
+        for k in range(steps):
+            u = torch.randint(0, U // 2, (B,), generator=gen, device='cuda')           # the upper half of the users: never touched
+            X = torch.stack([torch.cat([u, u]), torch.randint(0, I, (2 * B,), generator=gen, device='cuda')], 1)
+            out = m.train_step({'X': X, 'Y': y, 'rank': rank, 'train': True, 'dropout': 0.0})
+            ps.append(out['prediction'].clone())
+            if k == 9:                       # an evaluation in the middle of the epoch reads every row
+                m.eval()
+                ps.append(m.predict({'X': X})['prediction'].clone())
+                m.train()
+        assert (m.optimizer.lazy is not None) == lazy and m.optimizer.t == steps
+        sd = m.state_dict()                 # (flushes)
+        torch.cuda.synchronize()
+        assert float(m.flat_g.abs().max()) == 0.0
+        runs.append(m.flat_p.clone())
+        preds.append(torch.stack([p for p in ps]))
+        never = m.params['uid_embeddings.weight'][U // 2:].clone()
+        seen_u.append(never)
+    assert torch.equal(seen_u[0], seen_u[1])                                   # untouched rows: bit for bit
+    assert float(seen_u[0].abs().max()) > 0 and not torch.equal(seen_u[0][0], torch.zeros(D, device='cuda'))
+    d = (runs[0] - runs[1]).abs()
+    tol = steps * 0.01
+    assert float(d.max()) <= tol and int((d > steps * STEP_FRAC * 0.01).sum()) <= 4 * D + 8
+    assert float((preds[0] - preds[1]).abs().max()) <= 5e-3 * max(1.0, float(preds[1].abs().max()))
