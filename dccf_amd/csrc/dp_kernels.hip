@@ -80,7 +80,7 @@ __device__ __forceinline__ void dp_mark_rows(const MarkGlobal& mg, int64_t tid, 
 }
 
 __global__ __launch_bounds__(256) void k_dp_mark(MarkGlobal mg) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) *mg.mp.cnt_next = 0;
+  if (mg.mp.cnt_next && blockIdx.x == 0 && threadIdx.x == 0) *mg.mp.cnt_next = 0;      // (bytes only: no list, no counters)
   dp_mark_rows(mg, blockIdx.x * (int64_t)blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
 }
 
@@ -624,6 +624,7 @@ extern "C" int dccf_dp_local(dccf_ctx* ctx, const dccf_model_t* model, const dcc
     if (int e = dp_discard_prepared(ctx, model, dp, st)) return e;
   }
   const bool lazy = opt->lazy_K > 0;
+  bool marked_early = false;
   if (lazy) {
     ARG_CHECK(X_all != nullptr, "the lazy optimizer needs the replicated schedule (X_all) in every step");
     // rows ANY rank touches this step: known as bytes when the previous step prepared this one -> claimed and brought up to
@@ -639,7 +640,19 @@ extern "C" int dccf_dp_local(dccf_ctx* ctx, const dccf_model_t* model, const dcc
       if (!mine)
         if (int e = dccf_lazy_catchup_flags(opt, dp_gflags(dp, parity, 0), dp_gflags(dp, parity, 1), dp->segU, dp->segV, st)) return e;
     } else {
-      if (int e = dccf_lazy_flush_to_prev(opt, st)) return e;
+      // a step nobody announced (the first of an epoch): the replicated schedule still names the rows ANY rank touches — they
+      // are marked first, by a launch of their own, and only they are claimed and brought up to step - 1 (the catch-up reads the
+      // pending window's marks itself); bringing the whole table up to date instead cost ~70 us (DCCF_DP_FLUSH_UNPREPARED=1)
+      static const bool flush_all = getenv("DCCF_DP_FLUSH_UNPREPARED") != nullptr;
+      if (flush_all) {
+        if (int e = dccf_lazy_flush_to_prev(opt, st)) return e;
+      } else {
+        if (int e = dp_mark_global(X_all, dp->G, N, dp->S, dp->item_num, dp->seed, step0, dp_gflags(dp, parity, 0),
+                                   dp_gflags(dp, parity, 1), dp->segU, dp->segV, nullptr, nullptr, nullptr, stream))
+          return e;
+        if (int e = dccf_lazy_catchup_flags(opt, dp_gflags(dp, parity, 0), dp_gflags(dp, parity, 1), dp->segU, dp->segV, st)) return e;
+        marked_early = true;
+      }
     }
   }
   ctx->prep_dp = 0;
@@ -701,16 +714,16 @@ extern "C" int dccf_dp_local(dccf_ctx* ctx, const dccf_model_t* model, const dcc
     return 0;
   }
   MarkGlobal mg;
-  if (X_all) {     // overlap mode: the global marking rides in the export launch
+  if (X_all && !marked_early) {     // overlap mode: the global marking rides in the export launch
     // (bytes only: the merged import needs no list of the marked rows, so dp->glist / dp->gcnt stay untouched)
     if (int e = make_mark_global(X_all, dp->G, N, dp->S, dp->item_num, dp->seed, step0, dp_gflags(dp, parity, 0),
                                  dp_gflags(dp, parity, 1), dp->segU, dp->segV, nullptr, nullptr, nullptr, &mg))
       return e;
   }
   if (int e = dp_export_impl(opt->g, opt->n, opt->nseg, opt->seg_begin, opt->seg_rows, opt->seg_width, opt->seg_flags,
-                             dp->dense_begin, dp->loss, dp->buf, dp->cap, dp->D, 0, X_all ? &mg : nullptr, stream))
+                             dp->dense_begin, dp->loss, dp->buf, dp->cap, dp->D, 0, (X_all && !marked_early) ? &mg : nullptr, stream))
     return e;
-  if (lazy) return dccf_lazy_catchup_flags(opt, dp_gflags(dp, parity, 0), dp_gflags(dp, parity, 1), dp->segU, dp->segV, st);
+  if (lazy && !marked_early) return dccf_lazy_catchup_flags(opt, dp_gflags(dp, parity, 0), dp_gflags(dp, parity, 1), dp->segU, dp->segV, st);
   return 0;
 }
 
