@@ -139,6 +139,9 @@ int dccf_lazy_reset_claims(const void* o, hipStream_t st);
 // replicated multi-GPU path (dp_kernels.hip): rows flagged in (flags0, flags1) of segments (seg0, seg1) claimed + caught up;
 // phase 1 = window + marks + next-step preparation; everything brought to step - 1
 int dccf_lazy_catchup_flags(const void* o, const uint8_t* flags0, const uint8_t* flags1, int seg0, int seg1, hipStream_t st);
+// the rows of a batch of (user, item) pairs X [N][2]: slot j < N = row X[2 j] of segment seg_u, slot N + j = row X[2 j + 1] of
+// segment seg_v; *zero (may be NULL) is set to 0 by the same launch (mf_train_step: the loss accumulator)
+int dccf_lazy_catchup_pairs(const void* o, const int64_t* X, int64_t N, int seg_u, int seg_v, float* zero, hipStream_t st);
 int dccf_lazy_phase1(const void* o, const PrepNext* pn, hipStream_t st);
 int dccf_lazy_flush_to_prev(const void* o, hipStream_t st);
 // dccf_kernels.hip: workspace pointers / key of the step (X_next, N, step_next) into pn (w_begin / w_end / blocks and the

@@ -286,9 +286,16 @@ __global__ __launch_bounds__(256) void k_mf_train_small(mf_model_t M, mf_grads_t
   }
 }
 
+static int mf_train_launch(const mf_model_t* M, const int64_t* X, const float* Y, int64_t N, int32_t rank, const mf_grads_t* G,
+                           float* prediction, float* loss, void* stream, bool zero_loss);
 extern "C" int mf_train_fwdbwd(dccf_ctx* ctx, const mf_model_t* M, const int64_t* X, const float* Y, int64_t N,
                                int32_t rank, const mf_grads_t* G, float* prediction, float* loss, void* stream) {
   (void)ctx;
+  return mf_train_launch(M, X, Y, N, rank, G, prediction, loss, stream, true);
+}
+// zero_loss = false: an earlier launch on the stream already set *loss = 0 (mf_train_step)
+static int mf_train_launch(const mf_model_t* M, const int64_t* X, const float* Y, int64_t N, int32_t rank, const mf_grads_t* G,
+                           float* prediction, float* loss, void* stream, bool zero_loss) {
   ARG_CHECK(M && X && G && prediction && loss && N >= 0, "NULL argument");
   ARG_CHECK(M->P && M->Q && M->D >= 1 && M->D <= 256 && M->kind >= 0 && M->kind <= 2, "bad model");
   ARG_CHECK(G->gP && G->gQ, "NULL gradient pointer");
@@ -298,7 +305,7 @@ extern "C" int mf_train_fwdbwd(dccf_ctx* ctx, const mf_model_t* M, const int64_t
   if (rank == 1) ARG_CHECK(N % 2 == 0, "rank==1 needs [positives ; negatives] (even N)");
   if (rank == 0) ARG_CHECK(Y != nullptr, "rank==0 needs Y");
   hipStream_t st = (hipStream_t)stream;
-  HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), st));
+  if (zero_loss) HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), st));
   if (N == 0) return 0;
   const int per = rank == 1 ? MF_CH / 2 : MF_CH;
   const int64_t units = rank == 1 ? N / 2 : N;
@@ -319,34 +326,27 @@ extern "C" int mf_train_fwdbwd(dccf_ctx* ctx, const mf_model_t* M, const int64_t
 // ------------------------------------------------------------------------------------------------ one call per MF train step
 // The body of the reference's batch loop for the MF family (src/runners/BaseRunner.py:172-188 around BaseModel.forward,
 // src/models/BaseModel.py:203-219) under the windowed lazy regularisation of DESIGN.md section 4b: the rows of the batch are
-// claimed and brought up to step - 1 (dccf_lazy_catchup_rows), forward + loss + backward accumulate their gradient rows
+// claimed and brought up to step - 1 (k_lazy_catchup_pairs, which reads the ids from X), forward + loss + backward accumulate their gradient rows
 // (mf_train_fwdbwd), and ONE optimizer launch updates those rows with their gradient, everything outside the two row segments
 // (bias vectors, global bias) densely, and this step's window of the other rows (dccf_lazy_opt_step) — the dense pass over all
 // (user_num + item_num) x D parameters, 80 % of an IPSBiasedMF step at batch 128, shrinks to one K-th.  Same results as the dense
 // step: untouched rows bit-identical.
-__global__ __launch_bounds__(256) void k_split_ids(const int64_t* __restrict__ X, int64_t N, int32_t* __restrict__ ids) {
-  for (int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
-    ids[n] = (int32_t)X[2 * n];
-    ids[N + n] = (int32_t)X[2 * n + 1];
-  }
-}
-
 extern "C" int mf_train_step(dccf_ctx* ctx, const mf_model_t* M, const int64_t* X, const float* Y, int64_t N, int32_t rank,
                              const mf_grads_t* G, const dccf_opt_t* opt, int32_t* ids, float* prediction, float* loss,
                              void* stream) {
-  ARG_CHECK(M && X && G && opt && ids && prediction && loss && N >= 1, "NULL argument / empty batch");
+  (void)ctx;
+  (void)ids;                                   // (scratch of the first form of this call; the catch-up reads X itself)
+  ARG_CHECK(M && X && G && opt && prediction && loss && N >= 1, "NULL argument / empty batch");
   ARG_CHECK(opt->lazy_K > 0 && opt->nseg == 2 && opt->seg_rows[0] == M->user_num && opt->seg_rows[1] == M->item_num &&
                 opt->seg_width[0] == M->D && opt->seg_width[1] == M->D,
             "mf_train_step needs the lazy optimizer over the two row segments (P, Q) of this model");
   ARG_CHECK(2 * N <= opt->lazy_list_cap, "batch too large for the lazy row list");
   ARG_CHECK(M->user_num < 2147483647LL && M->item_num < 2147483647LL, "row ids must fit 32 bits");
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_split_ids, dim3((unsigned)min((int64_t)256, (N + 255) / 256)), dim3(256), 0, st, X, N, ids);
-  HIP_TRY(hipGetLastError());
-  if (int e = dccf_lazy_catchup_rows(opt, ids, N, 0, ids + N, N, 1, stream)) return e;
+  // three launches: catch-up (+ loss = 0), forward / backward, optimizer
+  if (int e = dccf_lazy_catchup_pairs(opt, X, N, 0, 1, loss, (hipStream_t)stream)) return e;
   mf_grads_t g = *G;
   g.touchedP = g.touchedQ = nullptr;          // the step's rows are on the lazy list: no bytes to keep
-  if (int e = mf_train_fwdbwd(ctx, M, X, Y, N, rank, &g, prediction, loss, stream)) return e;
+  if (int e = mf_train_launch(M, X, Y, N, rank, &g, prediction, loss, stream, false)) return e;
   return dccf_lazy_opt_step(opt, 2 * N, stream);
 }
 

@@ -635,6 +635,26 @@ __global__ __launch_bounds__(256) void k_lazy_catchup_rows(float* __restrict__ p
   }
 }
 
+// the same for a batch of (user, item) pairs (the MF family's train step): the ids are read from X itself
+template <int KIND>
+__global__ __launch_bounds__(256) void k_lazy_catchup_pairs(float* __restrict__ p, float* __restrict__ s1, float* __restrict__ s2,
+                                                            OptArgs a, RowSegs sg, LazyArgs z, const int64_t* __restrict__ X,
+                                                            int64_t N, int seg_u, int seg_v, float* __restrict__ zero) {
+  if (zero && blockIdx.x == 0 && threadIdx.x == 0) *zero = 0.f;
+  const int lane = threadIdx.x & 63, grp = lane >> 4;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  int* claim = lazy_claim_of(z, (int)z.step);
+  int* list = lazy_list_of(z, (int)z.step);
+  const int64_t slots = 2 * N;
+  for (int64_t j0 = wave * 4; j0 < slots; j0 += nw * 4) {
+    const int64_t j = j0 + grp;
+    const bool live = j < slots;
+    const int64_t jc = live ? j : slots - 1;
+    if (jc < N) lazy_catchup_slot<KIND>(p, s1, s2, a, sg, z, claim, list, jc, seg_u, (int)X[2 * jc], lane, live);
+    else lazy_catchup_slot<KIND>(p, s1, s2, a, sg, z, claim, list, jc, seg_v, (int)X[2 * (jc - N) + 1], lane, live);
+  }
+}
+
 // The optimizer launch of step t.  Workgroups by role: [0, pn.blocks) the next step's preparation; then `lb` workgroups walk the
 // step's list (one wave per row: gradient read, step t applied, gradient zeroed, byte cleared); `db` workgroups take the dense
 // tail (W, b, ...: everything outside the row segments); the rest advance this step's window — the rows
@@ -896,6 +916,21 @@ extern "C" int dccf_lazy_catchup_rows(const dccf_opt_t* o, const int32_t* rows_a
   const int grid = (int)min((int64_t)2048, (slots + 3) / 4);
   BY_KIND(j.kind, k_lazy_catchup_rows, dim3(grid), dim3(256), 0, (hipStream_t)stream, j.p, j.s1, j.s2, j.a, j.sg, z, rows_a, n_a,
           (int)seg_a, rows_b, n_b, (int)seg_b);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int dccf_lazy_catchup_pairs(const void* ov, const int64_t* X, int64_t N, int seg_u, int seg_v, float* zero, hipStream_t st) {
+  const dccf_opt_t* o = (const dccf_opt_t*)ov;
+  ARG_CHECK(o != nullptr && X != nullptr && N >= 1, "NULL opt / X");
+  OptJob j;
+  if (int e = opt_job(o, &j)) return e;
+  LazyArgs z;
+  if (int e = lazy_args(o, j, &z)) return e;
+  ARG_CHECK(seg_u >= 0 && seg_u < j.sg.n && seg_v >= 0 && seg_v < j.sg.n, "bad segment index");
+  ARG_CHECK(2 * N <= z.list_cap, "lazy optimizer: the step's row list is too short (lazy_list_cap)");
+  const int grid = (int)min((int64_t)2048, (2 * N + 3) / 4);
+  BY_KIND(j.kind, k_lazy_catchup_pairs, dim3(grid), dim3(256), 0, st, j.p, j.s1, j.s2, j.a, j.sg, z, X, N, seg_u, seg_v, zero);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -275,7 +275,7 @@ int mf_train_fwdbwd(dccf_ctx* ctx, const mf_model_t* model, const int64_t* X, co
  * regularisation (opt->lazy_K > 0, opt's two row segments = P and Q of `model`): the batch's rows are claimed and caught up,
  * forward + loss + backward run, and one optimizer launch applies step opt->step to the batch's rows (with their gradient), to
  * everything outside the row segments (bias vectors, global bias: dense) and to this step's window of the other rows.
- * ids: scratch, int32 [2 N].  Results equal mf_train_fwdbwd + dccf_dense_opt_step_rows (untouched rows bit for bit). */
+ * ids: unused (may be NULL; kept for ABI 5).  Results equal mf_train_fwdbwd + dccf_dense_opt_step_rows (untouched rows bit for bit). */
 int mf_train_step(dccf_ctx* ctx, const mf_model_t* model, const int64_t* X, const float* Y, int64_t N, int32_t rank,
                   const mf_grads_t* grads, const dccf_opt_t* opt, int32_t* ids, float* prediction, float* loss, void* stream);
 /* "save the full predicted user-item matrix as the exposure probability" (README.md:28-30): out [user_num, item_num]. */
