@@ -15,6 +15,15 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+def free_port():
+    """A TCP port nobody listens on right now, chosen by the kernel (the rendezvous of a multi-process test).  Fixed ports in the
+    ephemeral range (32768+) collide now and then with the source port of some earlier connection of the same session."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False))
 

@@ -652,7 +652,8 @@ def test_sharded_trainer_with_hip_backend_world1(L, direct):
     from dccf_amd.sharded import ShardedDCCF, HipBackend
     from test_sharded_gloo import make_world, expo_from_ips, CFG, KEYS
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    os.environ.setdefault('MASTER_PORT', '29617')
+    from conftest import free_port
+    os.environ['MASTER_PORT'] = str(free_port())
     if not dist.is_initialized():
         dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev())
     try:

@@ -177,7 +177,8 @@ import pytest
 @pytest.mark.parametrize('overlap', [False, True])
 def test_replicated_step_equals_union_batch(tmp_path, overlap):
     world = 2
-    port = 31000 + os.getpid() % 2000 + (7 if overlap else 0)
+    from conftest import free_port
+    port = free_port()
     mp.spawn(worker, args=(world, port, str(tmp_path), overlap), nprocs=world, join=True)
     c = CFG
     P, feat, expo, X = make_world(c)

@@ -112,7 +112,8 @@ def test_replicated_trainer_world1_equals_single_gpu_step(overlap):
     import torch.distributed as dist
     from dccf_amd import replicated, _lib as L
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    os.environ.setdefault('MASTER_PORT', '29731')
+    from conftest import free_port
+    os.environ['MASTER_PORT'] = str(free_port())
     dev = torch.device('cuda', 0)
     if not dist.is_initialized():
         dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
@@ -220,7 +221,8 @@ def test_two_ranks_hip_backend_replicas_bit_identical(tmp_path, overlap, world, 
     batches accumulated into one gradient on one GPU, to the float-atomic tolerance."""
     import torch.multiprocessing as mp
     from dccf_amd import _lib as L
-    port = 33000 + os.getpid() % 2000 + {False: 0, True: 11, 'prep': 23}[overlap] + 7 * world + {'adam': 0, 'adagrad': 41, 'gd': 57}[opt_name] + 101 * n_layers + D
+    from conftest import free_port
+    port = free_port()
     mp.spawn(_rank_main, args=(world, port, str(tmp_path), overlap, opt_name, n_layers, D), nprocs=world, join=True)
     rs = [dict(np.load(os.path.join(str(tmp_path), 'r%d_%s.npz' % (r, str(overlap))))) for r in range(world)]
     r0 = rs[0]
@@ -306,7 +308,8 @@ def test_two_ranks_hip_backend_row_sharded_equals_union_batch(tmp_path, lazy_K):
     from oracle import dccf_oracle as O
     from oracle import philox as PH
     world = 2
-    port = 36000 + os.getpid() % 2000
+    from conftest import free_port
+    port = free_port()
     mp.spawn(_sharded_rank_main, args=(world, port, str(tmp_path), lazy_K), nprocs=world, join=True)
     c = dict(TS.CFG, steps=5)      # (five steps: the lazy window cycles at K = 2)
     K = TS.KEYS
@@ -389,7 +392,8 @@ def test_cli_on_two_ranks(tmp_path):
                         feat_dim=int(g['feat_dim']), seed=int(g['data_seed']))
     cfg = dict(lr=float(g['lr']), epochs=int(g['epochs']), test_neg_n=int(g['test_neg_n']), D=int(g['D']),
                batch_size=int(g['batch_size']))
-    port = 35000 + os.getpid() % 2000
+    from conftest import free_port
+    port = free_port()
     mp.spawn(_cli_rank_main, args=(2, port, tmp, cfg), nprocs=2, join=True)
     r0, r1 = (dict(np.load(os.path.join(tmp, 'cli%d.npz' % r))) for r in range(2))
     for k in r0:
@@ -427,7 +431,8 @@ def test_cli_on_two_ranks_extra_layers_adagrad(tmp_path):
     tmp = str(tmp_path)
     synth.write_dataset(os.path.join(tmp, 'dataset'), 'toy', 300, 200, 5000, feat_dim=32, seed=3)
     cfg = dict(lr=0.01, epochs=2, test_neg_n=50, D=16, batch_size=96, seeds=[7], optimizer='Adagrad', more=['--n_layers', '2'])
-    mp.spawn(_cli_rank_main, args=(2, 37000 + os.getpid() % 2000, tmp, cfg), nprocs=2, join=True)
+    from conftest import free_port
+    mp.spawn(_cli_rank_main, args=(2, free_port(), tmp, cfg), nprocs=2, join=True)
     r0, r1 = (dict(np.load(os.path.join(tmp, 'cli%d.npz' % r))) for r in range(2))
     for k in r0:
         assert np.array_equal(r0[k], r1[k], equal_nan=True), k

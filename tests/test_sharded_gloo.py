@@ -126,7 +126,8 @@ def worker(rank, world, port, out):
 
 def test_sharded_step_equals_union_batch(tmp_path):
     world = 2
-    port = 29000 + os.getpid() % 2000
+    from conftest import free_port
+    port = free_port()
     mp.spawn(worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     c = CFG
     P, feat, ips, X = make_world(c)
