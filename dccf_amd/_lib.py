@@ -10,7 +10,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libdccf_hip.so')
 
-EXPORTS = ['dccf_ctx_create', 'dccf_ctx_destroy', 'dccf_ctx_reserve', 'dccf_last_error', 'dccf_abi_version',
+EXPORTS = ['dccf_ctx_create', 'dccf_ctx_destroy', 'dccf_ctx_set_deterministic', 'dccf_ctx_reserve', 'dccf_last_error', 'dccf_abi_version',
            'dccf_predict', 'dccf_train_fwdbwd', 'dccf_dense_opt_step', 'dccf_sumsq', 'mf_predict', 'mf_train_fwdbwd', 'mf_train_step',
            'mf_predict_full', 'dccf_sample_train_negatives', 'dccf_debug_candidates', 'dccf_debug_noise',
            'dccf_debug_keep', 'dccf_debug_keep_layer', 'dccf_debug_opt_elem', 'dccf_debug_workspace', 'dccf_profile', 'dccf_profile_read',
@@ -20,7 +20,7 @@ EXPORTS = ['dccf_ctx_create', 'dccf_ctx_destroy', 'dccf_ctx_reserve', 'dccf_last
            'dccf_dp_finish', 'dccf_ctx_prepared_steps', 'dccf_ctx_hosted_rows', 'shard_pack_multi', 'shard_unpack_multi', 'dccf_build_epoch_batches', 'dccf_lazy_scalars', 'dccf_lazy_flush', 'dccf_lazy_catchup_rows', 'dccf_lazy_opt_step', 'dccf_comm_unique_id',
            'dccf_comm_create', 'dccf_comm_destroy', 'dccf_comm_all_to_all_rows', 'dccf_comm_all_to_all_rows2', 'dccf_comm_all_reduce_sum']
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 OPT_KIND = {'gd': 0, 'adagrad': 1, 'adam': 2}
 MF_KIND = {'RecModel': 0, 'BiasedMF': 1, 'IPSBiasedMF': 2}
 
@@ -53,7 +53,7 @@ class OptT(C.Structure):
                 ('seg_flags', _f),
                 # windowed lazy regularisation (include/dccf_hip.h: dccf_opt_t.lazy_*)
                 ('lazy_K', C.c_int32), ('lazy_nscal', C.c_int32), ('lazy_last', _f), ('lazy_claim', _f), ('lazy_list', _f),
-                ('lazy_cnt', _f), ('lazy_scal', _f), ('lazy_t0', C.c_int64), ('lazy_list_cap', C.c_int64), ('lazy_id', C.c_int64)]
+                ('lazy_cnt', _f), ('lazy_scal', _f), ('lazy_t0', C.c_int64), ('lazy_list_cap', C.c_int64), ('lazy_id', C.c_int64), ('lazy_host', _f)]
 
 
 class DpT(C.Structure):
@@ -105,6 +105,7 @@ def load():
     sig = {
         'dccf_ctx_create': [C.POINTER(vp), C.c_int],
         'dccf_ctx_destroy': [vp],
+        'dccf_ctx_set_deterministic': [vp, C.c_int],
         'dccf_ctx_reserve': [vp, i64, i32, i32, i32, i32],
         'dccf_profile': [vp, C.c_int],
         'dccf_profile_read': [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
@@ -209,6 +210,11 @@ class Context(object):
     def __init__(self, device=0):
         self.h = C.c_void_p()
         check(load().dccf_ctx_create(C.byref(self.h), int(device)))
+
+    def set_deterministic(self, on=True):
+        """Deterministic gradient scatter for tests (dccf_ctx_set_deterministic): no float atomics in the backward, so every form of
+        the training step gives the same bits."""
+        check(load().dccf_ctx_set_deterministic(self.h, 1 if on else 0))
 
     def reserve(self, max_rows, D, F, S, A):
         check(load().dccf_ctx_reserve(self.h, int(max_rows), int(D), int(F), int(S), int(A)))
@@ -399,6 +405,9 @@ class LazyState(object):
         self.scal = torch.zeros(4 * self.NSCAL, dtype=torch.float32, device=device)
         self.t0 = -1
         self.dirty = False          # True while some row may be behind opt.step
+        # the last step whose lazy optimizer launch went out (dccf_opt_t.lazy_host: the library checks that steps arrive one by one)
+        self.host = (C.c_int64 * 2)(0, 0)
+        opt.lazy_host = C.addressof(self.host)
         opt.lazy_K, opt.lazy_nscal = self.K, self.NSCAL
         opt.lazy_last, opt.lazy_claim = ptr(self.last, torch.int32), ptr(self.claim, torch.int32)
         opt.lazy_list, opt.lazy_cnt = ptr(self.list, torch.int32), ptr(self.cnt, torch.int32)
@@ -425,6 +434,7 @@ class LazyState(object):
     def sync_all(self, step):
         """Every row IS at `step` (dense steps ran, or nothing ran yet): reset the counters."""
         self.last.fill_(int(step))
+        self.host[0] = int(step)
         self.dirty = False
 
     def catchup_rows(self, step, rows, n, seg=0):
@@ -448,6 +458,13 @@ class LazyState(object):
         self.cover(step)
         check(load().dccf_lazy_flush(C.byref(self.opt), stream()))
         self.dirty = False
+        self.check_rows()
+
+    def check_rows(self):
+        """Raises if a kernel met a row more than K steps behind (lazy_cnt[15]: steps were skipped behind the library's back).
+        Synchronises; called after a flush, i.e. before evaluation / checkpoints, never inside the step loop."""
+        if int(self.cnt[15]) != 0:
+            raise RuntimeError('lazy optimizer: a parameter row was more than lazy_K steps behind — steps did not arrive one by one')
 
 
 def dccf_train_step(ctx, m, r, X, Y, rank, dropout, gU, gV, gW, gb, opt, step, pred=None, loss=None, touchedU=None,

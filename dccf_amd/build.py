@@ -28,19 +28,23 @@ def build(force=False, verbose=True):
     # -> the loader reuses the one torch already mapped) instead of /opt/rocm/lib/libamdhip64.so.7.
     import torch
     tlib = os.path.join(os.path.dirname(torch.__file__), 'lib')
-    objs = []
-    for src in SRCS:
+    # -ffp-contract=off: a*b+c written as two operations stays two roundings in EVERY kernel (explicit fmaf() calls are
+    # still FMAs).  The `#pragma clang fp contract(off)` in the sources says the same, but hipcc was seen to contract
+    # inside a template instantiated from a header anyway (k_dense_opt_rows: s2*b2 + (1-b2)*g*g became v_pk_fma_f32
+    # and the row-aware optimizer stopped matching the dense one bit for bit).
+    def compile_one(src):
         obj = os.path.join(os.path.dirname(LIB), os.path.basename(src).replace('.hip', '.o'))
-        # -ffp-contract=off: a*b+c written as two operations stays two roundings in EVERY kernel (explicit fmaf() calls are
-        # still FMAs).  The `#pragma clang fp contract(off)` in the sources says the same, but hipcc was seen to contract
-        # inside a template instantiated from a header anyway (k_dense_opt_rows: s2*b2 + (1-b2)*g*g became v_pk_fma_f32
-        # and the row-aware optimizer stopped matching the dense one bit for bit).
         c = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-result', '-ffp-contract=off',
              '-c', src, '-o', obj] + os.environ.get('DCCF_EXTRA_HIPCC_FLAGS', '').split()
         if verbose:
             print(' '.join(c))
         subprocess.check_call(c)
-        objs.append(obj)
+        return obj
+
+    # the translation units are independent: compile them side by side (the largest one, dccf_kernels.hip, takes ~95 s alone)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=max(1, min(len(SRCS), int(os.environ.get('DCCF_BUILD_JOBS', '0')) or (os.cpu_count() or 2) // 2))) as ex:
+        objs = list(ex.map(compile_one, SRCS))
     cmd = [os.environ.get('CXX', 'g++'), '-shared', '-o', LIB] + objs + \
           ['-L' + tlib, '-lamdhip64', '-ldl', '-Wl,-rpath,' + tlib, '-Wl,--no-undefined']
     if verbose:

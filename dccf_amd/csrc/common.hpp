@@ -6,7 +6,7 @@
 #include <string.h>
 #include "../../include/dccf_hip.h"
 
-#define DCCF_ABI_VERSION 5
+#define DCCF_ABI_VERSION 6
 #pragma clang fp contract(off)
 
 // ---------------------------------------------------------------------------------------------- errors
@@ -49,6 +49,12 @@ struct dccf_ctx {
   int prep_valid;
   float* gw_part;                // scratch of GwPart (grown on demand)
   size_t gw_part_bytes;
+  // deterministic mode (dccf_ctx_set_deterministic): per-slot gradient rows of the backward + "first slot of a row" table
+  int det;
+  float* det_buf;
+  size_t det_bytes;
+  int* det_owner;
+  int64_t det_owner_n;
   int64_t lazy_prep_step;        // optimizer step whose rows the last lazy optimizer launch claimed and caught up (-1: none)
   const void* lazy_prep_claim;   // ... in this claim array
   int64_t lazy_prep_id;          // ... of the arrays the caller named so (dccf_opt_t.lazy_id)

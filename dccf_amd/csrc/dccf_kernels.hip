@@ -578,6 +578,11 @@ struct BwdArgs {
   // beside it on every CU, and the pass needs HBM, not the VALU / MFMA pipe
   OptJob oj;
   int opt_rows_y;            // grid rows that host it (0: none)
+  // deterministic mode (dccf_ctx_set_deterministic; run-time-width instances only): no float atomics — the user gradient of
+  // batch row n goes to det_u[n], the item gradient of candidate slot (n, s) (A == 2; of row l otherwise) to det_v[slot], the
+  // by-product gb of wave w of row split x to det_gb[x * BWD_NW + w]; k_det_sum adds them per destination in slot order
+  float *det_u, *det_v, *det_gb;
+  int det_ld;                // floats per det_gb entry
 };
 
 // FOLD: what k_pair_epilogue would have stored for batch row n, recomputed by the wave that walks n (every role needs it;
@@ -809,13 +814,17 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
         const float dt = due[mt] + __shfl_xor(due[mt], 32, 64);
         if (h == 0 && dok[mt]) {
           if (!DH) {           // (n_layers > 1: the user gradient comes from the LAST layer's output, k_gu_last)
-            float* gu = (p.slot_where ? p.slot_rows : p.gU) + urow_g * Dr;
-            atomicAdd(&gu[dbase + mt * 32 + c31], dt);
+            if (GEN && p.det_u) {
+              p.det_u[n * Dr + dbase + mt * 32 + c31] = dt;
+            } else {
+              float* gu = (p.slot_where ? p.slot_rows : p.gU) + urow_g * Dr;
+              atomicAdd(&gu[dbase + mt * 32 + c31], dt);
+            }
           }
           gb_acc[mt] += tot[mt];
         }
       }
-      if (!DH && p.touchedU && lane == 0) p.touchedU[u] = 1;
+      if (!DH && p.touchedU && lane == 0 && !(GEN && p.det_u)) p.touchedU[u] = 1;
     }
   }
   KEEP(acc[0][0][0]);
@@ -890,7 +899,10 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
   if (CHUNK && role == 0 && h == 0) {
 #pragma unroll
     for (int mt = 0; mt < ND; ++mt)
-      if (dok[mt]) atomicAdd(&p.gb[dbase + mt * 32 + c31], gb_acc[mt]);
+      if (dok[mt]) {
+        if (GEN && p.det_gb) p.det_gb[((int64_t)blockIdx.x * BWD_NW + wave) * p.det_ld + dbase + mt * 32 + c31] = gb_acc[mt];
+        else atomicAdd(&p.gb[dbase + mt * 32 + c31], gb_acc[mt]);
+      }
   }
   if (FOLD && CHUNK && role == 0 && dbase == 0 && lane == 0 && lsum != 0.f) atomicAdd(p.loss, lsum);
   TRACEB(role, 2);
@@ -949,6 +961,7 @@ __device__ __forceinline__ void bwd_dx_role(const BwdArgs& p, int dbase) {
           const int ro = min(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, rpn - 1);
           const int ci = p.cand[n * S1 + (ro >> 1)];
           sl8[r2] = p.slot_where ? (int)min((unsigned)p.slot_where[p.slot_offV + ci], (unsigned)(p.slot_cap - 1)) : ci;
+          if (GEN && p.det_v) sl8[r2] = (int)(n * S1 + (ro >> 1));
         }
       }
       f32x16 acc[ND];
@@ -988,9 +1001,13 @@ __device__ __forceinline__ void bwd_dx_role(const BwdArgs& p, int dbase) {
             const int ro = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (ro < rpn && dd < Dr) {
               const int64_t ci = sl8[r >> 1];
-              float* gv = (p.slot_where ? p.slot_rows : p.gV) + ci * Dr;
-              atomicAdd(&gv[dd], acc[nt][r] + acc[nt][r + 1]);
-              if (p.touchedV && c31 == 0 && nt == 0) p.touchedV[ci] = 1;
+              if (GEN && p.det_v) {
+                p.det_v[ci * Dr + dd] = acc[nt][r] + acc[nt][r + 1];
+              } else {
+                float* gv = (p.slot_where ? p.slot_rows : p.gV) + ci * Dr;
+                atomicAdd(&gv[dd], acc[nt][r] + acc[nt][r + 1]);
+                if (p.touchedV && c31 == 0 && nt == 0) p.touchedV[ci] = 1;
+              }
             }
           }
         } else {
@@ -999,9 +1016,13 @@ __device__ __forceinline__ void bwd_dx_role(const BwdArgs& p, int dbase) {
             const int ro = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (ro < rpn && dd < Dr) {
               const int64_t ci = p.cand[n * S1 + ro / A];
-              float* gv = p.slot_where ? p.slot_rows + (int64_t)min((unsigned)p.slot_where[p.slot_offV + ci], (unsigned)(p.slot_cap - 1)) * Dr : p.gV + ci * Dr;
-              atomicAdd(&gv[dd], acc[nt][r]);
-              if (p.touchedV && c31 == 0 && nt == 0) p.touchedV[ci] = 1;
+              if (GEN && p.det_v) {
+                p.det_v[(n * rpn + ro) * Dr + dd] = acc[nt][r];
+              } else {
+                float* gv = p.slot_where ? p.slot_rows + (int64_t)min((unsigned)p.slot_where[p.slot_offV + ci], (unsigned)(p.slot_cap - 1)) * Dr : p.gV + ci * Dr;
+                atomicAdd(&gv[dd], acc[nt][r]);
+                if (p.touchedV && c31 == 0 && nt == 0) p.touchedV[ci] = 1;
+              }
             }
           }
         }
@@ -1060,6 +1081,7 @@ struct MlpArgs {
   float* gb;                 // backward: [Dr] (+=)
   int64_t L;
   int rpn, A, Dr, DP, layer, last, fused;
+  int det;                   // backward, deterministic mode: ONE workgroup, its waves add gW_k / gb_k one after the other
   uint32_t drop_thr;
   float kscale;
   rng_key dkey;
@@ -1227,6 +1249,24 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpArgs p) {
       }
     }
   }
+  gbacc += __shfl_xor(gbacc, 32, 64);
+  if (p.det) {               // deterministic mode (ONE workgroup): the waves add one after the other, plain read-modify-write
+    for (int w = 0; w < 4; ++w) {
+      if (wave == w) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int mrow = cm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, n = nt * 32 + c31;
+            if (mrow < Dr && n < Dr) p.gW[(int64_t)mrow * Dr + n] = __fadd_rn(p.gW[(int64_t)mrow * Dr + n], accW[nt][r]);
+          }
+        if (h == 0 && cm * 32 + c31 < Dr) p.gb[cm * 32 + c31] = __fadd_rn(p.gb[cm * 32 + c31], gbacc);
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+    return;
+  }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -1234,7 +1274,6 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpArgs p) {
       const int mrow = cm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, n = nt * 32 + c31;
       if (mrow < Dr && n < Dr && accW[nt][r] != 0.f) atomicAdd(&p.gW[(int64_t)mrow * Dr + n], accW[nt][r]);
     }
-  gbacc += __shfl_xor(gbacc, 32, 64);
   if (h == 0 && cm * 32 + c31 < Dr && gbacc != 0.f) atomicAdd(&p.gb[cm * 32 + c31], gbacc);
 }
 
@@ -1243,7 +1282,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpArgs p) {
 __global__ __launch_bounds__(256) void k_gu_last(const float* __restrict__ hlast, const float* __restrict__ dmns, const int64_t* X,
                                                  float* gU, uint8_t* touchedU, int64_t N, int S1, int A, int Dr, int DP,
                                                  const int* slot_where, float* slot_rows, int64_t slot_offU, int slot_cap,
-                                                 StepRef sr) {
+                                                 StepRef sr, float* det_u) {
   X = step_X(sr, X, step_k(sr));
   const int lane = threadIdx.x & 63;
   const int64_t w0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -1257,10 +1296,99 @@ __global__ __launch_bounds__(256) void k_gu_last(const float* __restrict__ hlast
       if (lane + 64 < Dr) a1 = fmaf(dm, hr[lane + 64], a1);
     }
     const int64_t u = X[2 * n];
+    if (det_u) {               // deterministic mode: the row of batch row n, summed per user by k_det_sum
+      if (lane < Dr) det_u[n * Dr + lane] = a0;
+      if (lane + 64 < Dr) det_u[n * Dr + lane + 64] = a1;
+      continue;
+    }
     float* g = slot_where ? slot_rows + (int64_t)min((unsigned)slot_where[slot_offU + u], (unsigned)(slot_cap - 1)) * Dr : gU + u * Dr;
     if (lane < Dr) atomicAdd(&g[lane], a0);
     if (lane + 64 < Dr) atomicAdd(&g[lane + 64], a1);
     if (touchedU && lane == 0) touchedU[u] = 1;
+  }
+}
+
+// ================================================================================================ deterministic scatter
+// dccf_ctx_set_deterministic (tests; SURVEY.md section 7 "offer a sorted-segment deterministic mode"): float atomics add a row's
+// contributions in arrival order, so two runs of the same step differ in the last bits of a gradient row — which Adam turns into
+// fractions of lr.  In this mode the backward stores one row per SLOT (user slot n; item slot (n, s), or row l when A != 2) and
+// two small launches add the slots of a destination row in ascending slot order: k_det_owner finds the first slot of every
+// destination (atomicMin: an integer minimum does not depend on arrival order) and sets the "touched" bytes, k_det_sum lets the
+// wave of that first slot walk the later slots.  Its last workgroups add the backward's per-wave gb partial sums and per-split dW
+// partial sums in index order.  O(slots^2 / 64) id compares: a test mode, not a fast one.
+struct DetArgs {
+  const int64_t* X;
+  const int* cand;
+  int64_t N, NV, user_num;   // user slots, item slots; destination id = u, or user_num + item
+  int S1, A, Dr;
+  const float *det_u, *det_v;
+  float *gU, *gV;
+  uint8_t *touchedU, *touchedV;
+  int* owner;                // [user_num + item_num], INT_MAX between calls
+  // by-products
+  const float* det_gb; int n_gb, det_ld; float* gb;        // gb[c] += sum over the n_gb entries, c < Dr
+  const float* gw_part; int nsplit; int64_t gw_stride; float* gW;      // gW[i] += sum over the splits, i < gw_stride
+  StepRef sr;
+};
+__device__ __forceinline__ int64_t det_dest(const DetArgs& p, int64_t j) {
+  if (j < p.N) return p.X[2 * j];
+  const int64_t jv = j - p.N;
+  return p.user_num + p.cand[p.A == 2 ? jv : jv / p.A];
+}
+__global__ __launch_bounds__(256) void k_det_owner(DetArgs p) {
+  p.X = step_X(p.sr, p.X, step_k(p.sr));
+  const int64_t slots = p.N + p.NV;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < slots; j += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t d = det_dest(p, j);
+    atomicMin(&p.owner[d], (int)j);
+    if (j < p.N) { if (p.touchedU) p.touchedU[d] = 1; }
+    else if (p.touchedV) p.touchedV[d - p.user_num] = 1;
+  }
+}
+__global__ __launch_bounds__(256) void k_det_sum(DetArgs p, int row_blocks) {
+  p.X = step_X(p.sr, p.X, step_k(p.sr));
+  const int lane = threadIdx.x & 63;
+  if ((int)blockIdx.x >= row_blocks) {          // ---- by-products, one thread per element, sources in index order
+    const int64_t tid = (int64_t)(blockIdx.x - row_blocks) * blockDim.x + threadIdx.x, nt = (int64_t)(gridDim.x - row_blocks) * blockDim.x;
+    if (p.det_gb)
+      for (int64_t c = tid; c < p.Dr; c += nt) {
+        float v = p.gb[c];
+        for (int e = 0; e < p.n_gb; ++e) v = __fadd_rn(v, p.det_gb[(int64_t)e * p.det_ld + c]);
+        p.gb[c] = v;
+      }
+    if (p.gw_part)
+      for (int64_t i = tid; i < p.gw_stride; i += nt) {
+        float v = p.gW[i];
+        for (int r = 0; r < p.nsplit; ++r) v = __fadd_rn(v, p.gw_part[(int64_t)r * p.gw_stride + i]);
+        p.gW[i] = v;
+      }
+    return;
+  }
+  const int64_t slots = p.N + p.NV;
+  const int64_t w0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)row_blocks * blockDim.x) >> 6;
+  for (int64_t j = w0; j < slots; j += nw) {
+    const int64_t d = det_dest(p, j);
+    if (p.owner[d] != (int)j) continue;         // (wave-uniform)
+    const bool user = j < p.N;
+    const int64_t end = user ? p.N : slots;
+    float* g = user ? p.gU + d * p.Dr : p.gV + (d - p.user_num) * p.Dr;
+    const float* src = user ? p.det_u : p.det_v;
+    const int64_t sbase = user ? 0 : p.N;                           // row of slot j' = src + (j' - sbase) * Dr
+    float a0 = lane < p.Dr ? g[lane] : 0.f, a1 = lane + 64 < p.Dr ? g[lane + 64] : 0.f;
+    for (int64_t j0 = j; j0 < end; j0 += 64) {
+      const int64_t jj = j0 + lane;
+      uint64_t bits = __ballot(jj < end && det_dest(p, jj < end ? jj : j) == d);
+      while (bits) {
+        const int b = __ffsll((unsigned long long)bits) - 1;
+        bits &= bits - 1;
+        const float* r = src + (j0 + b - sbase) * p.Dr;
+        if (lane < p.Dr) a0 = __fadd_rn(a0, r[lane]);
+        if (lane + 64 < p.Dr) a1 = __fadd_rn(a1, r[lane + 64]);
+      }
+    }
+    if (lane < p.Dr) g[lane] = a0;
+    if (lane + 64 < p.Dr) g[lane + 64] = a1;
+    if (lane == 0) p.owner[d] = 0x7fffffff;     // (non-owners compare against their own slot index: either value differs from it)
   }
 }
 
@@ -1519,11 +1647,15 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     prof_end(ctx, 1, st);
   }
   // training with at most 16 candidates per row: the pair epilogue is folded into the backward (wave_dm)
-  const bool fold = train && NX == 0 && D == y.DT && S1 <= 16 && A <= 4 && N <= knobs().fold_max_n;
+  // deterministic mode (dccf_ctx_set_deterministic): no float atomics anywhere in the backward — run-time-width instances, the
+  // pair epilogue as its own launch (one workgroup: its loss sum then has one order), per-slot gradient rows + k_det_sum
+  const bool det = ctx->det && train && !ctx->slot_where;
+  ARG_CHECK(!det || N * (int64_t)(S1 * A + 1) < 2139062143LL, "deterministic mode: too many slots");
+  const bool fold = train && NX == 0 && D == y.DT && S1 <= 16 && A <= 4 && N <= knobs().fold_max_n && !det;
   if (!fold) {
     const int64_t units = (train && rank == 1) ? N / 2 : N;
     const int GS = S1 <= 16 ? 16 : (S1 <= 32 ? 32 : 64);
-    const int grid = (int)min((int64_t)2048, (units * GS + 255) / 256);
+    const int grid = det ? 1 : (int)min((int64_t)2048, (units * GS + 255) / 256);
     prof_begin(ctx, st);
 #define LAUNCH_PE(GS_)                                                                                              \
   hipLaunchKernelGGL((k_pair_epilogue<GS_>), dim3(grid), dim3(256), 0, st, S1, A, Y, m, dmns, pred, loss, N, rank, \
@@ -1555,19 +1687,44 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     hipLaunchKernelGGL((k_bwd<D_, MODE_, FOLD_, DH_, GEN_>), grid, dim3(64 * BWD_NW), smem, st, ba);                 \
   }
 #define LAUNCH_BWD2(D_, MODE_)                                                                                       \
-  if (D != D_) { if (NX > 0) LAUNCH_BWD3(D_, MODE_, false, true, true) else LAUNCH_BWD3(D_, MODE_, false, false, true) } \
+  if (D != D_ || det) { if (NX > 0) LAUNCH_BWD3(D_, MODE_, false, true, true) else LAUNCH_BWD3(D_, MODE_, false, false, true) } \
   else if (NX > 0) LAUNCH_BWD3(D_, MODE_, false, true, false)                                                       \
   else if (fold) LAUNCH_BWD3(D_, MODE_, true, false, false)                                                         \
   else LAUNCH_BWD3(D_, MODE_, false, false, false)
 #define LAUNCH_BWD(D_) if (fused) LAUNCH_BWD2(D_, 0) else LAUNCH_BWD2(D_, 1)
     BwdArgs ba;
     ba.dh = nullptr;
+    ba.det_u = ba.det_v = ba.det_gb = nullptr;
+    ba.det_ld = y.DP * y.GY > 64 ? 128 : 64;
+    const int64_t det_nv = A == 2 ? y.NS : y.L;            // item slots of the deterministic mode
+    const int64_t gx_det = max((int64_t)1, min((N + BWD_NW - 1) / BWD_NW, (int64_t)max(1, (N >= 2048 ? 1024 : (int)knobs().bwd_wgs) / ((y.NC + 2) * y.GY))));
+    if (det) {
+      const size_t need = ((size_t)(N + det_nv) * D + (size_t)gx_det * BWD_NW * ba.det_ld) * sizeof(float);
+      if (need > ctx->det_bytes) {
+        if (ctx->det_buf) HIP_TRY(hipFree(ctx->det_buf));
+        ctx->det_buf = nullptr; ctx->det_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&ctx->det_buf, need));
+        ctx->det_bytes = need;
+      }
+      const int64_t rows = M->user_num + M->item_num;
+      if (rows > ctx->det_owner_n) {
+        if (ctx->det_owner) HIP_TRY(hipFree(ctx->det_owner));
+        ctx->det_owner = nullptr; ctx->det_owner_n = 0;
+        HIP_TRY(hipMalloc((void**)&ctx->det_owner, (size_t)rows * sizeof(int)));
+        HIP_TRY(hipMemsetAsync(ctx->det_owner, 0x7f, (size_t)rows * sizeof(int), st));
+        ctx->det_owner_n = rows;
+      }
+      ba.det_u = ctx->det_buf;
+      ba.det_v = ba.det_u + (size_t)N * D;
+      ba.det_gb = ba.det_v + (size_t)det_nv * D;
+    }
     if (NX > 0) {
       prof_begin(ctx, st);
       // the extra layers, last to first: gW_k, gb_k and dh_{k-1}; then the user gradient from the last layer's output
       float* dhA = (float*)(ws + y.dh);
       float* dhB = (float*)(ws + y.dh + hstride);
-      const int bgrid = (int)max((int64_t)1, min((int64_t)512, (ntiles + 3) / 4));
+      const int bgrid = det ? 1 : (int)max((int64_t)1, min((int64_t)512, (ntiles + 3) / 4));
+      ma.det = det ? 1 : 0;
       for (int k = NX; k >= 1; --k) {
         ma.hin = k == 1 ? hbuf : (const float*)(ws + y.hx + (size_t)(k - 2) * hstride);
         ma.hout = (float*)(ws + y.hx + (size_t)(k - 1) * hstride);
@@ -1583,7 +1740,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
       ba.dh = ma.dhout;
       hipLaunchKernelGGL(k_gu_last, dim3((unsigned)min((int64_t)1024, (N + 3) / 4)), dim3(256), 0, st,
                          (const float*)(ws + y.hx + (size_t)(NX - 1) * hstride), (const float*)dmns, X, G->gU, G->touchedU, N, S1, A,
-                         D, y.DP, ctx->slot_where, ctx->slot_rows, ctx->slot_offU, ctx->slot_cap, sr);
+                         D, y.DP, ctx->slot_where, ctx->slot_rows, ctx->slot_offU, ctx->slot_cap, sr, ba.det_u);
       prof_end(ctx, 4, st);
     }
     ba.W = M->W; ba.U = M->U; ba.V = M->V; ba.feat = M->feat; ba.X = X; ba.cand = cand; ba.dmns = dmns; ba.hbuf = hbuf;
@@ -1598,8 +1755,8 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     ba.gw_part = nullptr;
     ba.gw_stride = (int64_t)D * (D + F);
     gw_splits = 0;
-    if (lazy && knobs().gw_part && N < 2048 && !ctx->slot_where && plan->opt->p <= M->W &&
-        M->W + (int64_t)D * (D + F) <= plan->opt->p + plan->opt->n && G->gW == plan->opt->g + (M->W - plan->opt->p)) {
+    if (det || (lazy && knobs().gw_part && N < 2048 && !ctx->slot_where && plan->opt->p <= M->W &&
+        M->W + (int64_t)D * (D + F) <= plan->opt->p + plan->opt->n && G->gW == plan->opt->g + (M->W - plan->opt->p))) {
       const size_t need = (size_t)gx * (size_t)ba.gw_stride * sizeof(float);
       if (need > ctx->gw_part_bytes) {
         if (ctx->gw_part) HIP_TRY(hipFree(ctx->gw_part));
@@ -1635,6 +1792,22 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
 #undef LAUNCH_BWD
 #undef LAUNCH_BWD2
 #undef LAUNCH_BWD3
+    if (det) {               // per-slot rows -> gU / gV in slot order; gb and dW partial sums in index order
+      ARG_CHECK(gx == gx_det, "deterministic mode: row splits");
+      DetArgs da;
+      memset(&da, 0, sizeof(da));
+      da.X = X; da.cand = cand; da.N = N; da.NV = det_nv; da.user_num = M->user_num; da.S1 = S1; da.A = A; da.Dr = D;
+      da.det_u = ba.det_u; da.det_v = ba.det_v; da.gU = G->gU; da.gV = G->gV;
+      da.touchedU = G->touchedU; da.touchedV = G->touchedV; da.owner = ctx->det_owner;
+      da.det_gb = ba.det_gb; da.n_gb = (int)gx * BWD_NW; da.det_ld = ba.det_ld; da.gb = G->gb;
+      da.gw_part = ctx->gw_part; da.nsplit = gw_splits; da.gw_stride = ba.gw_stride; da.gW = G->gW;
+      da.sr = sr;
+      const int64_t slots = N + det_nv;
+      hipLaunchKernelGGL(k_det_owner, dim3((unsigned)min((int64_t)1024, (slots + 255) / 256)), dim3(256), 0, st, da);
+      const int row_blocks = (int)min((int64_t)2048, (slots + 3) / 4);
+      hipLaunchKernelGGL(k_det_sum, dim3((unsigned)(row_blocks + 64)), dim3(256), 0, st, da, row_blocks);
+      gw_splits = 0;         // (dW is in gW already: the optimizer launch must not add the partial sums again)
+    }
     prof_end(ctx, 5, st);
   }
   HIP_TRY(hipGetLastError());

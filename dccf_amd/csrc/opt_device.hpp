@@ -239,6 +239,18 @@ __device__ __forceinline__ int lazy_eff_last(const LazyArgs& z, const LazyPend& 
   return (grow >= q.w0 && grow < q.w1 && f < q.t) ? q.t : f;
 }
 
+// lazy_eff_last with the invariant enforced: no row is more than K steps behind the step being launched.  A row that is
+// (a caller skipped a step number, or cleared `last` behind the library's back) is replayed from t - K only — never an index in
+// front of the step-scalar table — and the error flag z.cnt[15] is raised for the next flush / check to report.
+__device__ __forceinline__ int lazy_from(const LazyArgs& z, const LazyPend& q, int64_t grow, int t) {
+  const int f = lazy_eff_last(z, q, grow);
+  if (f < t - z.K) {
+    z.cnt[15] = 1;
+    return t - z.K;
+  }
+  return f;
+}
+
 // `steps` optimizer steps with a zero loss gradient on one element, starting after step `from`: exactly what the dense pass
 // would have done to it launch by launch
 template <int KIND>
@@ -310,7 +322,7 @@ __device__ __forceinline__ void lazy_window_pass(float* __restrict__ p, float* _
       const int64_t xc = live ? x : nslot - 1;
       const int64_t row = r0 + xc / w4;
       const int64_t grow = z.row_off[q] + row;
-      const int from = lazy_eff_last(z, pend, grow);
+      const int from = lazy_from(z, pend, grow, t);
       // a row this step touched is the list's business (its last is t - 1 until that wave has updated it: never replay it here)
       const bool need = live && from < t && (flush || claim[grow] != t);
       const int fr = need ? from : t;

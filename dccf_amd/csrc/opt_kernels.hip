@@ -52,7 +52,18 @@ extern "C" int dccf_ctx_create(dccf_ctx** out, int device) {
   c->hv_parity = c->hv_prepared = 0;
   c->cur_Xall = nullptr;
   c->prep_Xall = nullptr;
+  c->det = (getenv("DCCF_DETERMINISTIC") && atoi(getenv("DCCF_DETERMINISTIC")) != 0) ? 1 : 0;
+  c->det_buf = nullptr;
+  c->det_bytes = 0;
+  c->det_owner = nullptr;
+  c->det_owner_n = 0;
   *out = c;
+  return 0;
+}
+
+extern "C" int dccf_ctx_set_deterministic(dccf_ctx* ctx, int on) {
+  ARG_CHECK(ctx != nullptr, "ctx is NULL");
+  ctx->det = on ? 1 : 0;
   return 0;
 }
 
@@ -93,6 +104,10 @@ extern "C" int dccf_ctx_destroy(dccf_ctx* ctx) {
     delete[] ctx->ev_slot;
   }
   if (ctx->gw_part) (void)hipFree(ctx->gw_part);
+  if (ctx->det_buf) (void)hipFree(ctx->det_buf);
+  if (ctx->det_owner) (void)hipFree(ctx->det_owner);
+  for (int q = 0; q < 2; ++q)
+    if (ctx->hv_flags[q]) (void)hipFree(ctx->hv_flags[q]);
   if (ctx->side) (void)hipStreamDestroy(ctx->side);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
@@ -579,7 +594,7 @@ __device__ __forceinline__ void lazy_catchup_slot(float* __restrict__ p, float* 
   won = __shfl(won, lane & 48, 64);
   if (!won) return;
   const LazyPend pend = lazy_pend_read(z);
-  const int from = lazy_eff_last(z, pend, grow);
+  const int from = lazy_from(z, pend, grow, t);
   if (from >= t - 1) return;
   const int w4 = sg.width[q] >> 2;
   const int64_t b4 = (sg.begin[q] + row * sg.width[q]) >> 2;
@@ -729,7 +744,7 @@ __global__ __launch_bounds__(256) void k_lazy_opt(float* __restrict__ p, float* 
       won = __shfl(won, lane & 48, 64);
       // not mine: lost the row to another slot; on this step's list (that role brings it to t); in this step's window (ditto)
       if (!won || claim_t[grow] == t || (grow >= win0 && grow < win1)) continue;
-      const int from = lazy_eff_last(z, pend, grow);
+      const int from = lazy_from(z, pend, grow, t);
       if (from >= t) continue;
       const int w4 = sg.width[q] >> 2;
       const int64_t b4 = (sg.begin[q] + row * sg.width[q]) >> 2;
@@ -840,7 +855,17 @@ __global__ __launch_bounds__(256) void k_lazy_mark(LazyArgs z, int64_t win0, int
   if (blockIdx.x == 0 && threadIdx.x < 10) z.cnt[threadIdx.x] = threadIdx.x % 5 == 0 ? -1 : 0;      // nothing is pending after a flush
 }
 
-static int lazy_args(const dccf_opt_t* o, const OptJob& j, LazyArgs* z) {
+// The lazy arrays are only consistent if the steps arrive one by one: no row may be more than lazy_K steps behind (the replay
+// tables and the window schedule assume it).  lazy_host[0] (HOST, the caller's; optional) holds the last step whose optimizer
+// launch went out: a launch that belongs to step s (LZ_PRE: before it, LZ_STEP: its optimizer launch) needs s == last + 1, a
+// flush s == last; anything else is an argument error instead of a silent skip / an out-of-table read.
+enum { LZ_ANY = 0, LZ_PRE = 1, LZ_STEP = 2, LZ_FLUSH = 3 };
+static int lazy_args(const dccf_opt_t* o, const OptJob& j, LazyArgs* z, int mode = LZ_ANY) {
+  if (o->lazy_host && mode != LZ_ANY) {
+    const int64_t last = o->lazy_host[0];
+    if (mode == LZ_FLUSH) ARG_CHECK(o->step == last, "lazy optimizer: a flush must name the last step that was launched (opt->step == lazy_host[0])");
+    else ARG_CHECK(o->step == last + 1, "lazy optimizer: steps must arrive one by one (opt->step == lazy_host[0] + 1)");
+  }
   ARG_CHECK(o->lazy_K >= 2 && o->lazy_K <= LAZY_KMAX && o->lazy_last && o->lazy_claim && o->lazy_list && o->lazy_cnt && o->lazy_list_cap > 0,
             "lazy optimizer: lazy_K >= 2 and all arrays");
   ARG_CHECK(j.sg.n >= 1, "lazy optimizer needs row segments");
@@ -891,7 +916,7 @@ int dccf_lazy_catchup(const void* ov, const int64_t* X, const int* cand, int64_t
   OptJob j;
   if (int e = opt_job(ov, &j)) return e;
   LazyArgs z;
-  if (int e = lazy_args(o, j, &z)) return e;
+  if (int e = lazy_args(o, j, &z, LZ_PRE)) return e;
   ARG_CHECK(segU >= 0 && segU < j.sg.n && segV >= 0 && segV < j.sg.n, "bad segment index");
   const int64_t slots = N * S1 + N;
   if (slots == 0) return 0;
@@ -908,7 +933,7 @@ extern "C" int dccf_lazy_catchup_rows(const dccf_opt_t* o, const int32_t* rows_a
   OptJob j;
   if (int e = opt_job(o, &j)) return e;
   LazyArgs z;
-  if (int e = lazy_args(o, j, &z)) return e;
+  if (int e = lazy_args(o, j, &z, LZ_PRE)) return e;
   ARG_CHECK((n_a == 0 || (seg_a >= 0 && seg_a < j.sg.n)) && (n_b == 0 || (seg_b >= 0 && seg_b < j.sg.n)), "bad segment index");
   const int64_t slots = n_a + n_b;
   if (slots == 0) return 0;
@@ -926,7 +951,7 @@ int dccf_lazy_catchup_pairs(const void* ov, const int64_t* X, int64_t N, int seg
   OptJob j;
   if (int e = opt_job(o, &j)) return e;
   LazyArgs z;
-  if (int e = lazy_args(o, j, &z)) return e;
+  if (int e = lazy_args(o, j, &z, LZ_PRE)) return e;
   ARG_CHECK(seg_u >= 0 && seg_u < j.sg.n && seg_v >= 0 && seg_v < j.sg.n, "bad segment index");
   ARG_CHECK(2 * N <= z.list_cap, "lazy optimizer: the step's row list is too short (lazy_list_cap)");
   const int grid = (int)min((int64_t)2048, (2 * N + 3) / 4);
@@ -939,7 +964,7 @@ static int lazy_launch(const dccf_opt_t* o, int flush, const PrepNext* pnp, int6
   OptJob j;
   if (int e = opt_job(o, &j)) return e;
   LazyArgs z;
-  if (int e = lazy_args(o, j, &z)) return e;
+  if (int e = lazy_args(o, j, &z, flush ? LZ_FLUSH : LZ_STEP)) return e;
   DenseSegs ds;
   int64_t dense_total = 0;
   if (int e = dense_complement(j.sg, j.n, &ds, &dense_total)) return e;
@@ -969,6 +994,7 @@ static int lazy_launch(const dccf_opt_t* o, int flush, const PrepNext* pnp, int6
     hipLaunchKernelGGL(k_lazy_mark, dim3((unsigned)max((int64_t)1, min((int64_t)1024, (win1 - win0 + 255) / 256))), dim3(256), 0, st, z,
                        win0, win1, flush);
   HIP_TRY(hipGetLastError());
+  if (!flush && o->lazy_host) o->lazy_host[0] = o->step;
   return 0;
 }
 
@@ -1003,7 +1029,7 @@ __global__ __launch_bounds__(256) void k_lazy_catchup_flags(float* __restrict__ 
         const int b = __ffsll((unsigned long long)bits) - 1;
         bits &= bits - 1;
         const int64_t row = r0 + b, grow = z.row_off[q] + row;
-        const int from = __builtin_amdgcn_readfirstlane(lazy_eff_last(z, pend, grow));
+        const int from = __builtin_amdgcn_readfirstlane(lazy_from(z, pend, grow, t));
         if (lane == 0) lazy_claim_of(z, t)[grow] = t;
         if (from >= t - 1) continue;
         float* pr = p + sg.begin[q] + row * w;
@@ -1027,7 +1053,7 @@ int dccf_lazy_catchup_flags(const void* ov, const uint8_t* flags0, const uint8_t
   OptJob j;
   if (int e = opt_job(ov, &j)) return e;
   LazyArgs z;
-  if (int e = lazy_args(o, j, &z)) return e;
+  if (int e = lazy_args(o, j, &z, LZ_PRE)) return e;
   ARG_CHECK(flags0 && flags1 && seg0 >= 0 && seg0 < j.sg.n && seg1 >= 0 && seg1 < j.sg.n, "bad flags / segments");
   const int64_t rows = max(z.rows[seg0], z.rows[seg1]);
   const int grid = (int)max((int64_t)1, min((int64_t)2048, (rows + 255) / 256));
@@ -1043,7 +1069,7 @@ int dccf_lazy_phase1(const void* ov, const PrepNext* pnp, hipStream_t st) {
   OptJob j;
   if (int e = opt_job(o, &j)) return e;
   LazyArgs z;
-  if (int e = lazy_args(o, j, &z)) return e;
+  if (int e = lazy_args(o, j, &z, LZ_STEP)) return e;
   DenseSegs ds;
   memset(&ds, 0, sizeof(ds));
   const int64_t R = z.row_off[3] + z.rows[3];
@@ -1061,6 +1087,7 @@ int dccf_lazy_phase1(const void* ov, const PrepNext* pnp, hipStream_t st) {
   BY_KIND(j.kind, k_lazy_opt, dim3(pn.blocks + pn.cu_blocks + wb + mb), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.a, j.sg, ds, z, 0, 0, mb, win0, win1,
           0, 0, pn, gp);
   HIP_TRY(hipGetLastError());
+  if (o->lazy_host) o->lazy_host[0] = o->step;
   return 0;
 }
 

@@ -54,7 +54,7 @@ class FusedOptimizer(object):
         self.flush()
         self.t += 1
         if self.lazy is not None:
-            self.lazy.last.fill_(self.t)       # the dense pass below brings every row to t
+            self.lazy.sync_all(self.t)         # the dense pass below brings every row to t
         m = self.model
         segs = getattr(m, 'row_segments', None)
         if segs:     # g of rows the backward did not touch is zero by construction: not read, not re-zeroed
@@ -340,8 +340,8 @@ class RecModel(BaseModel):
             self._mf_ids = torch.empty(2 * 8192, dtype=torch.int32, device=self.device)
             self._mf_loss = torch.zeros(1, dtype=torch.float32, device=self.device)
             self._mf_opt_key = key
-        o.t += 1
-        o.lazy.cover(o.t)
+        t1 = o.t + 1                 # (the counter moves only once the library took the step: a raise leaves no phantom step)
+        o.lazy.cover(t1)
         o.lazy.dirty = True
         g = self.grads
         bias = self.kind != 'RecModel'
@@ -349,8 +349,9 @@ class RecModel(BaseModel):
                                         g['uid_embeddings.weight'], g['iid_embeddings.weight'],
                                         g['user_bias.weight'].view(-1) if bias else None,
                                         g['item_bias.weight'].view(-1) if bias else None,
-                                        g['global_bias'].view(-1) if bias else None, self._mf_opt, o.t, self._mf_ids,
+                                        g['global_bias'].view(-1) if bias else None, self._mf_opt, t1, self._mf_ids,
                                         loss=self._mf_loss)
+        o.t = t1
         return {'prediction': pred, 'check': [], 'loss': loss[0]}
 
     def full_matrix(self):
@@ -580,18 +581,19 @@ class DCCF(DMF):
             o.lazy = None
             # (at 2B > 2048 the step touches tens of thousands of rows and the dense pass is a small part of it: measured 5.05 M
             # pairs/s lazy against 5.3 M dense at B = 4096 — the dense pass stays there)
-            if (self.lazy_K >= 2 and not overlap and self.row_segments and feed_dict.get('inject') is None
+            # (injected draws — the parity tests' golden cases — take the same lazy path as the fused ones)
+            if (self.lazy_K >= 2 and not overlap and self.row_segments
                     and feed_dict['X'].shape[0] <= int(os.environ.get('DCCF_LAZY_MAX_N', '2048'))):
                 # windowed lazy regularisation: only 1 / lazy_K of the untouched rows is streamed per step (dccf_opt_t.lazy_*)
                 rows = self.user_num + self.item_num
                 o.lazy = _lib.LazyState(self._opt_struct, self.lazy_K, rows, 16 + 4 * 16384 * (self.sample_num + 2), o.lr, self.device)
                 o.lazy.sync_all(o.t)
         g = self.grads
-        o.t += 1
+        t1 = o.t + 1                     # (the counter moves only once the library took the step: a raise leaves no phantom step)
         if o.lazy is not None:
             if feed_dict['X'].shape[0] * (self.sample_num + 2) > o.lazy.list_cap:
                 raise RuntimeError('batch too large for the lazy optimizer row list')
-            o.lazy.cover(o.t)
+            o.lazy.cover(t1)
             o.lazy.dirty = True
         rs = self._rand(feed_dict)
         if X_next is not None and (overlap or feed_dict.get('inject') is not None or not X_next.is_contiguous()):
@@ -599,8 +601,9 @@ class DCCF(DMF):
         pred, loss = _lib.dccf_train_step(self.ctx, self._struct(), rs, feed_dict['X'].contiguous(),
                                           feed_dict['Y'], feed_dict['rank'], feed_dict['dropout'],
                                           g['uid_embeddings.weight'], g['iid_embeddings.weight'], g['mlp.0.weight'],
-                                          g['mlp.0.bias'], self._opt_struct, o.t, loss=self._loss, touchedU=self.touchedU,
+                                          g['mlp.0.bias'], self._opt_struct, t1, loss=self._loss, touchedU=self.touchedU,
                                           touchedV=self.touchedV, X_next=X_next, step_next=self._call + 1, gextra=self._extra(g))
+        o.t = t1
         return {'prediction': pred, 'check': [('prediction', pred)], 'loss': loss[0]}
 
 

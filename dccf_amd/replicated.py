@@ -131,7 +131,7 @@ class HipBackend(object):
         """After the gathered buffers arrived: rank-ordered sums -> optimizer (ov: only the marked rows + W, b are left)."""
         self.opt.step = t
         if self.lazy is not None and self.opt.lazy_K == 0:      # the dense step of a call without the schedule
-            self.lazy.last.fill_(int(t))
+            self.lazy.sync_all(int(t))
         self.L.check(self.f_finish(self.op, self.dpp, 1 if ov else 0, tr.parity, self._next(tr) if ov else None,
                                    self.L.stream()))
 

@@ -38,6 +38,13 @@ int dccf_abi_version(void);
  * dccf_profile_read adds elapsed ms / launch counts since the last read into HOST arrays of 8 slots:
  * 0 prep, 1 mlp_fwd (extra layers), 2 noise_fwd, 3 pair_epilogue, 4 mlp_bwd (extra layers + user gradient), 5 bwd,
  * 6 opt_launch (the optimizer launch of dccf_train_step). */
+/* Deterministic gradient scatter (tests; off unless the environment variable DCCF_DETERMINISTIC=1 is set when the context is
+ * created).  The float atomics of the backward add a row's contributions in arrival order, so two runs of one step differ in
+ * the last bits of a gradient row.  With on != 0 dccf_train_fwdbwd / dccf_train_step use no float atomic: every (batch row,
+ * candidate) slot's gradient row is stored and the rows of one destination are added in slot order, gb and dW from partial sums in
+ * index order, the loss by one workgroup — two runs, and every form of the step (split calls, prepared, hosted, lazy), then
+ * agree bit for bit.  Slower (a test mode); not available in the replicated path's slot mode (ignored there). */
+int dccf_ctx_set_deterministic(dccf_ctx* ctx, int on);
 int dccf_profile(dccf_ctx* ctx, int enable);
 int dccf_profile_read(dccf_ctx* ctx, double* ms, int64_t* counts);
 
@@ -210,6 +217,12 @@ typedef struct {
   int64_t lazy_list_cap;
   int64_t lazy_id;       /* names THIS set of lazy_* arrays: a new value whenever they are re-created or cleared (the context
                           * remembers for which arrays the previous optimizer launch claimed the next step's rows) */
+  int64_t* lazy_host;    /* HOST int64 [2] owned by the caller, or NULL (no check): [0] = the last step whose lazy optimizer launch
+                          * went out (the library writes it; the caller sets it when it brings every row to a step by other means).
+                          * The lazy arrays are only valid if steps arrive one by one — no row more than lazy_K steps behind — so a
+                          * step's launches need opt->step == [0] + 1 and dccf_lazy_flush opt->step == [0]: anything else is an
+                          * argument error.  Should a row be further behind all the same, the kernels replay it from step - lazy_K
+                          * only (never an index in front of lazy_scal) and set lazy_cnt[15] = 1 for the caller to check. */
 } dccf_opt_t;
 /* HOST: out[4 i .. 4 i + 3] = the Adam step scalars of step t0 + i (see lazy_scal), i < n. */
 int dccf_lazy_scalars(float lr, int64_t t0, int32_t n, float* out_host);

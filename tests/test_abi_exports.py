@@ -23,8 +23,9 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), 'libdccf_hip.so does not export %s' % n
     assert sorted(_lib.EXPORTS) == names
     loaded = _lib.load()
-    assert loaded.dccf_abi_version() == 5      # 2: extra mlp layers in dccf_model_t / dccf_grads_t; 3: dccf_opt_t.lazy_*; 4: lazy_scal holds 4 floats
-                                               # per step; 5: claims / lists by step parity, dccf_opt_t.lazy_list_cap
+    assert loaded.dccf_abi_version() == 6      # 2: extra mlp layers in dccf_model_t / dccf_grads_t; 3: dccf_opt_t.lazy_*; 4: lazy_scal holds 4 floats
+                                               # per step; 5: claims / lists by step parity, dccf_opt_t.lazy_list_cap; 6: dccf_opt_t.lazy_host,
+                                               # dccf_ctx_set_deterministic
     assert loaded.dccf_last_error() is not None
 
 

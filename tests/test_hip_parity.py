@@ -126,6 +126,42 @@ def test_dccf_injected_train_steps_match_reference(L, ctx, name):
             close(fp.views[k], g[pre + 'after/' + k], PARAM_RTOL, PARAM_ATOL + STEP_FRAC * float(g['lr']), name + ' after ' + k)
 
 
+@pytest.mark.parametrize('lazy_K', [0, 2, 8])
+@pytest.mark.parametrize('name', DCCF_CASES)
+def test_dccf_golden_cases_through_the_default_train_step(L, name, lazy_K):
+    """The reference's golden cases through what runner.fit and bench.py actually run: DCCF.train_step = ONE dccf_train_step call
+    per batch under the windowed lazy regularisation (lazy_K = 2: every window comes round inside the case's 2-3 steps; 8: the
+    default; 0: the dense pass), with the reference's captured draws injected.  Parameters after every step against `after/*`
+    (state_dict() flushes the rows that are behind), the loss and the prediction against the reference's."""
+    from dccf_amd.models import DCCF, FusedOptimizer
+    g = load_golden(name)
+    A, S, p, rank = int(g['A']), int(g['S']), float(g['dropout']), int(g['rank'])
+    keys = pkeys(g)
+    U, D = g['init/' + PKEYS[0]].shape
+    I = g['init/' + PKEYS[1]].shape[0]
+    m = DCCF(path=None, dataset=None, sentence_model=None, sample_num=S, attribute_num=A, std=float(g['std']), label_min=0,
+             label_max=1, feature_num=0, user_num=U, item_num=I, u_vector_size=D, i_vector_size=D, n_layers=(len(keys) - 2) // 2,
+             random_seed=1, model_path='/tmp/x.pt', feature_embedding=T(g['feat']), expo_prob=T(g['expo']))
+    m.load_state_dict({k: T(g['init/' + k]) for k in keys})
+    m.optimizer = FusedOptimizer(m, str(g['optimizer']).lower(), float(g['lr']), float(g['l2']))
+    m.lazy_K = lazy_K
+    m.train()
+    for s in range(int(g['steps'])):
+        pre = 's%d/' % s
+        batch = {'X': T(g[pre + 'X']), 'Y': T(g[pre + 'Y']), 'rank': rank, 'train': True, 'dropout': p,
+                 'inject': {'sample_item': T(g[pre + 'sample_item']), 'noise': T(g[pre + 'noise']),
+                            'keep': T(g[pre + 'mask']) if p > 0 else None}}
+        out = m.train_step(batch)
+        assert (m.optimizer.lazy is not None) == (lazy_K >= 2 and D in (16, 32, 64, 128))
+        close(out['prediction'], g[pre + 'prediction'], FWD_RTOL, FWD_ATOL, name + ' pred')
+        close(out['loss'].reshape(1), g[pre + 'loss'].reshape(1), FWD_RTOL, FWD_ATOL, name + ' loss')
+        sd = m.state_dict()
+        for k in keys:
+            close(sd[k], g[pre + 'after/' + k], PARAM_RTOL, PARAM_ATOL + STEP_FRAC * float(g['lr']), name + ' after ' + k)
+        assert float(m.flat_g.abs().max()) == 0.0
+        m.train()
+
+
 @pytest.mark.parametrize('name', DCCF_CASES)
 def test_dccf_injected_eval_predict(L, ctx, name):
     g = load_golden(name)
@@ -881,6 +917,103 @@ def test_overlapped_train_step_equals_split_step(L, opt_name, B, l2, D, NL):
         if opt_name == 'gd':      # same candidates, noise and W^T at every later step too
             for a, b in zip(states[0][5:], other[5:]):
                 close(b, a.cpu().numpy(), 1e-4, 1e-5, 'later predictions')
+
+
+@pytest.mark.parametrize('opt_name,B,D,NL,F', [('adam', 128, 64, 1, 96), ('adagrad', 37, 64, 1, 96), ('adam', 64, 128, 1, 97),
+                                              ('adam', 40, 48, 3, 96), ('adagrad', 128, 64, 2, 96), ('gd', 50, 16, 1, 96)])
+def test_every_form_of_the_train_step_is_bit_identical_in_deterministic_mode(L, opt_name, B, D, NL, F):
+    """dccf_ctx_set_deterministic ("a sorted-segment deterministic mode for tests"): the backward stores one
+    gradient row per (batch row, candidate) slot and adds the slots of a destination in slot order, dW / gb from partial sums in
+    index order — no float atomic.  Then EVERY form of the step — the split calls (forward/backward, then the dense optimizer),
+    dccf_train_step with the lazy regularisation (`step`), announced steps (`prep`), the side-stream and hosted overlap forms,
+    the dense forms, a lazy window that cycles (`lazy3`) — must leave the same bits in every parameter, in both Adam moments and
+    in every prediction: Adam / Adagrad included, where the float-atomic path can only be held to a fraction of lr."""
+    from dccf_amd.models import DCCF, FusedOptimizer
+    U, I = 3001, 1999
+    g = torch.Generator(device='cuda').manual_seed(5)
+    feat = torch.randn(I, F, generator=g, device='cuda') * 0.05
+    expo = torch.randn(U, I, generator=g, device='cuda')
+    gen = torch.Generator(device='cuda').manual_seed(9)
+    nst = 7
+    # duplicate users inside a batch (40 distinct ones on even steps) and duplicate items: the case atomics reorder
+    full = torch.stack([torch.stack([torch.randint(0, U // 2 if k % 2 else 40, (2 * B,), generator=gen, device='cuda'),
+                                     torch.randint(0, 60 if k % 3 == 0 else I, (2 * B,), generator=gen, device='cuda')], 1) for k in range(nst)])
+    tile = D in (16, 32, 64, 128)
+    states = []
+    modes = ('split', 'step', 'overlap', 'prep', 'hosted', 'dense', 'denseprep', 'lazy3', 'split') if tile else ('split', 'step', 'prep', 'split')
+    for mode in modes:
+        m = DCCF(path=None, dataset=None, sentence_model=None, sample_num=10, attribute_num=2, std=0.1, label_min=0, label_max=1,
+                 feature_num=0, user_num=U, item_num=I, u_vector_size=D, i_vector_size=D, n_layers=NL, random_seed=11,
+                 model_path='/tmp/x.pt', feature_embedding=feat, expo_prob=expo)
+        m.ctx.set_deterministic(True)
+        torch.manual_seed(3)
+        m.apply(m.init_paras)
+        m.optimizer = FusedOptimizer(m, opt_name, 0.01, 1e-3)
+        m.lazy_K = {'dense': 0, 'denseprep': 0, 'lazy3': 3}.get(mode, 16)
+        m.train()
+        y = torch.cat([torch.ones(B, device='cuda'), torch.zeros(B, device='cuda')])
+        preds, losses = [], []
+        for k in range(nst):
+            batch = {'X': full[k], 'Y': y, 'rank': 1, 'train': True, 'dropout': 0.2}
+            if mode == 'split':
+                out = m(batch)
+                m.optimizer.step()
+            elif mode in ('prep', 'denseprep', 'lazy3'):
+                out = m.train_step(batch, X_next=full[k + 1] if k + 1 < nst else None)
+            else:
+                out = m.train_step(batch, overlap={'overlap': 1, 'hosted': 2}.get(mode, 0))
+            preds.append(out['prediction'].clone())
+            losses.append(out['loss'].clone())
+        sd = m.state_dict()          # flushes
+        torch.cuda.synchronize()
+        states.append((mode, m.flat_p.clone(), m.optimizer.s1, m.optimizer.s2, preds, losses))
+    ref = states[0]
+    for other in states[1:]:
+        for a, b, what in zip(ref[1:4], other[1:4], ('parameters', 'first moment / sum', 'second moment')):
+            if a is not None:
+                assert torch.equal(a, b), '%s: %s differ from the split calls (max %g)' % (other[0], what, float((a - b).abs().max()))
+        for k, (a, b) in enumerate(zip(ref[4], other[4])):
+            assert torch.equal(a, b), '%s: prediction of step %d' % (other[0], k)
+        for k, (a, b) in enumerate(zip(ref[5], other[5])):
+            assert torch.equal(a, b), '%s: loss of step %d' % (other[0], k)
+
+
+def test_deterministic_mode_agrees_with_the_atomic_path_and_the_oracle(L, ctx):
+    """The deterministic scatter is another ORDER of the same sums: against the float-atomic backward (the default) and against
+    the oracle on the same fused draws the gradients agree to the float-atomic tolerance; two deterministic runs are equal."""
+    rng = np.random.RandomState(3)
+    U_, I_, D, F, S, A, pairs, p = 300, 200, 64, 96, 10, 2, 24, 0.2
+    keys = PKEYS
+    P = {keys[0]: (rng.randn(U_, D) * 0.3).astype(np.float32), keys[1]: (rng.randn(I_, D) * 0.3).astype(np.float32),
+         keys[2]: (rng.randn(D, D + F) * 0.1).astype(np.float32), keys[3]: (rng.randn(D) * 0.1).astype(np.float32)}
+    feat = (rng.randn(I_, F) * 0.5).astype(np.float32)
+    expo = rng.randn(U_, I_).astype(np.float32)
+    u = rng.randint(0, 12, pairs)                                    # heavy duplication of users and items
+    X = np.concatenate([np.stack([u, rng.randint(0, 20, pairs)], 1), np.stack([u, rng.randint(0, 20, pairs)], 1)]).astype(np.int64)
+    Y = np.concatenate([np.ones(pairs), np.zeros(pairs)]).astype(np.float32)
+    tp = [T(P[k]) for k in keys]
+    m = L.model_struct(tp[0], tp[1], tp[2], tp[3], T(feat), T(expo), S, A, 0.1)
+    N, seed, step = 2 * pairs, 77, 3
+    runs = []
+    c2 = L.Context(0)
+    for det in (False, True, True):
+        c2.set_deterministic(det)
+        gr = [torch.zeros_like(t) for t in tp]
+        tu, tv = torch.zeros(U_ + 3, dtype=torch.uint8, device=dev())[:U_], torch.zeros(I_ + 3, dtype=torch.uint8, device=dev())[:I_]
+        pred, loss = L.dccf_train_fwdbwd(c2, m, L.rand_struct(seed=seed, step=step), T(X), T(Y), 1, p, *gr, touchedU=tu, touchedV=tv)
+        runs.append((gr, pred.clone(), loss.clone(), tu.clone(), tv.clone()))
+    si = L.debug_candidates(N, S, I_, seed, step, dev()).cpu().numpy()
+    nz = L.debug_noise(N * (S + 1) * A, F, 0.1, seed, step, dev()).cpu().numpy()
+    kp = L.debug_keep(N * (S + 1) * A, D, p, seed, step, dev()).cpu().numpy()
+    fw = O.dccf_forward(P, feat, expo, X, si, nz, kp, p, A)
+    lo, dpred = O.loss_and_dpred(fw['prediction'], Y, 1)
+    go = O.dccf_backward(P, fw, dpred, A)
+    for k, a, b, c in zip(keys, runs[0][0], runs[1][0], runs[2][0]):
+        assert torch.equal(b, c), k                                   # deterministic twice: the same bits
+        close(b, a.cpu().numpy(), GRAD_RTOL, GRAD_ATOL, 'deterministic vs atomic ' + k)
+        close(b, go[k], GRAD_RTOL, GRAD_ATOL, 'deterministic vs oracle ' + k)
+    assert torch.equal(runs[1][1], runs[0][1]) and torch.equal(runs[1][3], runs[0][3]) and torch.equal(runs[1][4], runs[0][4])
+    close(runs[1][2], np.asarray(lo, dtype=np.float32).reshape(1), FWD_RTOL, FWD_ATOL, 'loss')
 
 
 def test_prepared_state_survives_nothing_it_should_not(L):
