@@ -140,6 +140,7 @@ def emit(obj):
 def main():
     args = parse()
     quiet_stdout()
+    from dccf_amd import utils
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
@@ -151,22 +152,26 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d'
                              % (args.gpus, args.gpus))
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
-    if args.stream:
-        torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     if args.mp == 'sharded' and world == 1:
         args.force_sharded = 1              # --mp names the layout at any N (N = 1: the pipeline with a one-rank communicator)
     if args.mp == 'replicated' and world == 1:
         args.force_replicated = 1
+    if world > 1:
+        # one process per GPU: device binding, the GPU-count check, the process group with a finite timeout (dccf_amd/utils.py);
+        # everything up to the end of the warm-up runs under a host-side deadline (a first-contact hang exits non-zero)
+        rank, world = utils.init_distributed()
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if args.stream:
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     if world > 1 or args.force_sharded or args.force_replicated:
+        import datetime
         import torch.distributed as dist
         if world == 1:
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            os.environ.setdefault('MASTER_PORT', '29618')
-            dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
-        else:
-            dist.init_process_group(backend, **({'device_id': dev} if backend == 'nccl' else {}))
+            os.environ.setdefault('MASTER_PORT', str(utils.free_port()))      # (chosen by the kernel: a fixed port collides now and then)
+            dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev,
+                                    timeout=datetime.timedelta(seconds=utils.dist_timeout_s()))
         n_params = (args.users + args.items) * args.dim + args.dim * (args.dim + args.feat) + args.dim
         if args.mp == 'auto':
             args.mp = 'replicated' if n_params <= 1e8 else 'sharded'

@@ -33,7 +33,7 @@ class ModelT(C.Structure):
                 ('U', _f), ('V', _f), ('W', _f), ('b', _f), ('feat', _f), ('expo', _f),
                 ('ipsP', _f), ('ipsQ', _f), ('ipsBu', _f), ('ipsBi', _f), ('ipsProp', _f),
                 ('ipsB0', C.c_float), ('ipsM', C.c_float), ('ipsD', C.c_int32), ('n_extra', C.c_int32),
-                ('Wl', _f * 7), ('bl', _f * 7)]
+                ('Wl', _f * 7), ('bl', _f * 7), ('expo_gathered', _f)]
 
 
 class RandT(C.Structure):
@@ -257,8 +257,9 @@ class Context(object):
             pass
 
 
-def model_struct(U, V, W, b, feat, expo, S, A, std, ips=None, extra=None):
-    """extra: [(mlp.k.weight [D, D], mlp.k.bias [D]) for k = 1 .. n_layers - 1] (src/models/DCCF.py:61-62)."""
+def model_struct(U, V, W, b, feat, expo, S, A, std, ips=None, extra=None, expo_gathered=None):
+    """extra: [(mlp.k.weight [D, D], mlp.k.bias [D]) for k = 1 .. n_layers - 1] (src/models/DCCF.py:61-62).
+    expo_gathered: [N, S + 1] exposures of the call's own (row, candidate) slots instead of a matrix / factors."""
     m = ModelT()
     m.user_num, m.D = U.shape
     m.item_num = V.shape[0]
@@ -283,7 +284,8 @@ def model_struct(U, V, W, b, feat, expo, S, A, std, ips=None, extra=None):
         if tuple(Wk.shape) != (m.D, m.D) or tuple(bk.shape) != (m.D,):
             raise RuntimeError('extra mlp layers must be [D, D] / [D]')
         m.Wl[k], m.bl[k] = ptr(Wk, f32), ptr(bk, f32)
-    m._refs = (U, V, W, b, feat, expo, ips, extra)   # the struct holds raw addresses: keep the tensors alive with it
+    m.expo_gathered = ptr(expo_gathered, f32)
+    m._refs = (U, V, W, b, feat, expo, ips, extra, expo_gathered)   # the struct holds raw addresses: keep the tensors alive with it
     return m
 
 
@@ -652,16 +654,23 @@ def build_epoch_batches(uid, iid, neg, perm, batch_size, bad, seed=0, epoch=0):
 
 
 def shard_jobs(jobs):
-    """A HOST array of shard_job_t from [(idx, dst, n, tables, payload)] (idx / dst int32 tensors or None); keeps the tensors
-    alive.  `n`, `idx` and `dst` may be rewritten per step through the returned array (a[q].n = ..., a[q].idx = ptr)."""
+    """A HOST array of shard_job_t from [(idx, dst, n, tables, payload[, col])] (idx / dst int32 tensors or None; col: the job's
+    rows start at column `col` of the payload rows); keeps the tensors alive.  `n`, `idx` and `dst` may be rewritten per step
+    through the returned array (a[q].n = ..., a[q].idx = ptr)."""
     a = (ShardJobT * len(jobs))()
     keep = []
-    for q, (idx, dst, n, tables, payload) in enumerate(jobs):
+    for q, job in enumerate(jobs):
+        idx, dst, n, tables, payload = job[:5]
+        col = int(job[5]) if len(job) > 5 else 0
         a[q].idx, a[q].dst, a[q].n = ptr(idx, torch.int32), ptr(dst, torch.int32), int(n)
+        width = 0
         for t, tb in enumerate(tables):
             a[q].tables[t] = ptr(tb, torch.float32)
             a[q].widths[t] = int(tb.shape[1]) if tb.dim() > 1 else 1
-        a[q].ntables, a[q].ld, a[q].buf = len(tables), int(payload.shape[1]), ptr(payload, torch.float32)
+            width += a[q].widths[t]
+        if col < 0 or col + width > int(payload.shape[1]):
+            raise RuntimeError('shard job: columns [%d, %d) do not fit the payload rows (%d floats)' % (col, col + width, payload.shape[1]))
+        a[q].ntables, a[q].ld, a[q].buf = len(tables), int(payload.shape[1]), ptr(payload, torch.float32) + 4 * col
         keep.append((idx, dst, tables, payload))
     a._keep = keep
     return a

@@ -5,7 +5,7 @@
 //
 // RCCL is NOT a link-time dependency of this library: the process is PyTorch-ROCm, whose wheel ships its own librccl.so.1, and
 // two RCCL copies in one process must not happen.  The entry points are resolved at run time from the copy the process has
-// already mapped (dlopen with RTLD_NOLOAD first; torch.distributed loads it), falling back to the loader's search path.
+// already mapped (dlopen with RTLD_NOLOAD only; torch.distributed loads it) — never from the loader's search path.
 #include "common.hpp"
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -27,10 +27,11 @@ const Api& api() {
   static const Api a = [] {
     Api q;
     memset(&q, 0, sizeof(q));
+    // only the copy the process has ALREADY mapped (PyTorch-ROCm's, loaded with torch.distributed's nccl backend): a plain
+    // dlopen could map a second RCCL next to it — exactly what must not happen.  Not mapped = "RCCL not available": the
+    // caller's torch.distributed branch does the same work.
     void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
-    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) return q;
 #define SYM(field, name) q.field = (decltype(q.field))dlsym(h, name)
     SYM(GetUniqueId, "ncclGetUniqueId");
@@ -66,7 +67,7 @@ struct Comm {
 
 extern "C" int dccf_comm_unique_id(uint8_t* out128) {
   ARG_CHECK(out128 != nullptr, "NULL output");
-  ARG_CHECK(api().ok, "RCCL is not available in this process (librccl.so.1 could not be resolved)");
+  ARG_CHECK(api().ok, "RCCL is not available in this process (no librccl.so.1 mapped: create the torch.distributed nccl process group first)");
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
   ncclUniqueId id;
   NCCL_TRY(api().GetUniqueId(&id));
@@ -76,7 +77,7 @@ extern "C" int dccf_comm_unique_id(uint8_t* out128) {
 
 extern "C" int dccf_comm_create(void** comm, const uint8_t* id128, int32_t world, int32_t rank) {
   ARG_CHECK(comm && id128 && world >= 1 && rank >= 0 && rank < world, "bad arguments");
-  ARG_CHECK(api().ok, "RCCL is not available in this process (librccl.so.1 could not be resolved)");
+  ARG_CHECK(api().ok, "RCCL is not available in this process (no librccl.so.1 mapped: create the torch.distributed nccl process group first)");
   ncclUniqueId id;
   memcpy(&id, id128, 128);
   Comm* c = new Comm();

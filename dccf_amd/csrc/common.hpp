@@ -329,7 +329,7 @@ __device__ __forceinline__ int64_t prep_cand(const dccf_model_t& M, const int64_
     it = (int64_t)(((uint64_t)pick4(r, (s - 1) & 3) * (uint64_t)item_num) >> 32);
   }
   cand[j] = (int)it;
-  eg[j] = expo_at(M, X[2 * n], it);
+  eg[j] = M.expo_gathered ? M.expo_gathered[j] : expo_at(M, X[2 * n], it);
   return it;
 }
 

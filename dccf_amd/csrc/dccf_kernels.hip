@@ -1400,8 +1400,8 @@ static int check_model(const dccf_model_t* M) {
   ARG_CHECK(M->S >= 0 && M->S <= 63 && M->A >= 1 && M->A <= 64, "S in [0,63], A in [1,64]");
   ARG_CHECK(M->user_num > 0 && M->item_num > 0 && M->item_num < 2147483647LL, "bad user_num / item_num");
   ARG_CHECK(M->U && M->V && M->W && M->b && M->feat, "NULL parameter / feature pointer");
-  ARG_CHECK(M->expo || (M->ipsP && M->ipsQ && M->ipsBu && M->ipsBi && M->ipsProp && M->ipsD > 0),
-            "need expo or the IPS factors");
+  ARG_CHECK(M->expo || M->expo_gathered || (M->ipsP && M->ipsQ && M->ipsBu && M->ipsBi && M->ipsProp && M->ipsD > 0),
+            "need expo, expo_gathered or the IPS factors");
   ARG_CHECK(M->n_extra >= 0 && M->n_extra <= DCCF_MAX_EXTRA, "n_extra (--n_layers - 1) must be in [0, 7]");
   for (int k = 0; k < M->n_extra; ++k) ARG_CHECK(M->Wl[k] && M->bl[k], "NULL weight / bias of an extra mlp layer");
   return 0;
@@ -1480,6 +1480,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
   ARG_CHECK(rnd->mode >= 0 && rnd->mode <= 2, "rnd.mode must be 0, 1 or 2");
   if (!fused && N > 0) ARG_CHECK(rnd->noise != nullptr, "injected mode needs noise");
   if (!fused_cand && N > 0) ARG_CHECK(M->S == 0 || rnd->sample_item, "injected candidates need sample_item");
+  ARG_CHECK(!M->expo_gathered || !fused_cand, "expo_gathered needs injected candidates (rnd.mode 0 or 2)");
   if (train) {
     ARG_CHECK(G && G->gU && G->gV && G->gW && G->gb && loss, "NULL gradient / loss pointer");
     ARG_CHECK(rank == 0 || rank == 1, "rank must be 0 or 1");

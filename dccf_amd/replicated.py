@@ -217,6 +217,36 @@ class ReplicatedDCCF(object):
         self.gcnt = torch.zeros(2, dtype=torch.int32, device=device)
         self.parity = 0
 
+    collectives = 'all_gather_into_tensor x1 per step, overlapped with the optimizer pass over the rows no rank touches'
+
+    def crosscheck_replicas(self):
+        """First contact with real RCCL at G > 1, outside any timed region (after the warm-up steps): the replicas must be
+        bit-identical — every rank applied the same rank-ordered sums.  A checksum of the parameters is compared across the ranks;
+        on a mismatch the reason goes to stderr, every rank takes rank 0's parameters and optimizer state and the step falls
+        back to its synchronous form (no second stream beside the all-gather, no prepared next step): same results, the
+        overlap is what is given up.  Returns True when the replicas agreed; self.collectives names what runs from here on."""
+        import sys
+        self.flush()
+        chk = torch.stack([self.flat_p.double().sum(), self.flat_p.double().abs().sum()])
+        lo, hi = chk.clone(), chk.clone()
+        if self.G > 1:
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        if torch.equal(lo, hi):
+            return True
+        print('[dccf_amd.replicated] rank %d: replicas differ after the warm-up steps (checksum %r, min %r, max %r): resynchronising '
+              'from rank 0 and falling back to the synchronous step' % (self.rank, chk.tolist(), lo.tolist(), hi.tolist()), file=sys.stderr)
+        for t in (self.flat_p, self.s1, self.s2):
+            if t is not None:
+                dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        self.flat_g.zero_()
+        for f in (self.tU, self.tV, self.gfU, self.gfV, self.gfU2, self.gfV2, self.lfU, self.lfV):
+            f.zero_()
+        self.overlap = False
+        self.next = None
+        self.collectives = 'all_gather_into_tensor x1 per step, synchronous (fallback: replicas differed after the warm-up with the overlapped form)'
+        return False
+
     @staticmethod
     def _buffer_words(cap, D, nd):
         return (4 + 2 * cap + cap * D + nd + 3) // 4 * 4     # == dp_buffer_words (include/dccf_hip.h)
@@ -296,8 +326,13 @@ def bench_main(args, rank, world, dev):
     import time
     from dccf_amd.data_processor import DeviceTrainSet
     from bench import synthetic_interactions
+    from dccf_amd import utils
     U, I, D, F, B = args.users, args.items, args.dim, args.feat, args.batch_size
     S, A = 10, 2
+    # everything up to the end of the warm-up (table setup, the first collectives on real RCCL) runs under a host-side deadline:
+    # a hang at first contact makes every rank exit non-zero with a message instead of burning the launcher's time limit
+    deadline = utils.Deadline(float(os.environ.get('DCCF_WARMUP_DEADLINE_S', '420')),
+                              'set-up + %d warm-up steps of the replicated %d-rank step' % (args.warmup, world))
     be = HipBackend(dev)
     g = torch.Generator(device=dev).manual_seed(args.seed)          # same tables on every rank
     feat = torch.randn(I, F, generator=g, device=dev) * 0.05
@@ -339,7 +374,13 @@ def bench_main(args, rank, world, dev):
         tr.train_step(sched[k, rank], y, pred, X_all=sched[k], X_all_next=nxt(sched, k, args.warmup))
     torch.cuda.synchronize()
     dist.barrier()
+    # first contact, outside the timed region: the replicas must agree after the warm-up; if not -> stderr, resync, synchronous step
+    agreed_after_warmup = tr.crosscheck_replicas()
     torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    deadline.cancel()
+    deadline = utils.Deadline(float(os.environ.get('DCCF_BENCH_DEADLINE_S', '600')), 'the timed %d steps + the roofline section' % args.steps)
     t0 = time.perf_counter()
     sched = schedule(1, args.steps)                            # the epoch's negative sampling is timed
     for k in range(args.steps):
@@ -420,8 +461,10 @@ def bench_main(args, rank, world, dev):
                           'batch_size_per_gpu': B, 'global_batch': B * world, 'optimizer': 'Adam lr=1e-3 l2=1e-4 dropout=0.2',
                           'collectives_per_step': 'all_gather x1 (touched gradient rows + [dW|db], %.2f MB per rank)'
                                                   % (tr.words * 4 / 1e6),
+                          'collectives': tr.collectives, 'replicas_agreed_after_warmup': bool(agreed_after_warmup),
                           'replicas_bit_identical': bool(torch.equal(lo, hi))},
                'roofline': roofline, 'cpu_baseline': None}
         import bench
         bench.emit(out)
+    deadline.cancel()
     dist.destroy_process_group()

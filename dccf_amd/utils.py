@@ -92,11 +92,65 @@ def barrier():
         dist.barrier()
 
 
+class Deadline(object):
+    """Host-side watchdog around a phase that may hang at first contact with a peer (the warm-up steps of a multi-rank job: the
+    first collectives on real RCCL): if the phase is not over — cancel() — after `seconds`, EVERY thread's stack is irrelevant,
+    the process prints what it was waiting for to stderr and exits with status 3.  Under torch.distributed.run a rank that
+    exits non-zero brings the whole job down with a message instead of burning the launcher's time limit.  Never a re-exec,
+    never a retry in the same process."""
+
+    def __init__(self, seconds, what):
+        import threading
+        self.what, self.seconds = what, float(seconds)
+        self._t = None
+        if self.seconds > 0:
+            self._t = threading.Timer(self.seconds, self._fire)
+            self._t.daemon = True
+            self._t.start()
+
+    def _fire(self):
+        import sys
+        rank = os.environ.get('RANK', '0')
+        sys.stderr.write('[dccf_amd] rank %s: DEADLINE of %.0f s exceeded while waiting for: %s — exiting with status 3 '
+                         '(a collective that never completes usually means a peer died or the ranks disagree on the schedule; '
+                         'DCCF_DIST_BACKEND=gloo rehearses the same launch without RCCL)\n' % (rank, self.seconds, self.what))
+        sys.stderr.flush()
+        os._exit(3)
+
+    def cancel(self):
+        if self._t is not None:
+            self._t.cancel()
+            self._t = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.cancel()
+        return False
+
+
+def free_port():
+    """A TCP port nobody listens on right now, chosen by the kernel (single-process rendezvous of the one-rank pipelines)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def dist_timeout_s():
+    """Timeout of every torch.distributed collective of this job (DCCF_DIST_TIMEOUT_S, default 180 s: c10d's own default is 10
+    to 30 minutes, longer than a driver's whole time limit)."""
+    return float(os.environ.get('DCCF_DIST_TIMEOUT_S', '180'))
+
+
 def init_distributed():
     """One process per GPU under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment): binds this
     process to its GPU and creates the process group — backend "nccl" = RCCL over xGMI; DCCF_DIST_BACKEND=gloo rehearses on a
-    box with fewer GPUs than ranks (the ranks then share the visible devices).  Returns (rank, world size)."""
-    import os
+    box with fewer GPUs than ranks (the ranks then share the visible devices).  Returns (rank, world size).  Fails early and
+    loudly: fewer visible GPUs than local ranks is an error here, not a hang inside the first collective, and every collective
+    of the group times out after dist_timeout_s()."""
+    import datetime
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world <= 1:
@@ -105,10 +159,17 @@ def init_distributed():
         return dist.get_rank(), dist.get_world_size()
     backend = os.environ.get('DCCF_DIST_BACKEND', 'nccl')
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    local_world = int(os.environ.get('LOCAL_WORLD_SIZE', str(world)))
+    ndev = torch.cuda.device_count()
+    if backend == 'nccl' and ndev < local_world:
+        raise RuntimeError('%d ranks on this node but only %d visible GPUs: the RCCL backend needs one GPU per rank '
+                           '(LOCAL_WORLD_SIZE=%d, LOCAL_RANK=%d; set DCCF_DIST_BACKEND=gloo to rehearse with shared devices)'
+                           % (local_world, ndev, local_world, local))
     if backend != 'nccl':
-        local = local % max(torch.cuda.device_count(), 1)
+        local = local % max(ndev, 1)
     torch.cuda.set_device(local)
-    dist.init_process_group(backend, **({'device_id': torch.device('cuda', local)} if backend == 'nccl' else {}))
+    kw = {'device_id': torch.device('cuda', local)} if backend == 'nccl' else {}
+    dist.init_process_group(backend, timeout=datetime.timedelta(seconds=dist_timeout_s()), **kw)
     return dist.get_rank(), dist.get_world_size()
 
 

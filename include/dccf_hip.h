@@ -76,6 +76,10 @@ typedef struct {
                         /* 91-94), each Linear + relu + dropout; 0 <= n_extra <= DCCF_MAX_EXTRA                          */
   const float* Wl[7];   /* mlp.k.weight [D, D], k = 1 .. n_extra  (Wl[k-1])                                             */
   const float* bl[7];   /* mlp.k.bias   [D]                                                                             */
+  const float* expo_gathered; /* optional [N, S+1]: Expo[u(n), cand[n][s]] of THIS call's batch, gathered by the caller (the
+                         * row-sharded trainer: the owner of a user row holds that user's row of the exposure matrix and ships
+                         * the 2 (S+1) values a pair needs with the embedding row).  Takes precedence over expo / the factors;
+                         * needs injected candidates (rnd.mode 0 or 2): the caller gathered at exactly those.                  */
 } dccf_model_t;
 #define DCCF_MAX_EXTRA 7
 

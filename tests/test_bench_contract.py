@@ -16,7 +16,8 @@ KEYS = ['metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', '
 
 
 def run(*flags):
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29741')
+    from conftest import free_port
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()))        # (a fresh port per bench process)
     r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--steps', '20', '--warmup', '5', '--users', '30000', '--items',
                         '9000'] + list(flags), cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-2000:]

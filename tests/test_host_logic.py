@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import load_golden, REPO
 from dccf_amd import utils, rank_metrics
 from dccf_amd.data_loader import DataLoader
 from dccf_amd.data_processor import DataProcessor
@@ -107,3 +107,34 @@ def test_product_refuses_to_run_without_gpu():
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         RecModel(label_min=0, label_max=1, feature_num=0, user_num=3, item_num=3, u_vector_size=4, i_vector_size=4,
                  random_seed=1, model_path='/tmp/x.pt')
+
+
+def test_deadline_exits_nonzero_with_a_message_and_can_be_cancelled():
+    """utils.Deadline (the host-side watchdog around the warm-up of a multi-rank job, first contact with real RCCL): when the
+    phase does not end in time the process says what it waited for on stderr and exits with status 3 — never a hang, never a
+    re-exec; a cancelled deadline does nothing."""
+    import subprocess
+    import sys
+    code = ("import sys, time; sys.path.insert(0, %r); from dccf_amd import utils\n"
+            "d = utils.Deadline(float(sys.argv[1]), 'the warm-up of a test')\n"
+            "if sys.argv[2] == 'cancel': d.cancel()\n"
+            "time.sleep(float(sys.argv[3])); print('survived')" % REPO)
+    r = subprocess.run([sys.executable, '-c', code, '0.3', 'keep', '5'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert r.returncode == 3 and b'DEADLINE' in r.stderr and b'the warm-up of a test' in r.stderr and b'survived' not in r.stdout
+    r = subprocess.run([sys.executable, '-c', code, '0.3', 'cancel', '0.8'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert r.returncode == 0 and b'survived' in r.stdout
+
+
+def test_init_distributed_refuses_fewer_gpus_than_local_ranks(monkeypatch):
+    """The RCCL backend needs one GPU per local rank: an early, readable error instead of a hang inside the first collective."""
+    import pytest
+    import torch
+    from dccf_amd import utils
+    monkeypatch.setenv('WORLD_SIZE', '64')
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '64')
+    monkeypatch.setenv('RANK', '0')
+    monkeypatch.setenv('LOCAL_RANK', '0')
+    monkeypatch.delenv('DCCF_DIST_BACKEND', raising=False)
+    assert torch.cuda.device_count() < 64
+    with pytest.raises(RuntimeError, match='one GPU per rank'):
+        utils.init_distributed()

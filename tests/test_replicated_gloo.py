@@ -242,3 +242,40 @@ def test_epoch_schedule_covers_every_pair_once(n, B, G):
     cnt = np.bincount(seen, minlength=n)
     assert cnt.min() == 1 and cnt.sum() - n < G and (cnt[min(B, n):] == 1).all()
     assert len(shares) // G == -(-n // (G * B))
+
+
+def _crosscheck_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from dccf_amd.replicated import ReplicatedDCCF
+    c = dict(CFG, overlap=True)
+    P, feat, expo, X = make_world(c)
+    T = torch.from_numpy
+    tr = ReplicatedDCCF(rank, world, c['U'], c['I'], c['D'], c['S'], c['A'], c['std'], c['dropout'], c['lr'], c['l2'], c['seed'],
+                        OracleBackend(), torch.device('cpu'), T(feat), expo=T(expo), max_rows=2 * c['B'])
+    tr.set_params(T(P[KEYS[0]]), T(P[KEYS[1]]), T(P[KEYS[2]]), T(P[KEYS[3]]))
+    Y = torch.cat([torch.ones(c['B']), torch.zeros(c['B'])])
+    tr.train_step(T(X[0][rank]), Y, X_all=T(X[0]))
+    ok_first = tr.crosscheck_replicas()                 # a healthy warm-up: the replicas agree, nothing changes
+    assert ok_first and tr.overlap and 'fallback' not in tr.collectives
+    if rank == 1:                                       # what a broken overlapped exchange would leave behind
+        tr.flat_p[7] += 1.0
+        tr.s1[3] += 0.5
+    ok = tr.crosscheck_replicas()
+    assert not ok and not tr.overlap and 'fallback' in tr.collectives
+    # the job goes on in the synchronous form, from rank 0's state: one more step, then the replicas must still agree
+    tr.train_step(T(X[1][rank]), Y, X_all=T(X[1]))
+    assert tr.crosscheck_replicas()
+    np.savez(os.path.join(out, 'cc%d.npz' % rank), p=tr.flat_p.numpy(), s1=tr.s1.numpy())
+    dist.destroy_process_group()
+
+
+def test_replicas_that_differ_after_warmup_resync_and_fall_back(tmp_path):
+    """first contact with real RCCL at G > 1 cannot be rehearsed on one GPU — so the check that guards it is:
+    after the warm-up the replicas' checksums are compared; on a mismatch every rank takes rank 0's state, the step falls back
+    to its synchronous form and the run says so (config.collectives) instead of timing a drifting job."""
+    from conftest import free_port
+    mp.spawn(_crosscheck_worker, args=(2, free_port(), str(tmp_path)), nprocs=2, join=True)
+    a, b = (dict(np.load(os.path.join(str(tmp_path), 'cc%d.npz' % r))) for r in range(2))
+    assert np.array_equal(a['p'], b['p']) and np.array_equal(a['s1'], b['s1'])

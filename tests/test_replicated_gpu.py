@@ -262,7 +262,20 @@ def test_two_ranks_hip_backend_replicas_bit_identical(tmp_path, overlap, world, 
 
 
 # ------------------------------------------------------------------------------------------------ row-sharded layout, 2 ranks
-def _sharded_rank_main(rank, world, port, out, lazy_K):
+SHARD_CASES = {
+    # the round-2 case: D = 16, F = 32, 8-d IPS factors
+    'small': dict(steps=5),
+    # BASELINE.json config 5's model shape: rank-128 embeddings, the 768-d feature projection, 64-d IPSBiasedMF factors for the
+    # exposure (a dense U x I matrix is impossible at 10M x 1M), S = 10 candidates, A = 2 noise draws
+    'config5': dict(U=301, I=257, D=128, F=768, Dq=64, S=10, A=2, B=16, steps=5),
+    # the dense exposure file sharded by user rows (what the CLI has), Adagrad, --n_layers 2
+    'dense_adagrad_l2': dict(U=211, I=157, D=64, F=96, S=10, A=2, B=12, steps=5, expo='dense', opt='adagrad', n_layers=2),
+    # an embedding size that is not a kernel tile (no row segments: the dense optimizer pass over the shard), GD, 3 layers
+    'gd_d48_l3': dict(U=97, I=83, D=48, F=100, S=4, A=2, B=9, steps=4, expo='dense', opt='gd', n_layers=3, lr=0.05),
+}
+
+
+def _sharded_rank_main(rank, world, port, out, lazy_K, case):
     """One rank of the row-sharded trainer with the HIP backend; both ranks share this box's one GPU, gloo moves the bytes."""
     import torch.distributed as dist
     import test_sharded_gloo as TS
@@ -272,37 +285,38 @@ def _sharded_rank_main(rank, world, port, out, lazy_K):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(dev)
-    c = dict(TS.CFG, steps=5)      # (five steps: the lazy window cycles at K = 2)
+    c = dict(TS.CFG, **SHARD_CASES[case])      # (five steps: the lazy window cycles at K = 2)
     P, feat, ips, X = TS.make_world(c)
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    ips_loc = dict(P=T(ips['P'][rank::world]), bu=T(ips['bu'][rank::world]), Q=T(ips['Q'][rank::world]),
-                   bi=T(ips['bi'][rank::world]), prop=T(ips['prop'][rank::world]), b0=0.1, M=0.1)
-    tr = sharded.ShardedDCCF(rank, world, c['U'], c['I'], c['D'], c['S'], c['A'], c['std'], c['dropout'], c['lr'], c['l2'],
-                             c['seed'], sharded.HipBackend(dev), dev, T(feat[rank::world]), ips_loc, lazy_K=lazy_K)
-    K = TS.KEYS
-    tr.set_global_params(T(P[K[0]]), T(P[K[1]]), T(P[K[2]]), T(P[K[3]]))
+    tr = TS.build_trainer(c, rank, world, sharded.HipBackend(dev), dev, P, feat, ips, lazy_K=lazy_K)
+    assert tr.crosscheck_collectives() == 'torch.distributed'          # (gloo: there is no direct communicator to check)
     preds, losses = [], []
     tr.begin_epoch(T(np.stack(X)), 3)
     for step in range(c['steps']):
         pred, loss = tr.train_step(step)
         preds.append(pred.cpu().numpy().copy())
         losses.append(float(loss))
-    assert (tr.lazy is not None) == (lazy_K >= 2)
+    assert (tr.lazy is not None) == (lazy_K >= 2 and c['D'] in (16, 32, 64, 128))
     tr.flush()                 # rows the lazy regularisation left behind are brought up to date before anybody looks
     torch.cuda.synchronize()
+    extra = {'x%d' % k: t.cpu().numpy() for k, t in enumerate(x for wb in tr.extra for x in wb)}
     np.savez(os.path.join(out, 'sh%d.npz' % rank), U=tr.U.cpu().numpy(), V=tr.V.cpu().numpy(), W=tr.W.cpu().numpy(),
              b=tr.b.cpu().numpy(), preds=np.stack(preds), losses=np.array(losses), gmax=float(tr.flat_g.abs().max()),
-             touched=int(tr.touched.sum()))
+             touched=int(tr.touched.sum()), **extra)
+    tr.close()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('lazy_K', [0, 2, 8])
-def test_two_ranks_hip_backend_row_sharded_equals_union_batch(tmp_path, lazy_K):
+@pytest.mark.parametrize('case,lazy_K', [('small', 0), ('small', 2), ('small', 8), ('config5', 0), ('config5', 8), ('config5', 2),
+                                         ('dense_adagrad_l2', 2), ('dense_adagrad_l2', 0), ('gd_d48_l3', 8)])
+def test_two_ranks_hip_backend_row_sharded_equals_union_batch(tmp_path, lazy_K, case):
     """World size 2 of the ROW-SHARDED layout with the HIP backend (pack / all-to-all / unpack / the single-GPU kernels on
-    compact tables / all-to-all / scatter-add / all-reduce / row-aware Adam — dense, or the windowed lazy regularisation of the
-    shard: the rows about to be sent are caught up first): every rank's predictions equal the oracle's on
-    the same counter-based draws, the shards partition the tables (rank r holds rows r, r + G, ...), W and b stay
-    replicated, and the parameters equal ONE oracle step on the union of the ranks' batches to the float-atomic tolerance."""
+    compact tables / all-to-all / scatter-add / all-reduce / row-aware optimizer — dense, or the windowed lazy regularisation of
+    the shard: the rows about to be sent are caught up first): every rank's predictions equal the oracle's on
+    the same counter-based draws, the shards partition the tables (rank r holds rows r, r + G, ...), W, b and the extra layers
+    stay replicated, and the parameters equal ONE oracle step on the union of the ranks' batches to the float-atomic tolerance.
+    Cases: BASELINE config 5's model shape (D = 128, F = 768, 64-d IPS factors, S = 10, A = 2); the dense exposure matrix
+    sharded by user rows with Adagrad and --n_layers 2; GD with an embedding size that is not a kernel tile and 3 layers."""
     import torch.multiprocessing as mp
     import test_sharded_gloo as TS
     from oracle import dccf_oracle as O
@@ -310,12 +324,13 @@ def test_two_ranks_hip_backend_row_sharded_equals_union_batch(tmp_path, lazy_K):
     world = 2
     from conftest import free_port
     port = free_port()
-    mp.spawn(_sharded_rank_main, args=(world, port, str(tmp_path), lazy_K), nprocs=world, join=True)
-    c = dict(TS.CFG, steps=5)      # (five steps: the lazy window cycles at K = 2)
+    mp.spawn(_sharded_rank_main, args=(world, port, str(tmp_path), lazy_K, case), nprocs=world, join=True)
+    c = dict(TS.CFG, **SHARD_CASES[case])
     K = TS.KEYS
     P, feat, ips, X = TS.make_world(c)
     expo = TS.expo_from_ips(ips)
-    opt = O.DenseOptimizer('adam', c['lr'], c['l2'])
+    NL, opt_name = c.get('n_layers', 1), c.get('opt', 'adam')
+    opt = O.DenseOptimizer(opt_name, c['lr'], c['l2'])
     N, Ld = 2 * c['B'], 2 * c['B'] * (c['S'] + 1) * c['A']
     Y = np.concatenate([np.ones(c['B'], np.float32), np.zeros(c['B'], np.float32)])
     res = [dict(np.load(os.path.join(str(tmp_path), 'sh%d.npz' % r))) for r in range(world)]
@@ -324,10 +339,11 @@ def test_two_ranks_hip_backend_row_sharded_equals_union_batch(tmp_path, lazy_K):
         total = {k: np.zeros_like(v) for k, v in P.items()}
         for r in range(world):
             noise = PH.noise(c['seed'], step * world + r, Ld, c['F'], c['std'])
-            keep = PH.dropout_keep(c['seed'], step * world + r, Ld, c['D'], float(np.float32(c['dropout'])))
+            keep = np.stack([PH.dropout_keep(c['seed'], step * world + r, Ld, c['D'], float(np.float32(c['dropout'])), layer=k)
+                             for k in range(NL)])
             fw = O.dccf_forward(P, feat, expo, X[step][r], cand_all[step][r], noise, keep, c['dropout'], c['A'])
             if step == 0:      # later steps start from parameters that differ by the float-atomic noise of the step before
-                np.testing.assert_allclose(res[r]['preds'][step], fw['prediction'], rtol=1e-4, atol=2e-6)
+                np.testing.assert_allclose(res[r]['preds'][step], fw['prediction'], rtol=1e-4, atol=2e-6 * max(1.0, np.abs(fw['prediction']).max()))
             loss, dpred = O.loss_and_dpred(fw['prediction'], Y, 1)
             assert float(loss) == pytest.approx(float(res[r]['losses'][step]), rel=2e-3)
             g = O.dccf_backward(P, fw, dpred, c['A'])
@@ -338,12 +354,18 @@ def test_two_ranks_hip_backend_row_sharded_equals_union_batch(tmp_path, lazy_K):
     for r in range(world):
         assert res[r]['gmax'] == 0.0 and res[r]['touched'] == 0            # nothing left behind
         assert res[r]['U'].shape[0] == len(range(r, c['U'], world)) and res[r]['V'].shape[0] == len(range(r, c['I'], world))
-        for mine, ref in ((res[r]['U'], P[K[0]][r::world]), (res[r]['V'], P[K[1]][r::world]), (res[r]['W'], P[K[2]]),
-                          (res[r]['b'], P[K[3]])):
+        pairs = [(res[r]['U'], P[K[0]][r::world]), (res[r]['V'], P[K[1]][r::world]), (res[r]['W'], P[K[2]]), (res[r]['b'], P[K[3]])]
+        for k in range(1, NL):
+            pairs += [(res[r]['x%d' % (2 * (k - 1))], P['mlp.%d.weight' % k]), (res[r]['x%d' % (2 * (k - 1) + 1)], P['mlp.%d.bias' % k])]
+        for mine, ref in pairs:
             d = np.abs(mine - ref)
-            # Adam turns the last-bit differences of float-atomic sums into fractions of lr on a few elements
-            assert d.max() <= steps * lr and (d > steps * 5e-3 * lr).mean() <= 0.02, (d.max(), (d > steps * 5e-3 * lr).mean())
+            if opt_name == 'gd':       # no amplification: plain fp32 agreement
+                assert d.max() <= 3e-5 * max(1.0, np.abs(ref).max()), d.max()
+            else:      # Adam / Adagrad turn the last-bit differences of float-atomic sums into fractions of lr on a few elements
+                assert d.max() <= steps * lr and (d > steps * 5e-3 * lr).mean() <= 0.02, (d.max(), (d > steps * 5e-3 * lr).mean())
     assert np.array_equal(res[0]['W'], res[1]['W']) and np.array_equal(res[0]['b'], res[1]['b'])     # replicas stay identical
+    for k in range(2 * (NL - 1)):
+        assert np.array_equal(res[0]['x%d' % k], res[1]['x%d' % k])
 
 
 # ------------------------------------------------------------------------------------------------ the CLI on two ranks
