@@ -1895,7 +1895,7 @@ extern "C" int dccf_train_step(dccf_ctx* ctx, const dccf_model_t* M, const dccf_
       G->touchedV && knobs().hostv) {
     for (int q = 0; q < opt->nseg; ++q)
       if (opt->p + opt->seg_begin[q] == M->V && opt->seg_rows[q] == M->item_num && opt->seg_width[q] == M->D &&
-          opt->seg_flags[q] == G->touchedV)
+          opt->seg_flags[q] == G->touchedV && (M->D == 16 || M->D == 32 || M->D == 64 || M->D == 128))
         plan.hostv_seg = q;
   }
   plan.X_next = (N > 0 && rank == 1) ? X_next : nullptr;

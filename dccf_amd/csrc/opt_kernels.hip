@@ -249,7 +249,19 @@ __device__ __forceinline__ void touched_rows(float* __restrict__ p, float* __res
 // Row-aware variant: g of a row whose "touched" byte is 0 is all zeros by construction -> not read, not re-zeroed.
 // A wave handles 64 consecutive float4 = 256 consecutive floats = whole rows (row widths 16..128 divide 256 and segments
 // start on a 256-float boundary), so every lane of a row sees the byte before the row's first lane clears it.
-template <int KIND, int UN, bool TO>
+// NT: non-temporal loads / stores of p, m, v — for buffers far beyond the 256 MiB Infinity Cache, where every byte is read once and
+// written once per launch and keeping lines in L2 / the LLC buys nothing (in-cache sizes are slower with it: DESIGN.md section 4)
+template <bool NT>
+__device__ __forceinline__ float4 opt_ld4(const float4* q) {
+  if (NT) return __builtin_nontemporal_load(q);
+  return *q;
+}
+template <bool NT>
+__device__ __forceinline__ void opt_st4(float4* q, const float4& v) {
+  if (NT) __builtin_nontemporal_store(v, q);
+  else *q = v;
+}
+template <int KIND, int UN, bool TO, bool NT = false>
 __global__ __launch_bounds__(256) void k_dense_opt_rows(float* __restrict__ p, float* __restrict__ g, float* __restrict__ s1,
                                                         float* __restrict__ s2, int64_t n, OptArgs a, RowSegs sg,
                                                         int phase, PrepNext pn) {
@@ -311,9 +323,9 @@ __global__ __launch_bounds__(256) void k_dense_opt_rows(float* __restrict__ p, f
           if (KIND == DCCF_OPT_ADAM) bv[u] = reinterpret_cast<const float4*>(s2)[ic];
         }
       } else {
-        pv[u] = reinterpret_cast<const float4*>(p)[ic];
-        if (KIND != DCCF_OPT_GD) av[u] = reinterpret_cast<const float4*>(s1)[ic];
-        if (KIND == DCCF_OPT_ADAM) bv[u] = reinterpret_cast<const float4*>(s2)[ic];
+        pv[u] = opt_ld4<NT>(reinterpret_cast<const float4*>(p) + ic);
+        if (KIND != DCCF_OPT_GD) av[u] = opt_ld4<NT>(reinterpret_cast<const float4*>(s1) + ic);
+        if (KIND == DCCF_OPT_ADAM) bv[u] = opt_ld4<NT>(reinterpret_cast<const float4*>(s2) + ic);
         touched[u] = fl[u] ? *fl[u] != 0 : true;
       }
     }
@@ -324,7 +336,7 @@ __global__ __launch_bounds__(256) void k_dense_opt_rows(float* __restrict__ p, f
       if (phase == OPT_PHASE_UNTOUCHED && (!fl[u] || touched[u])) continue;     // those wait for the backward (k_opt_touched)
       if (touched[u]) gv[u] = reinterpret_cast<float4*>(g)[i];
       opt_elem4<KIND>(pv[u], gv[u], av[u], bv[u], a);
-      reinterpret_cast<float4*>(p)[i] = pv[u];
+      opt_st4<NT>(reinterpret_cast<float4*>(p) + i, pv[u]);
       if (pn.blocks && i * 4 >= pn.w_begin && i * 4 < pn.w_end) {      // the forward's transposed copy of W, for the next step
         prep_next_wt(pn, i * 4, pv[u].x);
         prep_next_wt(pn, i * 4 + 1, pv[u].y);
@@ -332,8 +344,8 @@ __global__ __launch_bounds__(256) void k_dense_opt_rows(float* __restrict__ p, f
         prep_next_wt(pn, i * 4 + 3, pv[u].w);
       }
       if (touched[u]) reinterpret_cast<float4*>(g)[i] = make_float4(0, 0, 0, 0);
-      if (KIND != DCCF_OPT_GD) reinterpret_cast<float4*>(s1)[i] = av[u];
-      if (KIND == DCCF_OPT_ADAM) reinterpret_cast<float4*>(s2)[i] = bv[u];
+      if (KIND != DCCF_OPT_GD) opt_st4<NT>(reinterpret_cast<float4*>(s1) + i, av[u]);
+      if (KIND == DCCF_OPT_ADAM) opt_st4<NT>(reinterpret_cast<float4*>(s2) + i, bv[u]);
       if (fl[u] && touched[u] && first[u]) *fl[u] = 0;
     }
   }
@@ -393,7 +405,10 @@ int opt_make_job(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t
   sg.n = nseg;
   for (int q = 0; q < nseg; ++q) {
     const int w = seg_width[q];
-    ARG_CHECK(w == 16 || w == 32 || w == 64 || w == 128, "segment row width must be 16, 32, 64 or 128");
+    // 16 / 32 / 64 / 128: every form of the pass.  Any other multiple of 4 up to 128 (src/models/RecModel.py:17-27 accepts any
+    // embedding size): the row roles of the lazy optimizer (float4 slots of a row, integer arithmetic on the row number); the
+    // streaming row-aware pass — whole rows per wave, shifts — then runs as the plain dense pass (launch_job)
+    ARG_CHECK(w >= 4 && w <= 128 && w % 4 == 0, "segment row width must be a multiple of 4 in [4, 128]");
     ARG_CHECK(seg_begin[q] % 256 == 0 && seg_rows[q] >= 0 && seg_begin[q] + seg_rows[q] * w <= n && seg_flags[q],
               "segment must start on a 256-float boundary, lie inside the buffer and have flags");
     sg.begin[q] = seg_begin[q];
@@ -437,9 +452,22 @@ static int dense_complement(const RowSegs& sg, int64_t n, DenseSegs* ds, int64_t
   else if (kind == DCCF_OPT_ADAGRAD) hipLaunchKernelGGL(K<DCCF_OPT_ADAGRAD>, __VA_ARGS__);  \
   else hipLaunchKernelGGL(K<DCCF_OPT_ADAM>, __VA_ARGS__)
 
-static int launch_job(const OptJob& j, int phase, const int64_t* list, const int* cnt, int64_t max_rows, hipStream_t st,
+static bool tile_width(int w) { return w == 16 || w == 32 || w == 64 || w == 128; }
+
+static int launch_job(const OptJob& j0, int phase, const int64_t* list, const int* cnt, int64_t max_rows, hipStream_t st,
                       const PrepNext* pnp = nullptr) {
-  if (j.n == 0) return 0;
+  if (j0.n == 0) return 0;
+  OptJob j = j0;
+  bool general = false;
+  for (int q = 0; q < j.sg.n; ++q) general = general || !tile_width(j.sg.width[q]);
+  if (general) {
+    // row widths that are not a power of two: no "whole rows per wave" — the pass reads and re-zeroes the gradient everywhere
+    // (the plain dense step) and the rows' touched bytes are cleared wholesale
+    ARG_CHECK(phase == OPT_PHASE_ALL && j.sg.to_mask == 0, "the two-phase / hosted optimizer pass needs row widths of 16, 32, 64 or 128");
+    for (int q = 0; q < j.sg.n; ++q)
+      HIP_TRY(hipMemsetAsync(j.sg.flags[q], 0, (size_t)((j.sg.end[q] - j.sg.begin[q]) / j.sg.width[q]), st));
+    j.sg.n = 0;
+  }
   if (phase == OPT_PHASE_TOUCHED) {
     ARG_CHECK(list && cnt, "touched phase needs the row list");
     DenseSegs ds;
@@ -455,24 +483,37 @@ static int launch_job(const OptJob& j, int phase, const int64_t* list, const int
   }
   const int64_t work = (j.n + 3) / 4;
   // one float4 slot per thread at Electronics size (16384 workgroups): 61.5 -> 59.3 us against 4096 grid-striding workgroups
-  const int64_t gmax = getenv("DCCF_OPT_GRID") ? atoll(getenv("DCCF_OPT_GRID")) : 16384;
+  // (DCCF_OPT_TUNE=1: the knobs below are read at every launch — scripts/dense_opt_bench.py sweeps them in one process)
+  static const bool tune = getenv("DCCF_OPT_TUNE") != nullptr;
+  static const int64_t gmax0 = getenv("DCCF_OPT_GRID") ? atoll(getenv("DCCF_OPT_GRID")) : 16384;
+  static const int un0 = getenv("DCCF_OPT_UN") ? atoi(getenv("DCCF_OPT_UN")) : 2;
+  static const int nt0 = getenv("DCCF_OPT_NT") ? atoi(getenv("DCCF_OPT_NT")) : 0;
+  const int64_t gmax = tune && getenv("DCCF_OPT_GRID") ? atoll(getenv("DCCF_OPT_GRID")) : gmax0;
+  const int un_big = tune && getenv("DCCF_OPT_UN") ? atoi(getenv("DCCF_OPT_UN")) : un0;
+  const int nt_big = tune && getenv("DCCF_OPT_NT") ? atoi(getenv("DCCF_OPT_NT")) : nt0;
   PrepNext pn;
   memset(&pn, 0, sizeof(pn));
   if (pnp) pn = *pnp;
   const int grid = (int)min(gmax, (work + 255) / 256) + pn.blocks;
-#define OPT_ROWS_LAUNCH(KIND_, UN_, TO_) \
-  hipLaunchKernelGGL((k_dense_opt_rows<KIND_, UN_, TO_>), dim3(grid), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.n, j.a, j.sg, phase, pn)
-#define OPT_ROWS_KIND(UN_, TO_)                                               \
-  if (j.kind == DCCF_OPT_GD) OPT_ROWS_LAUNCH(DCCF_OPT_GD, UN_, TO_);           \
-  else if (j.kind == DCCF_OPT_ADAGRAD) OPT_ROWS_LAUNCH(DCCF_OPT_ADAGRAD, UN_, TO_); \
-  else OPT_ROWS_LAUNCH(DCCF_OPT_ADAM, UN_, TO_)
+#define OPT_ROWS_LAUNCH(KIND_, UN_, TO_, NT_) \
+  hipLaunchKernelGGL((k_dense_opt_rows<KIND_, UN_, TO_, NT_>), dim3(grid), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.n, j.a, j.sg, phase, pn)
+#define OPT_ROWS_KIND4(UN_, TO_, NT_)                                               \
+  if (j.kind == DCCF_OPT_GD) OPT_ROWS_LAUNCH(DCCF_OPT_GD, UN_, TO_, NT_);           \
+  else if (j.kind == DCCF_OPT_ADAGRAD) OPT_ROWS_LAUNCH(DCCF_OPT_ADAGRAD, UN_, TO_, NT_); \
+  else OPT_ROWS_LAUNCH(DCCF_OPT_ADAM, UN_, TO_, NT_)
+#define OPT_ROWS_KIND(UN_, TO_) OPT_ROWS_KIND4(UN_, TO_, false)
   // TO: a segment in "only the marked rows" mode (its other rows were updated by the pass hosted in the backward launch)
   if (j.n >= 100000000LL) {
-    if (j.sg.to_mask) { OPT_ROWS_KIND(2, true); } else { OPT_ROWS_KIND(2, false); }
+    // buffers far beyond the Infinity Cache: more independent p / m / v triples in flight per lane, optionally non-temporal
+    if (j.sg.to_mask) { OPT_ROWS_KIND(2, true); }
+    else if (un_big >= 4) { if (nt_big) { OPT_ROWS_KIND4(4, false, true); } else { OPT_ROWS_KIND4(4, false, false); } }
+    else if (un_big <= 1) { if (nt_big) { OPT_ROWS_KIND4(1, false, true); } else { OPT_ROWS_KIND4(1, false, false); } }
+    else { if (nt_big) { OPT_ROWS_KIND4(2, false, true); } else { OPT_ROWS_KIND4(2, false, false); } }
   } else {
     if (j.sg.to_mask) { OPT_ROWS_KIND(1, true); } else { OPT_ROWS_KIND(1, false); }
   }
 #undef OPT_ROWS_KIND
+#undef OPT_ROWS_KIND4
 #undef OPT_ROWS_LAUNCH
   HIP_TRY(hipGetLastError());
   return 0;

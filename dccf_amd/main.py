@@ -95,7 +95,7 @@ def main(argv=None):
     else:
         logging.basicConfig(filename=os.devnull, level=logging.WARNING)
     if world > 1:
-        logging.info('# ranks: %d (one process per GPU, replicated data-parallel training)' % world)
+        logging.info('# ranks: %d (one process per GPU, %s data-parallel training)' % (world, getattr(args, 'mp', 'replicated')))
     logging.info(vars(init_args))
     logging.info(vars(args))
     for what, v in (('DataLoader', init_args.data_loader), ('Model', init_args.model_name),
@@ -130,7 +130,7 @@ def main(argv=None):
     runner = runner_cls(optimizer=args.optimizer, learning_rate=args.lr, epoch=args.epoch, batch_size=args.batch_size,
                         eval_batch_size=args.eval_batch_size, dropout=args.dropout, l2=args.l2, metrics=args.metric,
                         check_epoch=args.check_epoch, early_stop=args.early_stop, fused_sampling=args.fused_sampling,
-                        use_graph=args.use_graph, device_eval=args.device_eval, overlap_opt=args.overlap_opt)
+                        use_graph=args.use_graph, device_eval=args.device_eval, overlap_opt=args.overlap_opt, mp=args.mp)
     logging.info('Test Before Training = ' + utils.format_metric(
         runner.evaluate(model, data_processor.get_test_data(), data_processor)) + ' ' + ','.join(runner.metrics))
     if args.load > 0:

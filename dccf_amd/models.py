@@ -143,6 +143,14 @@ class BaseModel(object):
     def parameters(self):
         return list(self.params.values())
 
+    def views_of(self, flat):
+        """The per-parameter views of a flat tensor laid out like flat_p (an optimizer's state buffer), by parameter name."""
+        out = OrderedDict()
+        for name, v in self.params.items():
+            o = self.offsets[name]
+            out[name] = flat[o:o + v.numel()].view(v.shape)
+        return out
+
     def named_parameters(self):
         return list(self.params.items())
 
@@ -467,11 +475,14 @@ class DCCF(DMF):
         self.touchedU = torch.zeros((self.user_num + 3) // 4 * 4, dtype=torch.uint8, device=self.device)[:self.user_num]
         self.touchedV = torch.zeros((self.item_num + 3) // 4 * 4, dtype=torch.uint8, device=self.device)[:self.item_num]
         D = self.ui_vector_size
-        if D in (16, 32, 64, 128):
+        if D % 4 == 0 and 4 <= D <= 128:
+            # 16 / 32 / 64 / 128: every form of the optimizer pass.  Other multiples of 4 (src/models/RecModel.py:17-27 accepts any
+            # size): the windowed lazy regularisation of train_step works on rows of any such width; dense calls on these segments
+            # run the plain dense pass
             self.row_segments = [(self.offsets['uid_embeddings.weight'], self.user_num, D, self.touchedU),
                                  (self.offsets['iid_embeddings.weight'], self.item_num, D, self.touchedV)]
-        else:        # any other width (src/models/RecModel.py:17-27): the row-aware optimizer wants power-of-two rows; the
-            self.row_segments = []     # plain dense step (gradient read and re-zeroed everywhere) takes over
+        else:        # rows that are not whole float4 slots (D = 7 ...): no row segments, the plain dense step throughout
+            self.row_segments = []
             self.touchedU = self.touchedV = None
 
     def _struct(self):

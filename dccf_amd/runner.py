@@ -43,13 +43,22 @@ class BaseRunner(object):
                             help='1: the optimizer pass over the embedding rows a DCCF batch does not touch runs on a '
                                  'low-priority side stream beside forward/backward (dccf_train_step overlap); measured '
                                  '+5 %% at batch 128 only with DCCF_SIDE_CUS=128 and a non-default stream, hence off')
+        parser.add_argument('--mp', type=str, default='replicated',
+                            help='layout of a multi-GPU run (python -m torch.distributed.run --nproc-per-node G -m dccf_amd.main ...): '
+                                 'replicated = every GPU holds the whole model, one all-gather of the touched gradient rows per step; '
+                                 'sharded = embedding rows, optimizer state, feature rows and the rows of the exposure matrix are '
+                                 'sharded by row mod G, all-to-all row exchange + all-reduce of the dense weights per step')
         parser.add_argument('--use_graph', type=int, default=0,
                             help='1: replay each DCCF training step as one hipGraph (needs --fused_sampling 1); measured '
                                  'slower than eager launches at batch 128 on MI355X (graph-launch floor), hence off')
         return parser
 
     def __init__(self, optimizer='GD', learning_rate=0.01, epoch=100, batch_size=128, eval_batch_size=128 * 128,
-                 dropout=0.2, l2=1e-5, metrics='RMSE', check_epoch=10, early_stop=1, fused_sampling=1, use_graph=0, device_eval=1, overlap_opt=0):
+                 dropout=0.2, l2=1e-5, metrics='RMSE', check_epoch=10, early_stop=1, fused_sampling=1, use_graph=0, device_eval=1, overlap_opt=0,
+                 mp='replicated'):
+        if mp not in ('replicated', 'sharded'):
+            raise ValueError('--mp must be replicated or sharded')
+        self.mp = mp
         self.optimizer_name, self.learning_rate, self.epoch = optimizer, learning_rate, epoch
         self.batch_size, self.eval_batch_size = batch_size, eval_batch_size
         self.dropout, self.no_dropout, self.l2_weight = dropout, 0.0, l2
@@ -104,6 +113,8 @@ class BaseRunner(object):
         if model.optimizer is None:
             model.optimizer = self._build_optimizer(model)
         if utils.world_size() > 1:
+            if self.mp == 'sharded':
+                return self._fit_sharded(model, data_processor, epoch)
             return self._fit_replicated(model, data_processor, epoch)
         model.train()
         out = None
@@ -188,16 +199,109 @@ class BaseRunner(object):
         # no Philox word twice: the trainer's words of this epoch start after everything the model's call counter handed out
         tr.word_base = model._call + 1 - tr.t * G
         loss = None
+        # first contact with the peers (the first collectives of the job) under a host-side deadline: a hang exits non-zero
+        first = not getattr(tr, '_met_peers', False)
+        dl = utils.Deadline(float(os.environ.get('DCCF_WARMUP_DEADLINE_S', '420')) if first else 0, 'the first replicated multi-rank step')
         for j in range(ns):
             _, loss = tr.train_step(sched[j, rank], y, pred, X_all=sched[j], X_all_next=sched[j + 1] if j + 1 < ns else None)
+            if j == 0 and first:
+                torch.cuda.synchronize()
+                dl.cancel()
         if last is not None:         # the rest of the epoch: one step of equal shares
             b = last.shape[1] // 2
             yl = torch.cat([torch.ones(b, device=dev), torch.zeros(b, device=dev)])
             pred = torch.empty(2 * b, dtype=torch.float32, device=dev)
             _, loss = tr.train_step(last[rank], yl, pred, X_all=last)
+        dl.cancel()
+        tr._met_peers = True
+        tr.flush()
+        if not tr.crosscheck_replicas():        # (stderr has the details; every rank resynchronised from rank 0)
+            logging.warning('replicas differed after epoch %d: resynchronised from rank 0, synchronous step from here on' % epoch)
+        o.t = tr.t
+        model._call = tr.word_base + tr.t * G        # every word below is used
+        data_processor._dev.check_negatives()
+        model.eval()
+        return {'prediction': pred, 'check': [('prediction', pred)], 'loss': loss[0] if loss is not None else model._loss[0]}
+
+    def _fit_sharded(self, model, data_processor, epoch):
+        """One epoch on the G GPUs of a node in the ROW-SHARDED layout (--mp sharded; dccf_amd/sharded.py; no reference
+        counterpart: src/main.py:106,153-155 is single-GPU).  Rank r trains with — and holds the optimizer state of — the embedding
+        rows r, r + G, ...; the feature rows and the rows of the exposure matrix (or the IPS factors) of those rows live with
+        them; W, b and the extra layers are replicated.  Same schedule as the replicated layout: optimizer step j trains batches
+        j G .. j G + G - 1 of the epoch as ONE step on their union (the reference's step at batch size G x --batch_size), what
+        does not divide is one more step of equal shares.  GD / Adagrad / Adam, --n_layers 1 .. 8, any embedding size up to 128.
+        After the epoch every rank gathers the tables into its model (one all-gather per table) and evaluates for itself — the
+        gathered replicas are identical, so the ranks take the same checkpoint / early-stopping decisions; rank 0 writes files."""
+        import torch.distributed as dist
+        from dccf_amd import sharded, replicated
+        G, rank, B = dist.get_world_size(), dist.get_rank(), self.batch_size
+        o = model.optimizer
+        p = model.params
+        names = ['uid_embeddings.weight', 'iid_embeddings.weight', 'mlp.0.weight', 'mlp.0.bias']
+        tr = getattr(model, '_sharded', None)
+        first = tr is None
+        if first:
+            if getattr(model, 'kind', '') != 'DCCF' or not self.fused_sampling or data_processor.rank != 1:
+                raise RuntimeError('training on several GPUs covers --model_name DCCF --rank 1 --fused_sampling 1')
+            o.flush()
+            dev = model.device
+            ips_local, expo_local = None, None
+            if model.expo_prob is not None:          # the dense <ds>.ips_expo_prob.npy: this rank keeps the rows of its users
+                expo_local = model.expo_prob[rank::G].contiguous()
+            else:
+                f = model.ips_factors
+                ips_local = dict(P=f['P'][rank::G].contiguous(), bu=f['bu'][rank::G].contiguous(), Q=f['Q'][rank::G].contiguous(),
+                                 bi=f['bi'][rank::G].contiguous(), prop=f['prop'][rank::G].contiguous(), b0=f['b0'], M=f['M'])
+            tr = sharded.ShardedDCCF(rank, G, model.user_num, model.item_num, model.ui_vector_size, model.sample_num,
+                                     model.attribute_num, model.std, self.dropout, o.lr, o.l2, model.random_seed,
+                                     sharded.HipBackend(dev), dev, model.feature_embedding[rank::G].contiguous(), ips_local,
+                                     expo_local=expo_local, opt_name=o.name, n_layers=model.n_layers)
+            tr.set_global_params(p[names[0]], p[names[1]], p[names[2]], p[names[3]], extra=model._extra(p))
+            for full, mine in ((o.s1, tr.s1), (o.s2, tr.s2)):        # the optimizer's state so far (zeros in a fresh run)
+                if full is None:
+                    continue
+                mv, tv = model.views_of(full), tr.views_of(mine)
+                tv[0].copy_(mv[names[0]][rank::G])
+                tv[1].copy_(mv[names[1]][rank::G])
+                for dst, name in zip(tv[2:], list(mv)[2:]):
+                    dst.copy_(mv[name])
+            tr.t = o.t
+            logging.info('# row-sharded training on %d ranks, collectives: %s' % (G, tr.crosscheck_collectives()))
+            model._sharded = tr
+            o.lazy = None                   # the trainer owns the parameters between the gathers
+        model.train()
+        full, tail = data_processor.device_epoch(max(epoch, 0), B)
+        dev = full.device
+        sched, last = replicated.epoch_schedule(full, tail, G)
+        ns = sched.shape[0]
+        # no Philox word twice: two words for the candidate streams of the epoch's two plans, then G words per optimizer step,
+        # all after everything the model's call counter handed out (evaluation passes draw from it between the epochs)
+        c0 = model._call + 1
+        tr.word_base = c0 + 2 - tr.t * G
+        pred = loss = None
+        # first contact with the peers (the first collectives of the job) under a host-side deadline: a hang exits non-zero
+        dl = utils.Deadline(float(os.environ.get('DCCF_WARMUP_DEADLINE_S', '420')) if first else 0, 'the first row-sharded step')
+        if ns > 0:
+            tr.begin_epoch(sched, c0)
+            for k in range(ns):
+                pred, loss = tr.train_step(k)
+                if k == 0 and first:
+                    torch.cuda.synchronize()
+                    dl.cancel()
+        if last is not None:         # the rest of the epoch: one step of equal shares
+            tr.begin_epoch(last.unsqueeze(0).contiguous(), c0 + 1)
+            pred, loss = tr.train_step(0)
+        dl.cancel()
         tr.flush()
         o.t = tr.t
         model._call = tr.word_base + tr.t * G        # every word below is used
+        # every rank's model gets the whole tables back (evaluation, checkpoints, l2): W, b and the extra layers are replicated
+        tr.gather_tables(p[names[0]], p[names[1]])
+        p[names[2]].copy_(tr.W)
+        p[names[3]].copy_(tr.b)
+        for (w, bb), (w0, b0) in zip(model._extra(p), tr.extra):
+            w.copy_(w0)
+            bb.copy_(b0)
         data_processor._dev.check_negatives()
         model.eval()
         return {'prediction': pred, 'check': [('prediction', pred)], 'loss': loss[0] if loss is not None else model._loss[0]}

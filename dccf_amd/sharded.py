@@ -195,7 +195,7 @@ class ShardedDCCF(object):
         # optimizer step; the two shards are ONE segment (the padding rows between them are never flagged)
         n_rows = (pads[0] + pads[1]) // D
         self.touched = torch.zeros((n_rows + 3) // 4 * 4, dtype=torch.uint8, device=device)[:n_rows]
-        self.segments = [(0, n_rows, D, self.touched)] if D in (16, 32, 64, 128) else None
+        self.segments = [(0, n_rows, D, self.touched)] if (D % 4 == 0 and D >= 4) else None      # (rows of whole float4 slots)
         self.dense_begin = pads[0] + pads[1]
         self.g_dense = self.flat_g[self.dense_begin:]                       # [dW | db | dW_1 | db_1 ...] (+ zero padding), contiguous
         self.user_pad = torch.ones((max(self.nU, 1), 1), dtype=f32, device=device)           # the "prop" column of user rows
@@ -220,6 +220,11 @@ class ShardedDCCF(object):
                 print('[dccf_amd.sharded] direct RCCL communicator unavailable (%s): collectives go through torch.distributed' % e,
                       file=sys.stderr)
                 self.collectives = 'torch.distributed (no direct communicator: %s)' % e
+
+    def views_of(self, flat):
+        """[U shard, V shard, W, b, W_1, b_1, ...] as views of a flat tensor laid out like flat_p (the optimizer state buffers)."""
+        shapes = [(self.nU, self.D), (self.nI, self.D), (self.D, self.D + self.F), (self.D,)] + [(self.D, self.D), (self.D,)] * (self.n_layers - 1)
+        return [flat[o:o + n].view(shp) for o, n, shp in zip(self.offs, self.sizes, shapes)]
 
     def close(self):
         """Destroys the directly created RCCL communicator (before torch.distributed's process group goes away)."""

@@ -505,6 +505,57 @@ def gen_e2e(outdir):
             shutil.rmtree(tmp)
 
 
+def gen_e2e_init(outdir):
+    """The UNTRAINED model's validation metrics by the reference's own classes (what its `Init:` log line reports,
+    src/runners/BaseRunner.py:229-237), many seeds, without the rest of main.py's run: DataLoader -> DCCF -> init_paras ->
+    drop_neg -> DataProcessor -> BaseRunner.evaluate(validation), constructed as src/main.py:100-174 does.  One evaluation pass
+    per seed (~2 minutes on config 1's shape) instead of a whole run (~25): the statistical target for the evaluation path alone
+    (tests/test_e2e_gpu.py), where round 2 saw a +0.0013 offset at 2.6 standard errors with 11 reference seeds."""
+    import logging
+    from dccf_amd import synth
+    from data_loaders.DataLoader import DataLoader
+    from data_processor.DataProcessor import DataProcessor
+    from runners.BaseRunner import BaseRunner
+    from models.DCCF import DCCF
+    c = E2E
+    CAP.enabled = False
+    rec = {k: np.array(v) for k, v in c.items() if k != 'seeds'}
+    tmp = tempfile.mkdtemp()
+    cwd = os.getcwd()
+    done, vals = [], []
+    try:
+        os.makedirs(os.path.join(tmp, 'src'))
+        synth.write_dataset(os.path.join(tmp, 'dataset'), 'toy', c['user_num'], c['item_num'], c['n_draws'],
+                            feat_dim=c['feat_dim'], seed=c['data_seed'])
+        os.chdir(os.path.join(tmp, 'src'))
+        logging.basicConfig(level=logging.WARNING)
+        for seed in c['seeds']:
+            torch.manual_seed(seed)
+            np.random.seed(seed)
+            dl = DataLoader(path='../dataset/', dataset='toy', label='label', sep=',')
+            dl.feature_info(include_id=DCCF.include_id, include_item_features=DCCF.include_item_features,
+                            include_user_features=DCCF.include_user_features)
+            model = DCCF(path=dl.path, dataset=dl.dataset, sentence_model='paraphrase-distilroberta-base-v1', sample_num=10,
+                         attribute_num=2, std=0.1, label_min=dl.label_min, label_max=dl.label_max, feature_num=0,
+                         user_num=dl.user_num, item_num=dl.item_num, u_vector_size=c['D'], i_vector_size=c['D'], n_layers=1,
+                         random_seed=seed, model_path=os.path.join(tmp, 'm.pt'))
+            model.apply(model.init_paras)
+            dl.drop_neg()
+            dp = DataProcessor(dl, model, rank=1, test_neg_n=c['test_neg_n'])
+            runner = BaseRunner(optimizer='Adam', learning_rate=c['lr'], epoch=0, batch_size=c['batch_size'], eval_batch_size=128 * 128,
+                                dropout=0.2, l2=1e-4, metrics='ndcg@5,recall@5,precision@5', check_epoch=0, early_stop=1)
+            v = runner.evaluate(model, dp.get_validation_data(), dp)
+            print('seed', seed, 'untrained validation', v, flush=True)
+            done.append(seed)
+            vals.append([float(x) for x in v])
+            rec['seeds'] = np.array(done)
+            rec['init_valid'] = np.array(vals)
+            np.savez_compressed(os.path.join(outdir, os.environ.get('E2E_OUT', 'e2e_init.npz')), **rec)
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp)
+
+
 if __name__ == '__main__':
     install_shims()
     which = sys.argv[1:] or ['dccf', 'mf', 'opt', 'batches', 'metrics']
@@ -524,3 +575,5 @@ if __name__ == '__main__':
         gen_dccf_ext(HERE)
     if 'e2e' in which:
         gen_e2e(HERE)
+    if 'e2e_init' in which:
+        gen_e2e_init(HERE)

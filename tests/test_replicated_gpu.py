@@ -296,7 +296,7 @@ def _sharded_rank_main(rank, world, port, out, lazy_K, case):
         pred, loss = tr.train_step(step)
         preds.append(pred.cpu().numpy().copy())
         losses.append(float(loss))
-    assert (tr.lazy is not None) == (lazy_K >= 2 and c['D'] in (16, 32, 64, 128))
+    assert (tr.lazy is not None) == (lazy_K >= 2 and c['D'] % 4 == 0)
     tr.flush()                 # rows the lazy regularisation left behind are brought up to date before anybody looks
     torch.cuda.synchronize()
     extra = {'x%d' % k: t.cpu().numpy() for k, t in enumerate(x for wb in tr.extra for x in wb)}
@@ -397,8 +397,11 @@ def _cli_rank_main(rank, world, port, tmp, cfg):
     dist.destroy_process_group()
 
 
-def test_cli_on_two_ranks(tmp_path):
-    """dccf_amd.main under a two-rank launch (src/main.py:24-195 is single-GPU: new capability behind the same flags), on the
+@pytest.mark.parametrize('layout', ['replicated', 'sharded'])
+def test_cli_on_two_ranks(tmp_path, layout):
+    """(layout: --mp replicated, the default, or --mp sharded — embedding rows, optimizer state, feature rows and the rows of the
+    dense exposure file sharded by row mod 2, all-to-all row exchange, tables gathered back for the evaluation.)
+    dccf_amd.main under a two-rank launch (src/main.py:24-195 is single-GPU: new capability behind the same flags), on the
     dataset and hyper-parameters of the reference's own main.py runs (tests/golden/e2e.npz) with --batch_size halved: every
     optimizer step trains the two ranks' batches as ONE step, i.e. the reference's step at its batch size — the seed-averaged
     validation NDCG@5 of every epoch must agree with the reference's runs like the single-GPU CLI does.  The replicas —
@@ -413,7 +416,7 @@ def test_cli_on_two_ranks(tmp_path):
     synth.write_dataset(os.path.join(tmp, 'dataset'), 'toy', int(g['user_num']), int(g['item_num']), int(g['n_draws']),
                         feat_dim=int(g['feat_dim']), seed=int(g['data_seed']))
     cfg = dict(lr=float(g['lr']), epochs=int(g['epochs']), test_neg_n=int(g['test_neg_n']), D=int(g['D']),
-               batch_size=int(g['batch_size']))
+               batch_size=int(g['batch_size']), more=['--mp', layout])
     from conftest import free_port
     port = free_port()
     mp.spawn(_cli_rank_main, args=(2, port, tmp, cfg), nprocs=2, join=True)
@@ -445,14 +448,15 @@ def test_cli_on_two_ranks(tmp_path):
             'epoch %d: two ranks %.4f vs reference %.4f (se %.4f)' % (e + 1, mine[:, e].mean(), ref[:, e].mean(), se)
 
 
-def test_cli_on_two_ranks_extra_layers_adagrad(tmp_path):
-    """The same launch with --n_layers 2 --optimizer Adagrad and a batch size that leaves the epoch's schedule uneven: the extra
+@pytest.mark.parametrize('layout', ['replicated', 'sharded'])
+def test_cli_on_two_ranks_extra_layers_adagrad(tmp_path, layout):
+    """The same launch (both layouts) with --n_layers 2 --optimizer Adagrad and a batch size that leaves the epoch's schedule uneven: the extra
     layers travel in the dense tail of the exchange, the replicas stay identical and the checkpoint holds all six tensors."""
     import torch.multiprocessing as mp
     from dccf_amd import synth
     tmp = str(tmp_path)
     synth.write_dataset(os.path.join(tmp, 'dataset'), 'toy', 300, 200, 5000, feat_dim=32, seed=3)
-    cfg = dict(lr=0.01, epochs=2, test_neg_n=50, D=16, batch_size=96, seeds=[7], optimizer='Adagrad', more=['--n_layers', '2'])
+    cfg = dict(lr=0.01, epochs=2, test_neg_n=50, D=16, batch_size=96, seeds=[7], optimizer='Adagrad', more=['--n_layers', '2', '--mp', layout])
     from conftest import free_port
     mp.spawn(_cli_rank_main, args=(2, free_port(), tmp, cfg), nprocs=2, join=True)
     r0, r1 = (dict(np.load(os.path.join(tmp, 'cli%d.npz' % r))) for r in range(2))
