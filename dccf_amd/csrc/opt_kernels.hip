@@ -251,15 +251,23 @@ __device__ __forceinline__ void touched_rows(float* __restrict__ p, float* __res
 // start on a 256-float boundary), so every lane of a row sees the byte before the row's first lane clears it.
 // NT: non-temporal loads / stores of p, m, v — for buffers far beyond the 256 MiB Infinity Cache, where every byte is read once and
 // written once per launch and keeping lines in L2 / the LLC buys nothing (in-cache sizes are slower with it: DESIGN.md section 4)
+typedef float opt_f4v __attribute__((ext_vector_type(4)));      // (the nontemporal builtins take clang vectors, not HIP's float4 struct)
 template <bool NT>
 __device__ __forceinline__ float4 opt_ld4(const float4* q) {
-  if (NT) return __builtin_nontemporal_load(q);
+  if (NT) {
+    const opt_f4v v = __builtin_nontemporal_load(reinterpret_cast<const opt_f4v*>(q));
+    return make_float4(v.x, v.y, v.z, v.w);
+  }
   return *q;
 }
 template <bool NT>
 __device__ __forceinline__ void opt_st4(float4* q, const float4& v) {
-  if (NT) __builtin_nontemporal_store(v, q);
-  else *q = v;
+  if (NT) {
+    const opt_f4v w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<opt_f4v*>(q));
+  } else {
+    *q = v;
+  }
 }
 template <int KIND, int UN, bool TO, bool NT = false>
 __global__ __launch_bounds__(256) void k_dense_opt_rows(float* __restrict__ p, float* __restrict__ g, float* __restrict__ s1,
