@@ -139,7 +139,9 @@ int dccf_opt_untouched_prep(const void* o, uint8_t* const* flags, const PrepNext
 // windowed lazy regularisation (dccf_opt_t.lazy_K > 0): the rows of the running step (X, cand, first global row of the user /
 // item segment) are claimed, listed and brought up to step - 1; then the step's optimizer launch
 int dccf_lazy_catchup(const void* o, const int64_t* X, const int* cand, int64_t N, int S1, int segU, int segV, hipStream_t st);
-int dccf_lazy_step(const void* o, const PrepNext* pn, int64_t nslots, hipStream_t st, const GwPart* gp = nullptr);      // nslots = N (S + 2) of the catch-up
+// nslots = N (S + 2) of the catch-up; win_from >= 0: the window role starts at that global row (the rows of the step's window
+// before it were advanced by workgroups hosted in the forward launch, LazyHost)
+int dccf_lazy_step(const void* o, const PrepNext* pn, int64_t nslots, hipStream_t st, const GwPart* gp = nullptr, int64_t win_from = -1);
 // claims somebody made for `step` (pn.cu_blocks of the previous launch) for a batch that did not come: forgotten
 int dccf_lazy_reset_claims(const void* o, hipStream_t st);
 // replicated multi-GPU path (dp_kernels.hip): rows flagged in (flags0, flags1) of segments (seg0, seg1) claimed + caught up;

@@ -39,6 +39,8 @@ struct Knobs {
   bool lazy_cu;           // DCCF_LAZY_NO_CU=1 the lazy optimizer launch does not catch up the next step's rows (a launch of its own does)
   bool gw_part;           // DCCF_NO_GW_PART=1 dW of a lazy step as float atomics into gW (not per-split partial sums)
   int64_t lazy_cu_blocks; // DCCF_LAZY_CU_BLOCKS workgroups of the next-step catch-up role (256: 128 / 512 / 768 measured, no better)
+  double lazy_host_frac;  // DCCF_LAZY_HOST_FRAC share of a lazy step's window advanced by idle workgroup slots of the forward launch (0: off)
+  int64_t lazy_host_blocks; // DCCF_LAZY_HOST_BLOCKS cap on those workgroups (default: every CU the tiles leave idle)
 };
 static const Knobs& knobs() {
   static const Knobs k = [] {
@@ -51,6 +53,8 @@ static const Knobs& knobs() {
     q.lazy_cu = getenv("DCCF_LAZY_NO_CU") == nullptr;
     q.gw_part = getenv("DCCF_NO_GW_PART") == nullptr;
     q.lazy_cu_blocks = getenv("DCCF_LAZY_CU_BLOCKS") ? max(1, atoi(getenv("DCCF_LAZY_CU_BLOCKS"))) : 256;
+    q.lazy_host_frac = getenv("DCCF_LAZY_HOST_FRAC") ? atof(getenv("DCCF_LAZY_HOST_FRAC")) : 0.0;
+    q.lazy_host_blocks = getenv("DCCF_LAZY_HOST_BLOCKS") ? max(1, atoi(getenv("DCCF_LAZY_HOST_BLOCKS"))) : 256;
     return q;
   }();
   return k;
@@ -223,7 +227,16 @@ __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT,
                                                    float* __restrict__ m, int64_t L, int S1,
                                                    int A, int F, rng_key nkey, rng_key dkey, float nscale,
                                                    uint32_t drop_thr, float kscale, StepRef sr, int store_h,
-                                                   float* __restrict__ zero1, int Dr_, int npass) {
+                                                   float* __restrict__ zero1, int Dr_, int npass, int tile_blocks, LazyHost lh) {
+  // workgroups past the tiles (lazy training step at small batches: 176 tiles leave 80 CUs idle): the head of this step's lazy
+  // window, advanced here instead of in the optimizer launch that follows (opt_device.hpp: LazyHost)
+  if (MODE == 0 && !GEN && !MP && lh.blocks && (int)blockIdx.x >= tile_blocks) {
+    const int bid = (int)blockIdx.x - tile_blocks;
+    if (lh.kind == DCCF_OPT_GD) lazy_hosted_window<DCCF_OPT_GD>(lh, bid, 512);
+    else if (lh.kind == DCCF_OPT_ADAGRAD) lazy_hosted_window<DCCF_OPT_ADAGRAD>(lh, bid, 512);
+    else lazy_hosted_window<DCCF_OPT_ADAM>(lh, bid, 512);
+    return;
+  }
   const int Dr = GEN ? Dr_ : D_;
   extern __shared__ float zpart[];   // [8][32][DW]
   TRACE(0);
@@ -274,7 +287,7 @@ __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT,
   const bool dv = lane < DW && dcol < Dr;
   const float bias_d = bias[dv ? dcol : 0];
   TRACE(1);
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += tile_blocks) {
     // epilogue operands of this wave's 4 rows: independent of the k-loop, fetched first.
     // !GEN: the wave takes the CONSECUTIVE rows 4 wave .. 4 wave + 3 — ONE Philox call per lane (= column) then yields the
     // dropout draws of all four (a call covers 4 consecutive rows of a column), kept as four wave-uniform column masks — and in
@@ -1523,6 +1536,8 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
   const bool prepared = train && !(plan && plan->overlap) && dccf_prep_matches(ctx, M, rnd, X, N);
   // hosted item table (dccf_train_step, no other overlap mode): two sets of "item row touched" bytes owned by the context
   const bool lazy = plan && train && plan->lazy_segU >= 0;
+  const bool det_mode = ctx->det && train && !ctx->slot_where;
+  int64_t lazy_win_from = -1;     // >= 0: the head of this step's lazy window was advanced by workgroups of the forward launch
   int gw_splits = 0;         // > 0: this step's backward left dW as that many partial sums in ctx->gw_part (GwPart)
   const bool hostv = plan && !plan->overlap && plan->hostv_seg >= 0 && train && !lazy;
   if (hostv) {
@@ -1591,7 +1606,20 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
   {
     // one forward kernel for every size: the evenly split K loop is as fast as a rows-per-wave variant at eval size
     // (0.333 vs 0.330 ms at B = 4096, 24.4 vs 24.2 M eval rows/s) and has no tile-count quantisation in between
-    const dim3 grid((unsigned)min((int64_t)1024, ntiles), y.GY), block(512);
+    const int tile_blocks = (int)min((int64_t)1024, ntiles);
+    // lazy training step, small batch: the tiles leave CUs idle (176 tiles at B = 128) — their workgroup slots advance the head
+    // of this step's lazy window (the claims of the step are complete: the previous optimizer launch or k_lazy_catchup made them)
+    LazyHost lh;
+    memset(&lh, 0, sizeof(lh));
+    lazy_win_from = -1;
+    if (lazy && fused && y.GY == 1 && D == y.DT && y.FP <= 896 && tile_blocks < 256 && knobs().lazy_host_frac > 0.0 && !det_mode) {
+      if (int e = dccf_lazy_host_args(plan->opt, &lh)) return e;
+      const int64_t span = (int64_t)((double)(lh.win1 - lh.win0) * knobs().lazy_host_frac);
+      lh.win1 = lh.win0 + span;
+      lh.blocks = span > 0 ? (int)min((int64_t)(256 - tile_blocks), (int64_t)knobs().lazy_host_blocks) : 0;
+      if (lh.blocks > 0) lazy_win_from = lh.win1;
+    }
+    const dim3 grid((unsigned)(tile_blocks + lh.blocks), y.GY), block(512);
     const size_t smem = (size_t)8 * 32 * y.ND * 32 * 4;
     prof_begin(ctx, st);
 #define LAUNCH_FWD3(D_, MODE_, NCM_, FAL_, MP_, GEN_)                                                                 \
@@ -1603,7 +1631,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     }                                                                                                                \
     hipLaunchKernelGGL((k_noise_fwd<D_, MODE_, NCM_, FAL_, MP_, GEN_>), grid, block, smem, st, WT, M->b, M->U, M->V, M->feat, X, cand, \
                        rnd->noise, rnd->keep, hbuf, m, y.L, S1, A, F, nkey, dkey, nscale, thr, kscale, sr,          \
-                       (train || NX > 0) ? 1 : 0, prepared ? loss : (float*)nullptr, D, y.FP / 768);                 \
+                       (train || NX > 0) ? 1 : 0, prepared ? loss : (float*)nullptr, D, y.FP / 768, tile_blocks, lh); \
   }
 #define LAUNCH_FWD2(D_, MODE_)                                                                          \
   if (D != D_) { if (y.FP == 768) LAUNCH_FWD3(D_, MODE_, 6, false, false, true) else LAUNCH_FWD3(D_, MODE_, 6, false, true, true) } \
@@ -1838,7 +1866,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
           pn.cu_segU = plan->lazy_segU;
           pn.cu_segV = plan->lazy_segV;
         }
-        if (int e = dccf_lazy_step(plan->opt, &pn, N * (int64_t)(S1 + 1), st, &gp)) return e;
+        if (int e = dccf_lazy_step(plan->opt, &pn, N * (int64_t)(S1 + 1), st, &gp, lazy_win_from)) return e;
         dccf_prep_next_commit(ctx, M, N, plan->X_next, rnd->seed, plan->step_next);
         if (pn.cu_blocks) {
           ctx->lazy_prep_step = (int64_t)plan->opt->step + 1;
@@ -1846,7 +1874,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
           ctx->lazy_prep_id = plan->opt->lazy_id;
         }
       } else {
-        if (int e = dccf_lazy_step(plan->opt, nullptr, N * (int64_t)(S1 + 1), st, &gp)) return e;
+        if (int e = dccf_lazy_step(plan->opt, nullptr, N * (int64_t)(S1 + 1), st, &gp, lazy_win_from)) return e;
       }
     } else if (plan->overlap) {
       if (!plan->hosted) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));

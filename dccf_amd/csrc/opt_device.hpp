@@ -341,6 +341,25 @@ __device__ __forceinline__ void lazy_window_pass(float* __restrict__ p, float* _
   }
 }
 
+// Part of a lazy step's window hosted as extra workgroups of ANOTHER launch of the same step (the forward: at batch 128 its 176
+// tiles leave 80 of the 256 CUs idle): rows [win0, win1) of the step's window are advanced to the step there, and the optimizer
+// launch that follows starts its own window role at win1.  The marks stay with the NEXT optimizer launch, as for the whole window.
+struct LazyHost {
+  float *p, *s1, *s2;
+  OptArgs a;
+  RowSegs sg;
+  LazyArgs z;
+  int64_t win0, win1;        // the hosted sub-window (global rows)
+  int kind, blocks;          // blocks == 0: nothing hosted
+};
+// fills everything but blocks / the sub-window's end (win1 = the end of the step's whole window on return)
+int dccf_lazy_host_args(const void* o, LazyHost* out);
+template <int KIND>
+__device__ __forceinline__ void lazy_hosted_window(const LazyHost& h, int bid, int nthreads) {
+  lazy_window_pass<KIND>(h.p, h.s1, h.s2, h.a, h.sg, h.z, h.win0, h.win1, 0, bid, h.blocks, nthreads,
+                         reinterpret_cast<const float4*>(h.z.scal), (int)h.z.t0);
+}
+
 // opt_kernels.hip: validation + bias corrections (host side) of one optimizer step
 int opt_make_job(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t n, float lr, float wd, float l2, float clip,
                  int64_t step, const int64_t* k_dev, int32_t nseg, const int64_t* seg_begin, const int64_t* seg_rows,

@@ -493,10 +493,18 @@ static int launch_job(const OptJob& j0, int phase, const int64_t* list, const in
   // one float4 slot per thread at Electronics size (16384 workgroups): 61.5 -> 59.3 us against 4096 grid-striding workgroups
   // (DCCF_OPT_TUNE=1: the knobs below are read at every launch — scripts/dense_opt_bench.py sweeps them in one process)
   static const bool tune = getenv("DCCF_OPT_TUNE") != nullptr;
-  static const int64_t gmax0 = getenv("DCCF_OPT_GRID") ? atoll(getenv("DCCF_OPT_GRID")) : 16384;
-  static const int un0 = getenv("DCCF_OPT_UN") ? atoi(getenv("DCCF_OPT_UN")) : 2;
-  static const int nt0 = getenv("DCCF_OPT_NT") ? atoi(getenv("DCCF_OPT_NT")) : 0;
-  const int64_t gmax = tune && getenv("DCCF_OPT_GRID") ? atoll(getenv("DCCF_OPT_GRID")) : gmax0;
+  // Buffers far beyond the 256 MiB Infinity Cache (p + m + v of 1e8 parameters = 1.2 GB): ONE float4 slot per thread — no grid
+  // stride —, non-temporal loads and stores: 6.28 TB/s = 78.5 % of the 8 TB/s peak on 268 M parameters = the box's copy rate
+  // (profiles/r03_dense_opt_bench.json; 2 or 4 slots in flight per lane, default-policy accesses or a capped grid: 5.1-5.7 TB/s).
+  // In-cache sizes keep the capped grid and the default policy (non-temporal is slower there: DESIGN.md section 4).
+  static const int64_t gmax_env = getenv("DCCF_OPT_GRID") ? atoll(getenv("DCCF_OPT_GRID")) : 0;
+  static const int un0 = getenv("DCCF_OPT_UN") ? atoi(getenv("DCCF_OPT_UN")) : 1;
+  static const int nt0 = getenv("DCCF_OPT_NT") ? atoi(getenv("DCCF_OPT_NT")) : 1;
+  static const int64_t big0 = getenv("DCCF_OPT_BIG_N") ? atoll(getenv("DCCF_OPT_BIG_N")) : 100000000LL;
+  const int64_t big_n = tune && getenv("DCCF_OPT_BIG_N") ? atoll(getenv("DCCF_OPT_BIG_N")) : big0;
+  const bool big = j.n >= big_n && !j.sg.to_mask;
+  const int64_t gmax_dflt = big ? ((int64_t)1 << 24) : 16384;
+  const int64_t gmax = tune && getenv("DCCF_OPT_GRID") ? atoll(getenv("DCCF_OPT_GRID")) : (gmax_env ? gmax_env : gmax_dflt);
   const int un_big = tune && getenv("DCCF_OPT_UN") ? atoi(getenv("DCCF_OPT_UN")) : un0;
   const int nt_big = tune && getenv("DCCF_OPT_NT") ? atoi(getenv("DCCF_OPT_NT")) : nt0;
   PrepNext pn;
@@ -511,8 +519,7 @@ static int launch_job(const OptJob& j0, int phase, const int64_t* list, const in
   else OPT_ROWS_LAUNCH(DCCF_OPT_ADAM, UN_, TO_, NT_)
 #define OPT_ROWS_KIND(UN_, TO_) OPT_ROWS_KIND4(UN_, TO_, false)
   // TO: a segment in "only the marked rows" mode (its other rows were updated by the pass hosted in the backward launch)
-  if (j.n >= 100000000LL) {
-    // buffers far beyond the Infinity Cache: more independent p / m / v triples in flight per lane, optionally non-temporal
+  if (j.n >= big_n) {
     if (j.sg.to_mask) { OPT_ROWS_KIND(2, true); }
     else if (un_big >= 4) { if (nt_big) { OPT_ROWS_KIND4(4, false, true); } else { OPT_ROWS_KIND4(4, false, false); } }
     else if (un_big <= 1) { if (nt_big) { OPT_ROWS_KIND4(1, false, true); } else { OPT_ROWS_KIND4(1, false, false); } }
@@ -727,7 +734,7 @@ template <int KIND>
 __global__ __launch_bounds__(256) void k_lazy_opt(float* __restrict__ p, float* __restrict__ g, float* __restrict__ s1,
                                                   float* __restrict__ s2, OptArgs a, RowSegs sg, DenseSegs ds, LazyArgs z,
                                                   int lb, int db, int mb, int64_t win0, int64_t win1, int flush, int nslots,
-                                                  PrepNext pn, GwPart gp) {
+                                                  PrepNext pn, GwPart gp, int64_t winS) {
   // the step scalars of the steps this launch can replay (t - K + 1 .. t), copied to LDS once: the replay loops read them with
   // a broadcast ds_read instead of a global load per lane and step inside their dependent chains
   __shared__ float4 s_sct[LAZY_KMAX + 1];
@@ -879,7 +886,8 @@ __global__ __launch_bounds__(256) void k_lazy_opt(float* __restrict__ p, float* 
   bid -= db;
   const int wb = (int)gridDim.x - pn.blocks - pn.cu_blocks - lb - db - mb;
   if (bid < wb) {                              // ---- the window (unless the backward launch hosted it)
-    lazy_window_pass<KIND>(p, s1, s2, a, sg, z, win0, win1, flush, bid, wb, blockDim.x, s_sct, sct_base);
+    // (winS > win0: the head of the window was advanced by workgroups hosted in this step's forward launch)
+    lazy_window_pass<KIND>(p, s1, s2, a, sg, z, winS, win1, flush, bid, wb, blockDim.x, s_sct, sct_base);
     return;
   }
   bid -= wb;
@@ -1009,7 +1017,8 @@ int dccf_lazy_catchup_pairs(const void* ov, const int64_t* X, int64_t N, int seg
   return 0;
 }
 
-static int lazy_launch(const dccf_opt_t* o, int flush, const PrepNext* pnp, int64_t nslots, hipStream_t st, const GwPart* gpp = nullptr) {
+static int lazy_launch(const dccf_opt_t* o, int flush, const PrepNext* pnp, int64_t nslots, hipStream_t st, const GwPart* gpp = nullptr,
+                       int64_t win_from = -1) {
   OptJob j;
   if (int e = opt_job(o, &j)) return e;
   LazyArgs z;
@@ -1029,7 +1038,8 @@ static int lazy_launch(const dccf_opt_t* o, int flush, const PrepNext* pnp, int6
   const int lb = (flush || nslots == 0) ? 0 : (int)min((int64_t)256, (nslots + 3) / 4);
   const int db = flush ? 0 : (int)min((int64_t)256, (dense_total + 255) / 256);
   static const int wb_cap = getenv("DCCF_LAZY_WB") ? max(1, atoi(getenv("DCCF_LAZY_WB"))) : 8192;
-  const int wb = (int)max((int64_t)1, min((int64_t)(flush ? 8192 : wb_cap), ((win1 - win0) * maxw4 + 255) / 256));
+  const int64_t winS = (!flush && win_from > win0) ? min(win_from, win1) : win0;
+  const int wb = (int)max((int64_t)1, min((int64_t)(flush ? 8192 : wb_cap), ((win1 - winS) * maxw4 + 255) / 256));
   const int mb = flush ? 0 : 32;       // (a flush marks with a launch of its own: every row, and nothing stays pending)
   ARG_CHECK(nslots <= z.list_cap && (pn.cu_blocks == 0 || pn.X_all || pn.N * (pn.S + 2) <= z.list_cap), "lazy optimizer: lazy_list_cap too small");
   if (flush) pn.cu_blocks = 0;
@@ -1038,7 +1048,7 @@ static int lazy_launch(const dccf_opt_t* o, int flush, const PrepNext* pnp, int6
   memset(&gp, 0, sizeof(gp));
   if (gpp && !flush) gp = *gpp;
   BY_KIND(j.kind, k_lazy_opt, dim3(grid), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.a, j.sg, ds, z, lb, db, mb, win0, win1, flush,
-          (int)nslots, pn, gp);
+          (int)nslots, pn, gp, winS);
   if (flush)
     hipLaunchKernelGGL(k_lazy_mark, dim3((unsigned)max((int64_t)1, min((int64_t)1024, (win1 - win0 + 255) / 256))), dim3(256), 0, st, z,
                        win0, win1, flush);
@@ -1047,8 +1057,22 @@ static int lazy_launch(const dccf_opt_t* o, int flush, const PrepNext* pnp, int6
   return 0;
 }
 
-int dccf_lazy_step(const void* ov, const PrepNext* pn, int64_t nslots, hipStream_t st, const GwPart* gp) {
-  return lazy_launch((const dccf_opt_t*)ov, 0, pn, nslots, st, gp);
+int dccf_lazy_step(const void* ov, const PrepNext* pn, int64_t nslots, hipStream_t st, const GwPart* gp, int64_t win_from) {
+  return lazy_launch((const dccf_opt_t*)ov, 0, pn, nslots, st, gp, win_from);
+}
+
+int dccf_lazy_host_args(const void* ov, LazyHost* out) {
+  const dccf_opt_t* o = (const dccf_opt_t*)ov;
+  OptJob j;
+  if (int e = opt_job(o, &j)) return e;
+  memset(out, 0, sizeof(*out));
+  if (int e = lazy_args(o, j, &out->z, LZ_PRE)) return e;
+  out->p = j.p; out->s1 = j.s1; out->s2 = j.s2; out->a = j.a; out->sg = j.sg; out->kind = j.kind;
+  const int64_t R = out->z.row_off[3] + out->z.rows[3];
+  const int64_t w = o->step % o->lazy_K;
+  out->win0 = R * w / o->lazy_K;
+  out->win1 = R * (w + 1) / o->lazy_K;
+  return 0;
 }
 extern "C" int dccf_lazy_opt_step(const dccf_opt_t* opt, int64_t nslots, void* stream) {
   ARG_CHECK(opt != nullptr && opt->lazy_K > 0 && nslots >= 0, "dccf_lazy_opt_step needs a lazy optimizer (lazy_K > 0)");
@@ -1134,7 +1158,7 @@ int dccf_lazy_phase1(const void* ov, const PrepNext* pnp, hipStream_t st) {
   GwPart gp;
   memset(&gp, 0, sizeof(gp));
   BY_KIND(j.kind, k_lazy_opt, dim3(pn.blocks + pn.cu_blocks + wb + mb), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.a, j.sg, ds, z, 0, 0, mb, win0, win1,
-          0, 0, pn, gp);
+          0, 0, pn, gp, win0);
   HIP_TRY(hipGetLastError());
   if (o->lazy_host) o->lazy_host[0] = o->step;
   return 0;

@@ -24,9 +24,12 @@ def main():
     flags = torch.zeros(n // D, dtype=torch.uint8, device=dev)
     segs = [(0, n // D, D, flags)]
     res = []
+    os.environ['DCCF_OPT_BIG_N'] = '1'          # (every size takes the knob-driven launch in this sweep)
+    full = (n + 3) // 4 // 256 + 1             # one float4 slot per thread
+    grids = sorted({g for g in (4096, 16384, 65536, full) if g <= full})
     for un in (1, 2, 4):
         for nt in (0, 1):
-            for grid in (4096, 8192, 16384, 32768, 65536, 262144):
+            for grid in grids:
                 os.environ.update(DCCF_OPT_UN=str(un), DCCF_OPT_NT=str(nt), DCCF_OPT_GRID=str(grid))
                 ev = []
                 for k in range(14):
