@@ -230,15 +230,24 @@ __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT,
                                                    float* __restrict__ zero1, int Dr_, int npass, int tile_blocks, LazyHost lh) {
   // workgroups past the tiles (lazy training step at small batches: 176 tiles leave 80 CUs idle): the head of this step's lazy
   // window, advanced here instead of in the optimizer launch that follows (opt_device.hpp: LazyHost)
+  extern __shared__ float zpart[];   // [8][32][DW]
   if (MODE == 0 && !GEN && !MP && lh.blocks && (int)blockIdx.x >= tile_blocks) {
     const int bid = (int)blockIdx.x - tile_blocks;
-    if (lh.kind == DCCF_OPT_GD) lazy_hosted_window<DCCF_OPT_GD>(lh, bid, 512);
-    else if (lh.kind == DCCF_OPT_ADAGRAD) lazy_hosted_window<DCCF_OPT_ADAGRAD>(lh, bid, 512);
-    else lazy_hosted_window<DCCF_OPT_ADAM>(lh, bid, 512);
+    // the step scalars of the steps the replay can reach, copied to LDS first (a broadcast ds_read per step instead of a global
+    // load inside every lane's dependent chain — what k_lazy_opt does too)
+    float4* sct = reinterpret_cast<float4*>(zpart);
+    const int sct_base = max((int)lh.z.step - lh.z.K, 0);
+    if (lh.kind == DCCF_OPT_ADAM) {
+      const int s = sct_base + (int)threadIdx.x;
+      if ((int)threadIdx.x <= lh.z.K && s >= (int)lh.z.t0 && s <= (int)lh.z.step) sct[threadIdx.x] = reinterpret_cast<const float4*>(lh.z.scal)[s - lh.z.t0];
+      __syncthreads();
+    }
+    if (lh.kind == DCCF_OPT_GD) lazy_hosted_window<DCCF_OPT_GD>(lh, bid, 512, sct, sct_base);
+    else if (lh.kind == DCCF_OPT_ADAGRAD) lazy_hosted_window<DCCF_OPT_ADAGRAD>(lh, bid, 512, sct, sct_base);
+    else lazy_hosted_window<DCCF_OPT_ADAM>(lh, bid, 512, sct, sct_base);
     return;
   }
   const int Dr = GEN ? Dr_ : D_;
-  extern __shared__ float zpart[];   // [8][32][DW]
   TRACE(0);
   // prepared step (no k_prep ran): the loss accumulator k_pair_epilogue adds into starts at 0
   if (zero1 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *zero1 = 0.f;

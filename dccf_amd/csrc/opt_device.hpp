@@ -355,9 +355,8 @@ struct LazyHost {
 // fills everything but blocks / the sub-window's end (win1 = the end of the step's whole window on return)
 int dccf_lazy_host_args(const void* o, LazyHost* out);
 template <int KIND>
-__device__ __forceinline__ void lazy_hosted_window(const LazyHost& h, int bid, int nthreads) {
-  lazy_window_pass<KIND>(h.p, h.s1, h.s2, h.a, h.sg, h.z, h.win0, h.win1, 0, bid, h.blocks, nthreads,
-                         reinterpret_cast<const float4*>(h.z.scal), (int)h.z.t0);
+__device__ __forceinline__ void lazy_hosted_window(const LazyHost& h, int bid, int nthreads, const float4* sct, int sct_base) {
+  lazy_window_pass<KIND>(h.p, h.s1, h.s2, h.a, h.sg, h.z, h.win0, h.win1, 0, bid, h.blocks, nthreads, sct, sct_base);
 }
 
 // opt_kernels.hip: validation + bias corrections (host side) of one optimizer step

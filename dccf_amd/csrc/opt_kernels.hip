@@ -493,14 +493,16 @@ static int launch_job(const OptJob& j0, int phase, const int64_t* list, const in
   // one float4 slot per thread at Electronics size (16384 workgroups): 61.5 -> 59.3 us against 4096 grid-striding workgroups
   // (DCCF_OPT_TUNE=1: the knobs below are read at every launch — scripts/dense_opt_bench.py sweeps them in one process)
   static const bool tune = getenv("DCCF_OPT_TUNE") != nullptr;
-  // Buffers far beyond the 256 MiB Infinity Cache (p + m + v of 1e8 parameters = 1.2 GB): ONE float4 slot per thread — no grid
+  // Buffers beyond the 256 MiB Infinity Cache (p + m + v of 2.5e7 parameters = 300 MB): ONE float4 slot per thread — no grid
   // stride —, non-temporal loads and stores: 6.28 TB/s = 78.5 % of the 8 TB/s peak on 268 M parameters = the box's copy rate
   // (profiles/r03_dense_opt_bench.json; 2 or 4 slots in flight per lane, default-policy accesses or a capped grid: 5.1-5.7 TB/s).
   // In-cache sizes keep the capped grid and the default policy (non-temporal is slower there: DESIGN.md section 4).
   static const int64_t gmax_env = getenv("DCCF_OPT_GRID") ? atoll(getenv("DCCF_OPT_GRID")) : 0;
   static const int un0 = getenv("DCCF_OPT_UN") ? atoi(getenv("DCCF_OPT_UN")) : 1;
   static const int nt0 = getenv("DCCF_OPT_NT") ? atoi(getenv("DCCF_OPT_NT")) : 1;
-  static const int64_t big0 = getenv("DCCF_OPT_BIG_N") ? atoll(getenv("DCCF_OPT_BIG_N")) : 100000000LL;
+  // (33 M parameters = 400 MB of p + m + v: 5.83 against 5.52 TB/s; 67 M: 6.46 / 5.98; 134 M: 6.23 / 5.75 — non-temporal and one slot per
+  // thread win as soon as the state no longer fits the 256 MiB cache; 16.4 M = 197 MB, the Electronics model, stays below)
+  static const int64_t big0 = getenv("DCCF_OPT_BIG_N") ? atoll(getenv("DCCF_OPT_BIG_N")) : 25000000LL;
   const int64_t big_n = tune && getenv("DCCF_OPT_BIG_N") ? atoll(getenv("DCCF_OPT_BIG_N")) : big0;
   const bool big = j.n >= big_n && !j.sg.to_mask;
   const int64_t gmax_dflt = big ? ((int64_t)1 << 24) : 16384;

@@ -1,0 +1,297 @@
+// full128_bench.hip — where the time of the full U x I exposure matrix goes at D = 128 (BASELINE config 4; VERDICT r2 item 7: 14.9 ms
+// against rocBLAS's 12.5 ms for the bare product), and which changes to k_mf_full_rows (dccf_amd/csrc/mf_kernels.hip) pay:
+//   LD 1   the B operand as dwordx4 loads from a Q^T laid out [tile][k-group of 4][k parity][item][4] (16 loads per tile and wave
+//          instead of 64 dword loads)
+//   ST 1   the tile's rows leave as 16-byte-aligned dwordx4 stores (the row's misalignment — item_num is odd — is absorbed by a per-row
+//          shift inside the LDS tile) + one masked dword store for the <= 3 + 3 edge elements, instead of dword-per-lane stores
+//   AL 1   the A operand (32 users x 128) in LDS instead of 64 registers per lane (fewer VGPRs: three workgroups per CU)
+//   NW     waves per workgroup (tile = NW x 32 items)
+//   DBG    bit 0: no global stores, bit 1: no MFMA, bit 2: B operand fetched once (no loads in the loop)
+// Diagnostic only; on the GPU box:
+//     hipcc --offload-arch=gfx950 -O3 -ffp-contract=off scripts/full128_bench.hip -o /tmp/full128 && /tmp/full128 > gpurun_out/full128_bench.txt
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Args {
+  const float *P, *Q, *QT, *QT4, *bu, *bi, *prop;
+  float b0, Mclip;
+  float* out;
+  int64_t U, I, Ipad;
+  int splits;
+};
+
+__global__ void k_qt(const float* __restrict__ Q, int64_t I, int64_t Ipad, int TW, float* __restrict__ QT) {      // [T][k][TW]
+  for (int64_t x = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; x < Ipad * 128; x += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t T = x / (128LL * TW);
+    const int k = (int)((x / TW) % 128), c = (int)(x % TW);
+    const int64_t i = T * TW + c;
+    QT[x] = i < I ? Q[i * 128 + k] : 0.f;
+  }
+}
+__global__ void k_qt4(const float* __restrict__ Q, int64_t I, int64_t Ipad, int TW, float* __restrict__ QT4) {    // [T][q][h][TW][4]
+  for (int64_t x = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; x < Ipad * 128; x += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t T = x / (128LL * TW);
+    const int64_t rem = x % (128LL * TW);
+    const int i = (int)(rem & 3), col = (int)((rem >> 2) % TW), qh = (int)(rem / (4LL * TW));
+    const int h = qh & 1, q = qh >> 1, k = 2 * (4 * q + i) + h;
+    const int64_t it = T * TW + col;
+    QT4[x] = it < I ? Q[it * 128 + k] : 0.f;
+  }
+}
+
+template <int NW, int LD, int ST, int AL, int DBG, int WPE>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_full(Args a) {
+  constexpr int D = 128, TW = NW * 32, KS = 64, CW = TW + 8, ALD = 68;
+  __shared__ __attribute__((aligned(16))) float Cs[2][32][CW];
+  __shared__ float Bu[32];
+  __shared__ __attribute__((aligned(16))) float As[AL ? 2 * 32 * ALD : 4];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane >> 5, c31 = lane & 31;
+  const int64_t gt = (a.I + TW - 1) / TW;
+  const int64_t band = blockIdx.x / a.splits, sp = blockIdx.x % a.splits;
+  const int64_t T0 = gt * sp / a.splits, T1 = gt * (sp + 1) / a.splits;
+  const int64_t u0 = band * 32;
+  float pa[AL ? 1 : KS];
+  if (!AL) {
+    const float4* prow = reinterpret_cast<const float4*>(a.P + min(u0 + c31, a.U - 1) * D);
+#pragma unroll
+    for (int j = 0; j < D / 4; ++j) {
+      const float4 v = prow[j];
+      pa[2 * j] = h ? v.y : v.x;
+      pa[2 * j + 1] = h ? v.w : v.z;
+    }
+  } else {
+    for (int idx = threadIdx.x; idx < 32 * D; idx += 64 * NW) {
+      const int row = idx / D, e = idx % D;
+      As[((e & 1) * 32 + row) * ALD + (e >> 1)] = a.P[min(u0 + row, a.U - 1) * D + e];
+    }
+  }
+  if (threadIdx.x < 32) Bu[threadIdx.x] = a.bu[min(u0 + (int64_t)threadIdx.x, a.U - 1)];
+  // per-row shift inside the LDS tile (ST): row u starts at float offset u * I + c0 of `out`, c0 a multiple of 4 -> its
+  // misalignment depends on the row alone; pad = (4 - ((-off) & 3)) & 3 = off & 3
+  uint32_t pads = 0;
+  if (ST) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      pads |= (uint32_t)(((u0 + row) * a.I) & 3) << (2 * r);
+    }
+  }
+  __syncthreads();
+  float qb[LD ? 1 : KS];
+  float4 q4[LD ? 16 : 1];
+  float bin = 0.f, prn = 1.f;
+  auto prefetch = [&](int64_t T) {
+    const int64_t i = min(T * TW + wave * 32 + c31, a.I - 1);
+    if (LD) {
+      const float4* qc = reinterpret_cast<const float4*>(a.QT4) + T * (int64_t)(D * TW / 4) + (int64_t)h * TW + wave * 32 + c31;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) q4[q] = qc[(int64_t)q * 2 * TW];
+    } else {
+      const float* qc = a.QT + T * (int64_t)(D * TW) + h * TW + wave * 32 + c31;
+#pragma unroll
+      for (int k = 0; k < KS; ++k) qb[k] = qc[2 * k * TW];
+    }
+    bin = a.bi[i];
+    prn = fmaxf(a.prop[i], a.Mclip);
+  };
+  if (T0 < T1) prefetch(T0);
+  int buf = 0;
+  for (int64_t T = T0; T < T1; ++T) {
+    const float bic = bin + a.b0, prc = prn;
+    const float rinv = 1.0f / prc;
+    const int64_t c0 = T * TW;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (!(DBG & 2)) {
+      if (AL) {
+        const float4* ap = reinterpret_cast<const float4*>(&As[(h * 32 + c31) * ALD]);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const float4 av = ap[q];
+          const float4 bv = LD ? q4[q] : make_float4(qb[LD ? 0 : 4 * q], qb[LD ? 0 : 4 * q + 1], qb[LD ? 0 : 4 * q + 2], qb[LD ? 0 : 4 * q + 3]);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+        }
+      } else if (LD) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[AL ? 0 : 4 * q], q4[q].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[AL ? 0 : 4 * q + 1], q4[q].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[AL ? 0 : 4 * q + 2], q4[q].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[AL ? 0 : 4 * q + 3], q4[q].w, acc, 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[AL ? 0 : k], qb[LD ? 0 : k], acc, 0, 0, 0);
+      }
+    } else {
+      acc[0] = LD ? q4[0].x : qb[0];
+    }
+    if (!(DBG & 4) && T + 1 < T1) prefetch(T + 1);
+    float (*C)[CW] = Cs[buf];
+    buf ^= 1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      float v = acc[r] + Bu[row] + bic;
+      const float q = v * rinv;
+      v = fmaf(fmaf(-q, prc, v), rinv, q);
+      C[row][(ST ? (int)((pads >> (2 * r)) & 3u) : 0) + wave * 32 + c31] = v;
+    }
+    __syncthreads();
+    if (DBG & 1) continue;
+    if (c0 + TW <= a.I && u0 + 32 <= a.U) {
+      if (ST) {
+        // rows leave as aligned dwordx4 runs: NW == 4: a half-wave per row (128 floats = 32 float4), NW == 8: a wave per row
+        constexpr int LPR = TW / 4;                       // lanes per row
+        constexpr int RPI = 64 / LPR;                     // rows per store instruction
+#pragma unroll
+        for (int rr = 0; rr < 32 / NW / RPI; ++rr) {
+          const int row = wave + NW * (rr * RPI + (RPI == 2 ? (lane >> 5) : 0));
+          const int j = lane & (LPR - 1);
+          const int64_t off = (u0 + row) * a.I + c0;
+          const int pad = (int)(off & 3), s = (4 - pad) & 3, nb = (TW - s) >> 2;
+          float* o = a.out + off;
+          if (j < nb) *reinterpret_cast<float4*>(o + s + 4 * j) = *reinterpret_cast<const float4*>(&C[row][pad + s + 4 * j]);
+          if (s && j < 4) {                               // <= 3 elements in front of the aligned body, the rest behind it
+            const int idx = j < s ? j : s + 4 * nb + (j - s);
+            if (idx < TW) o[idx] = C[row][pad + idx];
+          }
+        }
+      } else {
+        float* orow = a.out + (u0 + wave) * a.I + c0 + lane;
+#pragma unroll
+        for (int rr = 0; rr < 32 / NW; ++rr) {
+#pragma unroll
+          for (int q = 0; q < TW / 64; ++q) orow[q * 64] = C[wave + NW * rr][q * 64 + lane];
+          orow += (int64_t)NW * a.I;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int rr = 0; rr < 32 / NW; ++rr) {
+        const int row = wave + NW * rr;
+        const int64_t u = u0 + row;
+        if (u < a.U) {
+          const int pad = ST ? (int)((u * a.I) & 3) : 0;
+          float* orow = a.out + u * a.I + c0;
+#pragma unroll
+          for (int q = 0; q < TW / 64; ++q) {
+            const int c = q * 64 + lane;
+            if (c0 + c < a.I) orow[c] = C[row][pad + c];
+          }
+        }
+      }
+    }
+  }
+}
+
+static std::vector<float> hP, hQ, hbu, hbi, hprop;
+
+template <int NW, int LD, int ST, int AL, int DBG, int WPE>
+static int run(Args a, const char* name, float* hout_check) {
+  constexpr int TW = NW * 32;
+  const int64_t bands = (a.U + 31) / 32, gt = (a.I + TW - 1) / TW;
+  a.splits = gt >= 64 ? 32 : (gt >= 16 ? 8 : 1);
+  a.Ipad = gt * TW;
+  float *QT = nullptr, *QT4 = nullptr;
+  CHECK(hipMalloc((void**)&QT, (size_t)a.Ipad * 128 * 4));
+  CHECK(hipMalloc((void**)&QT4, (size_t)a.Ipad * 128 * 4));
+  hipLaunchKernelGGL(k_qt, dim3(4096), dim3(256), 0, 0, a.Q, a.I, a.Ipad, TW, QT);
+  hipLaunchKernelGGL(k_qt4, dim3(4096), dim3(256), 0, 0, a.Q, a.I, a.Ipad, TW, QT4);
+  a.QT = QT;
+  a.QT4 = QT4;
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  float best = 1e9f;
+  for (int it = 0; it < 6; ++it) {
+    CHECK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL((k_full<NW, LD, ST, AL, DBG, WPE>), dim3((unsigned)(bands * a.splits)), dim3(64 * NW), 0, 0, a);
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (it >= 1 && ms < best) best = ms;
+  }
+  CHECK(hipGetLastError());
+  double maxerr = -1.0;
+  if (DBG == 0) {
+    // spot check: corners, edges and pseudo-random entries against a host reference in double
+    maxerr = 0.0;
+    uint64_t st = 12345;
+    for (int t = 0; t < 200; ++t) {
+      st = st * 6364136223846793005ULL + 1442695040888963407ULL;
+      int64_t u = (int64_t)((st >> 33) % (uint64_t)a.U), i = (int64_t)((st >> 13) % (uint64_t)a.I);
+      if (t == 0) { u = 0; i = 0; }
+      if (t == 1) { u = a.U - 1; i = a.I - 1; }
+      if (t == 2) { u = 1; i = a.I - 1; }
+      if (t == 3) { u = a.U - 1; i = 0; }
+      if (t >= 4 && t < 36) { u = 33 + (t & 3); i = (t - 4) * 131 + (t & 7); }
+      float got = 0.f;
+      CHECK(hipMemcpy(&got, a.out + u * a.I + i, 4, hipMemcpyDeviceToHost));
+      double ref = 0.0;
+      for (int k = 0; k < 128; ++k) ref += (double)hP[u * 128 + k] * (double)hQ[i * 128 + k];
+      ref = (ref + hbu[u] + hbi[i] + a.b0) / fmax((double)hprop[i], (double)a.Mclip);
+      maxerr = fmax(maxerr, fabs(ref - (double)got));
+    }
+  }
+  const double flop = 2.0 * (double)a.U * (double)a.I * 128.0;
+  printf("%-44s NW %d LD %d ST %d AL %d DBG %d WPE %d : %7.3f ms  %6.1f TFLOP/s  max|err| %.2e\n", name, NW, LD, ST, AL, DBG, WPE, best,
+         flop / best / 1e9, maxerr);
+  fflush(stdout);
+  CHECK(hipFree(QT));
+  CHECK(hipFree(QT4));
+  return 0;
+}
+
+int main() {
+  const int64_t U = 75258, I = 64443;
+  hP.resize(U * 128); hQ.resize(I * 128); hbu.resize(U); hbi.resize(I); hprop.resize(I);
+  uint32_t s = 1;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
+  for (auto& v : hP) v = rnd() * 0.2f;
+  for (auto& v : hQ) v = rnd() * 0.2f;
+  for (auto& v : hbu) v = rnd() * 0.2f;
+  for (auto& v : hbi) v = rnd() * 0.2f;
+  for (auto& v : hprop) v = rnd() + 0.5f;
+  Args a;
+  float *P, *Q, *bu, *bi, *prop, *out;
+  CHECK(hipMalloc((void**)&P, hP.size() * 4)); CHECK(hipMalloc((void**)&Q, hQ.size() * 4));
+  CHECK(hipMalloc((void**)&bu, U * 4)); CHECK(hipMalloc((void**)&bi, I * 4)); CHECK(hipMalloc((void**)&prop, I * 4));
+  CHECK(hipMalloc((void**)&out, (size_t)U * I * 4));
+  CHECK(hipMemcpy(P, hP.data(), hP.size() * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(Q, hQ.data(), hQ.size() * 4, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(bu, hbu.data(), U * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(bi, hbi.data(), I * 4, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(prop, hprop.data(), I * 4, hipMemcpyHostToDevice));
+  a.P = P; a.Q = Q; a.bu = bu; a.bi = bi; a.prop = prop; a.b0 = 0.1f; a.Mclip = 0.1f; a.out = out; a.U = U; a.I = I;
+  int rc = 0;
+  rc |= run<4, 0, 0, 0, 0, 2>(a, "current form (round 2)", out);
+  rc |= run<4, 0, 0, 0, 1, 2>(a, "  no stores", out);
+  rc |= run<4, 0, 0, 0, 2, 2>(a, "  no MFMA", out);
+  rc |= run<4, 0, 0, 0, 4, 2>(a, "  no loads in the loop", out);
+  rc |= run<4, 0, 0, 0, 3, 2>(a, "  no stores, no MFMA (loads + epilogue)", out);
+  rc |= run<4, 0, 0, 0, 5, 2>(a, "  no stores, no loads (MFMA + epilogue)", out);
+  rc |= run<4, 0, 0, 0, 6, 2>(a, "  no MFMA, no loads (epilogue + stores)", out);
+  rc |= run<4, 1, 0, 0, 0, 2>(a, "dwordx4 B loads", out);
+  rc |= run<4, 0, 1, 0, 0, 2>(a, "aligned dwordx4 row stores", out);
+  rc |= run<4, 1, 1, 0, 0, 2>(a, "both", out);
+  rc |= run<4, 1, 1, 1, 0, 3>(a, "both + A in LDS, 3 waves per SIMD", out);
+  rc |= run<4, 1, 1, 1, 0, 4>(a, "both + A in LDS, 4 waves per SIMD", out);
+  rc |= run<4, 1, 0, 1, 0, 3>(a, "x4 loads + A in LDS, 3 waves per SIMD", out);
+  rc |= run<8, 1, 1, 0, 0, 2>(a, "8 waves: both", out);
+  rc |= run<8, 1, 1, 1, 0, 2>(a, "8 waves: both + A in LDS (2 per SIMD)", out);
+  rc |= run<8, 1, 1, 1, 0, 3>(a, "8 waves: both + A in LDS (3 per SIMD)", out);
+  rc |= run<8, 0, 0, 0, 0, 2>(a, "8 waves: round-2 form", out);
+  return rc;
+}
