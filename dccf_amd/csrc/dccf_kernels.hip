@@ -53,7 +53,7 @@ static const Knobs& knobs() {
     q.lazy_cu = getenv("DCCF_LAZY_NO_CU") == nullptr;
     q.gw_part = getenv("DCCF_NO_GW_PART") == nullptr;
     q.lazy_cu_blocks = getenv("DCCF_LAZY_CU_BLOCKS") ? max(1, atoi(getenv("DCCF_LAZY_CU_BLOCKS"))) : 256;
-    q.lazy_host_frac = getenv("DCCF_LAZY_HOST_FRAC") ? atof(getenv("DCCF_LAZY_HOST_FRAC")) : 0.0;
+    q.lazy_host_frac = getenv("DCCF_LAZY_HOST_FRAC") ? atof(getenv("DCCF_LAZY_HOST_FRAC")) : 0.25;
     q.lazy_host_blocks = getenv("DCCF_LAZY_HOST_BLOCKS") ? max(1, atoi(getenv("DCCF_LAZY_HOST_BLOCKS"))) : 256;
     return q;
   }();

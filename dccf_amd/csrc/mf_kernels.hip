@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256) void k_transpose_q(const float* __restrict__ Q
 // the 128-B segments MFMA accumulators give directly.
 template <int D, int RB, int NW>
 __global__ __launch_bounds__(64 * NW) void k_mf_full_rows(mf_model_t M, float* __restrict__ out, int splits,
-                                                         const float* __restrict__ QT, int64_t Ipad) {
+                                                         const float* __restrict__ QT, int64_t Ipad, int64_t nbands, int order) {
   constexpr int TW = NW * 32;                 // items per tile: one 32 x 32 block per wave
   __shared__ float Cs[2][32][TW + 4];
   __shared__ float Bu[RB * 32];
@@ -567,7 +567,19 @@ __global__ __launch_bounds__(64 * NW) void k_mf_full_rows(mf_model_t M, float* _
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = lane >> 5, c31 = lane & 31;
   const int64_t gt = (M.item_num + TW - 1) / TW;
-  const int64_t band = blockIdx.x / splits, sp = blockIdx.x % splits;
+  // workgroup -> (band, piece).  order 0: the piece index fastest — XCD x (= workgroup id mod 8) reads the pieces = x (mod 8),
+  // but the ~64 workgroups resident on an XCD cover ALL its splits / 8 pieces at once.  order 1 (splits a multiple of 8): the XCD
+  // keeps ONE piece while the bands stream past it — id = ((sp_hi * nbands) + band) * 8 + sp_lo — so its live slice of Q^T is
+  // 1 / splits of it (1 MB at D = 128, 64 k items) instead of 1 / 8 (4.1 MB: more than the XCD's 4 MB L2)
+  int64_t band, sp;
+  if (order == 1) {
+    const int64_t lo = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    band = rest % nbands;
+    sp = (rest / nbands) * 8 + lo;
+  } else {
+    band = blockIdx.x / splits;
+    sp = blockIdx.x % splits;
+  }
   const int64_t T0 = gt * sp / splits, T1 = gt * (sp + 1) / splits;
   const int64_t u0 = band * (32 * RB);
   float pa[RB][KS];
@@ -676,7 +688,10 @@ static int launch_full_rows(const mf_model_t* M, float* out, hipStream_t st) {
   HIP_TRY(hipMallocAsync((void**)&QT, (size_t)Ipad * D * sizeof(float), st));
   hipLaunchKernelGGL(k_transpose_q, dim3((unsigned)min((int64_t)4096, (Ipad * D + 255) / 256)), dim3(256), 0, st, M->Q, M->item_num, D,
                      Ipad, NW * 32, QT);
-  hipLaunchKernelGGL((k_mf_full_rows<D, RB, NW>), dim3((unsigned)(bands * splits)), dim3(64 * NW), 0, st, *M, out, splits, QT, Ipad);
+  int order = (splits % 8 == 0 && D >= 128) ? 1 : 0;
+  if (getenv("DCCF_FULL_ORDER")) order = (atoi(getenv("DCCF_FULL_ORDER")) == 1 && splits % 8 == 0) ? 1 : 0;
+  hipLaunchKernelGGL((k_mf_full_rows<D, RB, NW>), dim3((unsigned)(bands * splits)), dim3(64 * NW), 0, st, *M, out, splits, QT, Ipad, bands,
+                     order);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipFreeAsync(QT, st));
   return 0;
@@ -784,23 +799,34 @@ extern "C" int dccf_sample_train_negatives(const int64_t* rows_indptr, const int
 // pos row j = (uid, iid)[perm[k*B + j]], neg row j = (uid, neg)[perm[k*B + j]] — rows j and B + j carry the same uid.  The
 // n % B rows left over form the shorter last batch `tail` [2r, 2].  A negative of -1 (a user with nothing left to draw,
 // dccf_sample_train_negatives) is replaced by 0 and reported through *bad: no id below 0 ever reaches a kernel as a row index.
-// perm == NULL: the epoch's permutation is computed on the fly — a keyed bijection of [0, 2^b) (b = bits of n - 1; four rounds of
-// "multiply by an odd key, add, xor-shift", each a bijection of b-bit integers) walked until it lands below n (cycle walking: at
-// most two rounds on average).  It plays shuffle_in_unison_scary's role (src/utils/utils.py:82-92) without a sort: no
-// permutation array, no extra launches (torch.randperm is a key sort of five launches, more than a 20-step epoch can hide).
-__device__ __forceinline__ uint64_t perm_round(uint64_t x, uint64_t mask, int b, uint64_t ka, uint64_t kc) {
-  x = (x * (ka | 1ull) + kc) & mask;
-  x ^= x >> ((b + 1) >> 1);
-  return x;
+// perm == NULL: the epoch's permutation is computed on the fly — a keyed bijection of [0, 2^b) (b = bits of n - 1, at least 2): a
+// 12-round alternating Feistel network (halves of ceil(b/2) / floor(b/2) bits, round function = splitmix64's finalizer of the right
+// half + the round key), walked until it lands below n (cycle walking: fewer than two passes on average).  It plays
+// shuffle_in_unison_scary's role (src/utils/utils.py:82-92) without a sort: no permutation array, no extra launches
+// (torch.randperm is a key sort of five launches, more than a 20-step epoch can hide).  oracle/philox.py::epoch_perm restates it
+// bit for bit and holds it to a chi-square on small domains (round 2's multiply-add-xorshift rounds failed that test).
+#define EPOCH_PERM_ROUNDS 12
+struct PermKeys { uint64_t k[EPOCH_PERM_ROUNDS]; };
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
 }
-__device__ __forceinline__ int64_t epoch_perm(int64_t i, int64_t n, int b, uint64_t k0, uint64_t k1) {
-  const uint64_t mask = b >= 64 ? ~0ull : ((1ull << b) - 1);
+__device__ __forceinline__ int64_t epoch_perm(int64_t i, int64_t n, int b, const PermKeys& ks) {
+  const int lb = b >> 1, hb = b - lb;
   uint64_t x = (uint64_t)i;
   do {
-    x = perm_round(x, mask, b, k0 * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull, k1 ^ 0x8CB92BA72F3D8DD7ull);
-    x = perm_round(x, mask, b, k1 * 0xC2B2AE3D27D4EB4Full + 0x165667B19E3779F9ull, k0 + 0x27D4EB2F165667C5ull);
-    x = perm_round(x, mask, b, (k0 ^ (k1 << 1)) * 0xFF51AFD7ED558CCDull + 0x9FB21C651E98DF25ull, k1 * 0x2545F4914F6CDD1Dull);
-    x = perm_round(x, mask, b, (k1 ^ (k0 >> 3)) * 0xC4CEB9FE1A85EC53ull + 0x94D049BB133111EBull, k0 * 0xBF58476D1CE4E5B9ull);
+    int wl = hb, wr = lb;
+    uint64_t L = x >> wr, R = x & ((1ull << wr) - 1);
+#pragma unroll
+    for (int r = 0; r < EPOCH_PERM_ROUNDS; ++r) {
+      const uint64_t F = mix64(R + ks.k[r]);
+      const uint64_t nr = L ^ (F & ((1ull << wl) - 1));
+      L = R;
+      R = nr;
+      const int t = wl; wl = wr; wr = t;
+    }
+    x = (L << wr) | R;
   } while (x >= (uint64_t)n);
   return (int64_t)x;
 }
@@ -808,10 +834,10 @@ __device__ __forceinline__ int64_t epoch_perm(int64_t i, int64_t n, int b, uint6
 __global__ __launch_bounds__(256) void k_epoch_batches(const int64_t* __restrict__ uid, const int64_t* __restrict__ iid,
                                                        const int64_t* __restrict__ neg, const int64_t* __restrict__ perm, int64_t n,
                                                        int64_t B, int64_t* __restrict__ full, int64_t* __restrict__ tail,
-                                                       int32_t* __restrict__ bad, int pbits, uint64_t pk0, uint64_t pk1) {
+                                                       int32_t* __restrict__ bad, int pbits, PermKeys pk) {
   const int64_t nb = n / B, r = n - nb * B;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t s = perm ? perm[i] : epoch_perm(i, n, pbits, pk0, pk1);
+    const int64_t s = perm ? perm[i] : epoch_perm(i, n, pbits, pk);
     const int64_t u = uid[s], ip = iid[s];
     int64_t ng = neg[s];
     if (ng < 0) {
@@ -833,19 +859,20 @@ extern "C" int dccf_build_epoch_batches(const int64_t* uid, const int64_t* iid, 
   if (n == 0) return 0;
   ARG_CHECK(uid && iid && neg && (n < batch_size || full) && (n % batch_size == 0 || tail), "NULL argument");
   const int grid = (int)min((int64_t)2048, (n + 255) / 256);
-  int b = 1;
-  while (b < 63 && (1ll << b) < n) ++b;
-  // two 64-bit keys from (seed, epoch): splitmix64 steps
-  uint64_t z = seed * 0x9E3779B97F4A7C15ull + epoch * 0xBF58476D1CE4E5B9ull + 0x94D049BB133111EBull, k[2];
-  for (int i = 0; i < 2; ++i) {
+  int b = 2;
+  while (b < 62 && (1ll << b) < n) ++b;
+  // the round keys from (seed, epoch): splitmix64 steps
+  uint64_t z = seed * 0x9E3779B97F4A7C15ull + epoch * 0xBF58476D1CE4E5B9ull + 0x94D049BB133111EBull;
+  PermKeys pk;
+  for (int i = 0; i < EPOCH_PERM_ROUNDS; ++i) {
     z += 0x9E3779B97F4A7C15ull;
     uint64_t x = z;
     x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
     x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    k[i] = x ^ (x >> 31);
+    pk.k[i] = x ^ (x >> 31);
   }
   hipLaunchKernelGGL(k_epoch_batches, dim3(grid), dim3(256), 0, (hipStream_t)stream, uid, iid, neg, perm, n, batch_size, full, tail, bad,
-                     b, k[0], k[1]);
+                     b, pk);
   HIP_TRY(hipGetLastError());
   return 0;
 }

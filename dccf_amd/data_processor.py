@@ -316,7 +316,10 @@ class DeviceTrainSet(object):
     def check_negatives(self):
         """Raises if an epoch_batches() since the last check met a user without an admissible negative (the reference asserts,
         DataProcessor.py:495).  Called at the end of an epoch: no host synchronisation inside the step loop."""
-        assert self.n == 0 or int(self._bad) == 0, 'no admissible training negative left for some user'
+        if self.n and int(self._bad) != 0:        # (an explicit raise: an assert is stripped under python -O)
+            self._bad.zero_()
+            raise RuntimeError('no admissible training negative left for some user (src/data_processor/DataProcessor.py:495 asserts '
+                               'here): its pairs of this epoch were trained against item 0')
 
     def epoch_batches(self, epoch, batch_size):
         """Two launches per epoch: the sampler and the batch tensor (the permutation — the in-unison shuffle of

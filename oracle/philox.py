@@ -177,3 +177,55 @@ def eval_negatives(seed, tag, users, item_num, hist_indptr, hist_items, neg_n):
                     break
         out[w] = acc
     return out
+
+
+# ------------------------------------------------------------------------------------------------ the epoch's permutation
+EPOCH_PERM_ROUNDS = 12
+
+
+def _mix64(x):
+    """splitmix64's finalizer (exact 64-bit wrap)."""
+    M = (1 << 64) - 1
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & M
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & M
+    return x ^ (x >> 31)
+
+
+def epoch_perm_keys(seed, epoch):
+    """The round keys dccf_build_epoch_batches derives from (seed, epoch) (dccf_amd/csrc/mf_kernels.hip): splitmix64 steps."""
+    M = (1 << 64) - 1
+    z = (int(seed) * 0x9E3779B97F4A7C15 + int(epoch) * 0xBF58476D1CE4E5B9 + 0x94D049BB133111EB) & M
+    ks = []
+    for _ in range(EPOCH_PERM_ROUNDS):
+        z = (z + 0x9E3779B97F4A7C15) & M
+        ks.append(_mix64(z))
+    return ks
+
+
+def epoch_perm(seed, epoch, n):
+    """perm[i] for i < n: the keyed bijection k_epoch_batches evaluates per index instead of torch.randperm — plays
+    shuffle_in_unison_scary's role (src/utils/utils.py:82-92).  A 12-round alternating Feistel network on b-bit integers
+    (b = bits of n - 1, at least 2; halves of ceil(b/2) and floor(b/2) bits; round function = splitmix64's finalizer of the
+    right half + the round key), cycle-walked until the value is below n.  (Round 2's four rounds of multiply-add-xorshift were
+    measurably non-uniform on small domains — tests/test_oracle_golden.py holds this one to a chi-square.)"""
+    M = (1 << 64) - 1
+    ks = epoch_perm_keys(seed, epoch)
+    b = 2
+    while (1 << b) < n:
+        b += 1
+    lb = b // 2
+    hb = b - lb
+    out = np.empty(n, dtype=np.int64)
+    for i in range(n):
+        x = i
+        while True:
+            wl, wr = hb, lb
+            L, R = x >> wr, x & ((1 << wr) - 1)
+            for r in range(EPOCH_PERM_ROUNDS):
+                F = _mix64((R + ks[r]) & M)
+                L, R, wl, wr = R, L ^ (F & ((1 << wl) - 1)), wr, wl
+            x = (L << wr) | R
+            if x < n:
+                break
+        out[i] = x
+    return out

@@ -231,3 +231,23 @@ def test_device_train_set_flags_a_user_without_admissible_negative():
     ok = DeviceTrainSet(uid[I_:], iid[I_:], 3, I_, seed=5)
     ok.epoch_batches(0, 4)
     ok.check_negatives()
+
+
+def test_device_epoch_permutation_equals_the_oracle():
+    """k_epoch_batches' keyed bijection (the epoch's in-unison shuffle without a sort) against oracle/philox.py::epoch_perm, which
+    the CPU suite holds to a chi-square: the device evaluates the same permutation, bit for bit — sizes around powers of two, a
+    tail batch, several (seed, epoch) keys."""
+    from oracle import philox as PH
+    from dccf_amd import _lib as L
+    dev = torch.device('cuda:0')
+    bad = torch.zeros(1, dtype=torch.int32, device=dev)
+    for n, B, seed, epoch in ((7, 3, 2019, 0), (130, 16, 2019, 5), (1000, 128, 7, 123456), (1025, 128, 2019, 1), (4096, 100, 99, 2)):
+        uid = torch.arange(n, device=dev) * 3 + 1
+        iid = torch.arange(n, device=dev)                    # the positive item of row s IS s: the batches spell the permutation out
+        neg = torch.arange(n, device=dev) + 10 * n
+        full, tail = L.build_epoch_batches(uid, iid, neg, None, B, bad, seed, epoch)
+        got = torch.cat([full[:, :B, 1].reshape(-1)] + ([tail[:tail.shape[0] // 2, 1]] if tail is not None else [])).cpu().numpy()
+        ref = PH.epoch_perm(seed, epoch, n)
+        assert np.array_equal(got, ref), (n, B, seed, epoch)
+        negs = torch.cat([full[:, B:, 1].reshape(-1)] + ([tail[tail.shape[0] // 2:, 1]] if tail is not None else [])).cpu().numpy()
+        assert np.array_equal(negs, ref + 10 * n) and int(bad) == 0

@@ -224,3 +224,35 @@ def test_reference_checkpoint_fixture_matches_golden_parameters():
     last = 's%d/after/' % (int(g['steps']) - 1)
     for k in keys:
         assert np.array_equal(sd[k].numpy(), g[last + k])
+
+
+def test_epoch_permutation_is_a_bijection_and_uniform():
+    """The keyed bijection that replaces torch.randperm for the epoch's in-unison shuffle (k_epoch_batches; ADVICE r2: it had
+    coverage tests only — and round 2's multiply-add-xorshift rounds fail THIS test at n = 7 with p ~ 1e-43).  For every
+    (seed, epoch, n): a permutation.  Over many epochs: position -> value counts are uniform (chi-square per position and over
+    all positions), and so are the differences of neighbouring values (no visible structure in (perm[i], perm[i + 1]))."""
+    from oracle import philox as PH
+    from scipy.stats import chi2
+    for n in (1, 2, 3, 7, 130, 1000, 1025):
+        for seed, epoch in ((2019, 0), (2019, 1), (7, 123456)):
+            p = PH.epoch_perm(seed, epoch, n)
+            assert sorted(p.tolist()) == list(range(n)), (n, seed, epoch)
+    assert not np.array_equal(PH.epoch_perm(2019, 0, 130), PH.epoch_perm(2019, 1, 130))
+    assert not np.array_equal(PH.epoch_perm(2019, 0, 130), PH.epoch_perm(2020, 0, 130))
+    for n, E in ((5, 5000), (7, 7000), (130, 6500)):
+        C = np.zeros((n, n))
+        Dm = np.zeros(n)
+        for e in range(E):
+            p = PH.epoch_perm(2019, e, n)
+            C[np.arange(n), p] += 1
+            Dm += np.bincount((p[1:] - p[:-1]) % n, minlength=n)
+        exp = E / n
+        stat = ((C - exp) ** 2 / exp).sum(1)                    # one chi-square (n - 1 dof) per position
+        pv = chi2.sf(stat, n - 1)
+        assert pv.min() > 1e-4 / n, (n, pv.min())               # (Bonferroni over the n positions)
+        # all positions together: the sum of n chi-squares (n (n - 1) dof; the positions are only mildly dependent)
+        assert chi2.sf(stat.sum(), n * (n - 1)) > 1e-4, (n, stat.sum())
+        # neighbour differences: 0 is impossible (a permutation), the other n - 1 residues are equally likely
+        d = Dm[1:]
+        sd = ((d - d.mean()) ** 2 / d.mean()).sum()
+        assert chi2.sf(sd, n - 2) > 1e-4, (n, sd)
