@@ -83,14 +83,14 @@ static Lay make_layout(int64_t N, int D, int F, int S, int A, int NX = 0) {
   y.N = N;
   y.NS = N * y.S1;
   y.L = y.NS * A;
-  y.DP = D <= 32 ? 32 : (int)align_up(D, 64);
-  y.DT = D <= 16 ? 16 : (D <= 32 ? 32 : (D <= 64 ? 64 : 128));
+  y.DT = D <= 16 ? 16 : (D <= 32 ? 32 : (D <= 64 ? 64 : (D <= 128 ? 128 : 256)));
+  y.DP = y.DT <= 32 ? 32 : y.DT;                 // the row stride of h / W^T = the kernels' compile-time DP of that tile
   y.NC = (int)align_up(F, 128) / 128;
   // W^T is zero-padded to the forward's compile-time chunk count: 2, 6 or 7 chunks in one pass, passes of 6 beyond (F > 896)
   y.FP = (y.NC <= 2 ? 2 : (y.NC <= 6 ? 6 : (y.NC == 7 ? 7 : (y.NC + 5) / 6 * 6))) * 128;
-  if (D != (D <= 16 ? 16 : (D <= 32 ? 32 : (D <= 64 ? 64 : 128)))) y.FP = (y.NC + 5) / 6 * 6 * 128;   // (fewer kernel instances)
+  if (D != y.DT || D > 128) y.FP = (y.NC + 5) / 6 * 6 * 128;   // (fewer kernel instances; the 256 tile is run-time width only)
   y.ND = y.DP == 32 ? 1 : 2;
-  y.GY = y.DP == 32 ? 1 : y.DP / 64;
+  y.GY = y.DP == 32 ? 1 : (D + 63) / 64;         // 64-column groups that hold real columns (a 192-wide model in the 256 tile: 3)
   size_t o = 0;
   y.cand = o;  o += align_up((size_t)y.NS * 4, 256);
   y.WT = o;    o += align_up((size_t)(D + y.FP) * y.DP * 4, 256);
@@ -668,12 +668,13 @@ __device__ __forceinline__ float wave_dm_calc(const BwdArgs& p, int64_t n, const
 }
 
 // roles "feature chunk" (CHUNK) and "item": A = dz^T for the rows of n, B = eps (regenerated / injected) or V[cand]
+// (the item role covers at most 128 columns of dW_i = 4 N tiles: a 256-wide tile has two item roles, `ig` = which one)
 template <int D, int MODE, bool CHUNK, bool FOLD, bool DH, bool GEN>
-__device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int role, int dbase) {
+__device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int role, int dbase, int ig = 0) {
   constexpr int DP = D <= 32 ? 32 : (D + 63) / 64 * 64;
   constexpr int ND = D <= 32 ? 1 : 2;
   constexpr int NT = (D + 31) / 32;
-  constexpr int NB = CHUNK ? 4 : NT;      // N tiles of this role
+  constexpr int NB = CHUNK ? 4 : (NT < 4 ? NT : 4);      // N tiles of this role
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, c31 = lane & 31;
   const int S1 = p.S1, A = p.A, F = p.F, Dr = GEN ? p.Dr : D;
@@ -713,7 +714,7 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
     if (DH) { _Pragma("unroll") for (int mt = 0; mt < ND; ++mt) DHV[jj][mt] = p.dh[lr_ * DP + dbase + mt * 32 + c31]; } \
     if (!CHUNK) {                                                                                                \
       const float* vrow_ = p.V + (int64_t)p.cand[ns_] * Dr;                                                      \
-      _Pragma("unroll") for (int nt = 0; nt < NB; ++nt) BQ[jj][nt] = vrow_[min(nt * 32 + c31, Dr - 1)];          \
+      _Pragma("unroll") for (int nt = 0; nt < NB; ++nt) BQ[jj][nt] = vrow_[min((ig * 4 + nt) * 32 + c31, Dr - 1)]; \
     } else if (MODE == 1) {                                                                                      \
       _Pragma("unroll") for (int o = 0; o < NB; ++o)                                                             \
         BQ[jj][o] = p.noise[lr_ * F + min(role * 128 + 32 * o + c31, F - 1)];                                    \
@@ -889,7 +890,7 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
         const int mt = q / (NB * 16), o = (q / 16) % NB, r = q % 16;
         const int hh = j >> 3, c = 4 * (j & 7);
         const int d = dbase + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const int col = CHUNK ? Dr + role * 128 + 32 * o + c : o * 32 + c;
+        const int col = CHUNK ? Dr + role * 128 + 32 * o + c : (ig * 4 + o) * 32 + c;
         const bool ok = d < Dr && (CHUNK ? (role * 128 + 32 * o + c < F) : (col < Dr));
         if (ok) *reinterpret_cast<float4*>(&dstw[(int64_t)d * (Dr + F) + col]) = t;
       }
@@ -909,7 +910,7 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
 #pragma unroll
       for (int w = 1; w < BWD_NW; ++w) v += part[k][w];
       const int d = dbase + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      const int col = CHUNK ? Dr + role * 128 + 32 * o + c31 : o * 32 + c31;
+      const int col = CHUNK ? Dr + role * 128 + 32 * o + c31 : (ig * 4 + o) * 32 + c31;
       const bool ok = d < Dr && (CHUNK ? (role * 128 + 32 * o + c31 < F) : (col < Dr));
       if (ok) {
         if (p.gw_part) dst[(int64_t)d * (Dr + F) + col] = v;
@@ -932,11 +933,14 @@ __device__ __forceinline__ void bwd_col_role(const BwdArgs& p, float* red, int r
 #undef BWD_LOAD_BATCH
 
 // role "dx": gV[cand] += dz W_i   (MFMA: M = rows of n, N = d', K = d)
+// (a wave keeps at most 128 rows of W_i in registers: a 256-wide tile has two dx roles, `kh` = which half of the contraction — their
+// partial rows meet in the float atomics)
 template <int D, bool FOLD, bool DH, bool GEN>
-__device__ __forceinline__ void bwd_dx_role(const BwdArgs& p, int dbase) {
+__device__ __forceinline__ void bwd_dx_role(const BwdArgs& p, int dbase, int kh = 0) {
   constexpr int DP = D <= 32 ? 32 : (D + 63) / 64 * 64;
   constexpr int ND = D <= 32 ? 1 : 2;
-  constexpr int KD = D / 2;
+  constexpr int KD = (D < 128 ? D : 128) / 2;
+  const int k0 = kh * 128;                       // first contraction index of this role
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, c31 = lane & 31;
   const int S1 = p.S1, A = p.A, F = p.F, Dr = GEN ? p.Dr : D;
@@ -949,8 +953,8 @@ __device__ __forceinline__ void bwd_dx_role(const BwdArgs& p, int dbase) {
 #pragma unroll
     for (int nt = 0; nt < ND; ++nt) {
       const int dd = dbase + nt * 32 + c31;
-      const float wx = p.W[(int64_t)min(2 * j + h, Dr - 1) * (Dr + F) + min(dd, Dr - 1)];
-      wd[j][nt] = (dd < Dr && 2 * j + h < Dr) ? wx : 0.f;
+      const float wx = p.W[(int64_t)min(k0 + 2 * j + h, Dr - 1) * (Dr + F) + min(dd, Dr - 1)];
+      wd[j][nt] = (dd < Dr && k0 + 2 * j + h < Dr) ? wx : 0.f;
     }
   const int RT = (rpn + 31) / 32;
   for (int64_t n = n0; n < p.N; n += nstride) {
@@ -997,8 +1001,8 @@ __device__ __forceinline__ void bwd_dx_role(const BwdArgs& p, int dbase) {
         float hvv[JB], uxx[JB];
 #pragma unroll
         for (int jj = 0; jj < JB; ++jj) {           // issue the batch's loads ...
-          hvv[jj] = hrow[2 * (j0 + jj) + h];                       // (columns >= Dr of h are never written: masked below)
-          uxx[jj] = DH ? dhrow[2 * (j0 + jj) + h] : urow[min(2 * (j0 + jj) + h, Dr - 1)];
+          hvv[jj] = hrow[k0 + 2 * (j0 + jj) + h];                  // (columns >= Dr of h are never written: masked below)
+          uxx[jj] = DH ? dhrow[k0 + 2 * (j0 + jj) + h] : urow[min(k0 + 2 * (j0 + jj) + h, Dr - 1)];
         }
 #pragma unroll
         for (int jj = 0; jj < JB; ++jj) {           // ... then pin them (one wait for the batch)
@@ -1007,7 +1011,7 @@ __device__ __forceinline__ void bwd_dx_role(const BwdArgs& p, int dbase) {
         }
 #pragma unroll
         for (int jj = 0; jj < JB; ++jj) {
-          const bool on = hvv[jj] > 0.f && (D == Dr || 2 * (j0 + jj) + h < Dr);
+          const bool on = hvv[jj] > 0.f && (D == Dr || k0 + 2 * (j0 + jj) + h < Dr);
           const float a = DH ? ((on && lv) ? uxx[jj] * p.kscale : 0.f) : (on ? (dmv * uxx[jj]) * p.kscale : 0.f);
 #pragma unroll
           for (int nt = 0; nt < ND; ++nt) acc[nt] = MFMA32(a, wd[j0 + jj][nt], acc[nt]);
@@ -1063,21 +1067,23 @@ __global__ __launch_bounds__(64 * BWD_NW) BWD_WPE void k_bwd(BwdArgs p) {
   }
   constexpr int DW = (D_ <= 32 ? 1 : 2) * 32;
   constexpr int GY = D_ <= 64 ? 1 : D_ / 64;
+  constexpr int NI = D_ <= 128 ? 1 : D_ / 128;         // item roles (128 columns of dW_i each), dx roles (128 rows of W_i each)
   const int role = blockIdx.y / GY;
   const int dbase = (blockIdx.y % GY) * DW;
-  if ((int)blockIdx.y >= (p.NC + 2) * GY) {            // hosted untouched-row optimizer pass
+  if ((int)blockIdx.y >= (p.NC + 2 * NI) * GY) {       // hosted untouched-row optimizer pass
     opt_resolve(p.oj.a);
-    const int64_t bid = (int64_t)(blockIdx.y - (p.NC + 2) * GY) * gridDim.x + blockIdx.x;
+    const int64_t bid = (int64_t)(blockIdx.y - (p.NC + 2 * NI) * GY) * gridDim.x + blockIdx.x;
     const int64_t nblk = (int64_t)p.opt_rows_y * gridDim.x;
     if (p.oj.kind == DCCF_OPT_GD) opt_untouched_pass<DCCF_OPT_GD, 4>(p.oj, bid, nblk, 64 * BWD_NW);
     else if (p.oj.kind == DCCF_OPT_ADAGRAD) opt_untouched_pass<DCCF_OPT_ADAGRAD, 4>(p.oj, bid, nblk, 64 * BWD_NW);
     else opt_untouched_pass<DCCF_OPT_ADAM, 4>(p.oj, bid, nblk, 64 * BWD_NW);
     return;
   }
+  if (GEN && dbase >= p.Dr) return;                    // a column group of the tile that holds no real column (192 in the 256 tile)
   if (role < p.NC) bwd_col_role<D_, MODE, true, FOLD, DH, GEN>(p, red, role, dbase);
-  else if (role == p.NC) bwd_col_role<D_, MODE, false, FOLD, DH, GEN>(p, red, role, dbase);
-  else bwd_dx_role<D_, FOLD, DH, GEN>(p, dbase);
-  if (role > p.NC) TRACEB(7, 2);
+  else if (role < p.NC + NI) bwd_col_role<D_, MODE, false, FOLD, DH, GEN>(p, red, role, dbase, role - p.NC);
+  else bwd_dx_role<D_, FOLD, DH, GEN>(p, dbase, role - p.NC - NI);
+  if (role >= p.NC + NI) TRACEB(7, 2);
 }
 
 // ================================================================================================ K4: extra mlp layers
@@ -1417,7 +1423,8 @@ __global__ __launch_bounds__(256) void k_det_sum(DetArgs p, int row_blocks) {
 // ================================================================================================ host side
 static int check_model(const dccf_model_t* M) {
   ARG_CHECK(M != nullptr, "model is NULL");
-  ARG_CHECK(M->D >= 1 && M->D <= 128, "D must be in [1, 128]");
+  ARG_CHECK(M->D >= 1 && M->D <= 256, "D must be in [1, 256]");
+  ARG_CHECK(M->D <= 128 || M->n_extra == 0, "embedding sizes above 128 are built for --n_layers 1 (the extra layers keep W_k in LDS)");
   ARG_CHECK(M->F >= 1 && M->F <= 65536, "F must be in [1, 65536]");
   ARG_CHECK(M->S >= 0 && M->S <= 63 && M->A >= 1 && M->A <= 64, "S in [0,63], A in [1,64]");
   ARG_CHECK(M->user_num > 0 && M->item_num > 0 && M->item_num < 2147483647LL, "bad user_num / item_num");
@@ -1435,6 +1442,13 @@ static int check_model(const dccf_model_t* M) {
   else if ((D) <= 32) { CALL(32); }     \
   else if ((D) <= 64) { CALL(64); }     \
   else { CALL(128); }
+// forward / backward also have the 256-wide tile, as run-time-width instances only (embedding sizes 129 .. 256)
+#define BY_D_WIDE(D, CALL, CALL_WIDE)   \
+  if ((D) <= 16) { CALL(16); }          \
+  else if ((D) <= 32) { CALL(32); }     \
+  else if ((D) <= 64) { CALL(64); }     \
+  else if ((D) <= 128) { CALL(128); }   \
+  else { CALL_WIDE(256); }
 
 // The optimizer half of dccf_train_step, threaded through run_dccf: `overlap` forks the untouched-row pass onto the
 // context's side stream right after k_prep has marked the rows of this batch.
@@ -1649,7 +1663,11 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
   else if (y.FP == 896) LAUNCH_FWD3(D_, MODE_, 7, false, false, false)                                  \
   else LAUNCH_FWD3(D_, MODE_, 6, false, true, false)
 #define LAUNCH_FWD(D_) if (fused) LAUNCH_FWD2(D_, 0) else LAUNCH_FWD2(D_, 1)
-    BY_D(D, LAUNCH_FWD)
+#define LAUNCH_FWD2W(D_, MODE_) if (y.FP == 768) LAUNCH_FWD3(D_, MODE_, 6, false, false, true) else LAUNCH_FWD3(D_, MODE_, 6, false, true, true)
+#define LAUNCH_FWDW(D_) if (fused) LAUNCH_FWD2W(D_, 0) else LAUNCH_FWD2W(D_, 1)
+    BY_D_WIDE(D, LAUNCH_FWD, LAUNCH_FWDW)
+#undef LAUNCH_FWDW
+#undef LAUNCH_FWD2W
 #undef LAUNCH_FWD
 #undef LAUNCH_FWD2
 #undef LAUNCH_FWD3
@@ -1689,6 +1707,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
   // pair epilogue as its own launch (one workgroup: its loss sum then has one order), per-slot gradient rows + k_det_sum
   const bool det = ctx->det && train && !ctx->slot_where;
   ARG_CHECK(!det || N * (int64_t)(S1 * A + 1) < 2139062143LL, "deterministic mode: too many slots");
+  ARG_CHECK(!det || D <= 128, "deterministic mode covers embedding sizes up to 128 (above, two roles add into one gradient row)");
   const bool fold = train && NX == 0 && D == y.DT && S1 <= 16 && A <= 4 && N <= knobs().fold_max_n && !det;
   if (!fold) {
     const int64_t units = (train && rank == 1) ? N / 2 : N;
@@ -1705,7 +1724,9 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
   if (train) {
     // roles x column halves on grid.y, row splits on grid.x: about one workgroup per CU in total, 4 batch rows (one per
     // wave) per workgroup at least
-    const int roles = (y.NC + 2) * y.GY;
+    const int bwd_gy = y.DT <= 64 ? 1 : y.DT / 64;                 // the kernel's column groups (compile time, of the tile)
+    const int bwd_ni = y.DT <= 128 ? 1 : y.DT / 128;               // item roles = dx roles (128 columns / rows of W_i each)
+    const int roles = (y.NC + 2 * bwd_ni) * bwd_gy;
     // small batches: ~1 workgroup per CU; large ones: ~4 per CU (4 waves per SIMD fill the shared VALU / fp32-MFMA pipe)
     const int64_t gx = max((int64_t)1, min((N + BWD_NW - 1) / BWD_NW, (int64_t)max(1, (N >= 2048 ? 1024 : (int)knobs().bwd_wgs) / roles)));
     // hosted optimizer pass: as many extra workgroups as CUs (one beside each role workgroup)
@@ -1735,7 +1756,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     ba.det_u = ba.det_v = ba.det_gb = nullptr;
     ba.det_ld = y.DP * y.GY > 64 ? 128 : 64;
     const int64_t det_nv = A == 2 ? y.NS : y.L;            // item slots of the deterministic mode
-    const int64_t gx_det = max((int64_t)1, min((N + BWD_NW - 1) / BWD_NW, (int64_t)max(1, (N >= 2048 ? 1024 : (int)knobs().bwd_wgs) / ((y.NC + 2) * y.GY))));
+    const int64_t gx_det = max((int64_t)1, min((N + BWD_NW - 1) / BWD_NW, (int64_t)max(1, (N >= 2048 ? 1024 : (int)knobs().bwd_wgs) / ((y.NC + 2 * (y.DT <= 128 ? 1 : y.DT / 128)) * (y.DT <= 64 ? 1 : y.DT / 64)))));
     if (det) {
       const size_t need = ((size_t)(N + det_nv) * D + (size_t)gx_det * BWD_NW * ba.det_ld) * sizeof(float);
       if (need > ctx->det_bytes) {
@@ -1826,7 +1847,9 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
         ba.touchedV = nullptr;       // (the bytes are there already; the optimizer launch consumes them)
       }
     }
-    BY_D(D, LAUNCH_BWD)
+#define LAUNCH_BWDW(D_) if (fused) LAUNCH_BWD3(D_, 0, false, false, true) else LAUNCH_BWD3(D_, 1, false, false, true)
+    BY_D_WIDE(D, LAUNCH_BWD, LAUNCH_BWDW)
+#undef LAUNCH_BWDW
 #undef LAUNCH_BWD
 #undef LAUNCH_BWD2
 #undef LAUNCH_BWD3
@@ -2167,6 +2190,7 @@ extern "C" int dccf_eval_prepare(dccf_ctx* ctx, const dccf_model_t* M, float* Pf
   ARG_CHECK(ctx && Pf && Lt, "NULL argument");
   if (int e = check_model(M)) return e;
   ARG_CHECK(M->n_extra == 0, "projected evaluation noise covers --n_layers 1 (use --eval_noise full)");
+  ARG_CHECK(M->D <= 128, "projected evaluation noise covers embedding sizes up to 128 (use --eval_noise full)");
   hipStream_t st = (hipStream_t)stream;
   const int D = M->D, F = M->F;
   const Lay y = make_layout(0, D, F, M->S, M->A);
@@ -2205,6 +2229,7 @@ extern "C" int dccf_predict_projected(dccf_ctx* ctx, const dccf_model_t* M, cons
   if (int e = check_model(M)) return e;
   ARG_CHECK(rnd->mode == 1 && rnd->k_dev == nullptr, "projected predict draws everything on the device (rnd.mode = 1)");
   ARG_CHECK(M->n_extra == 0, "projected evaluation noise covers --n_layers 1 (use --eval_noise full)");
+  ARG_CHECK(M->D <= 128, "projected evaluation noise covers embedding sizes up to 128 (use --eval_noise full)");
   ARG_CHECK(N >= 0 && N * (int64_t)(M->S + 1) * M->A < 4294967296LL, "N*(S+1)*A must be < 2^32");
   ARG_CHECK(N == 0 || (X && prediction), "NULL X / prediction");
   ARG_CHECK(dropout >= 0.f && dropout < 1.f, "dropout must be in [0,1)");

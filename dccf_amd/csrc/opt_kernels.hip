@@ -416,7 +416,7 @@ int opt_make_job(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t
     // 16 / 32 / 64 / 128: every form of the pass.  Any other multiple of 4 up to 128 (src/models/RecModel.py:17-27 accepts any
     // embedding size): the row roles of the lazy optimizer (float4 slots of a row, integer arithmetic on the row number); the
     // streaming row-aware pass — whole rows per wave, shifts — then runs as the plain dense pass (launch_job)
-    ARG_CHECK(w >= 4 && w <= 128 && w % 4 == 0, "segment row width must be a multiple of 4 in [4, 128]");
+    ARG_CHECK(w >= 4 && w <= 256 && w % 4 == 0, "segment row width must be a multiple of 4 in [4, 256]");
     ARG_CHECK(seg_begin[q] % 256 == 0 && seg_rows[q] >= 0 && seg_begin[q] + seg_rows[q] * w <= n && seg_flags[q],
               "segment must start on a 256-float boundary, lie inside the buffer and have flags");
     sg.begin[q] = seg_begin[q];

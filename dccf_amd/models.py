@@ -431,6 +431,8 @@ class DCCF(DMF):
         self.n_layers = int(n_layers)
         if not 1 <= self.n_layers <= 8:
             raise ValueError('--n_layers must be in [1, 8] (src/models/DMF.py:14; the HIP path holds up to 7 extra D x D layers)')
+        if u_vector_size > 256 or (u_vector_size > 128 and self.n_layers > 1):
+            raise ValueError('embedding sizes up to 256 (src/models/RecModel.py:17-27 accepts any; above 128 with --n_layers 1 only)')
         self._feat_in, self._expo_in, self.ips_factors = feature_embedding, expo_prob, ips_factors
         RecModel.__init__(self, label_min=label_min, label_max=label_max, feature_num=feature_num, user_num=user_num,
                           item_num=item_num, u_vector_size=u_vector_size, i_vector_size=i_vector_size,
@@ -475,7 +477,7 @@ class DCCF(DMF):
         self.touchedU = torch.zeros((self.user_num + 3) // 4 * 4, dtype=torch.uint8, device=self.device)[:self.user_num]
         self.touchedV = torch.zeros((self.item_num + 3) // 4 * 4, dtype=torch.uint8, device=self.device)[:self.item_num]
         D = self.ui_vector_size
-        if D % 4 == 0 and 4 <= D <= 128:
+        if D % 4 == 0 and 4 <= D <= 256:
             # 16 / 32 / 64 / 128: every form of the optimizer pass.  Other multiples of 4 (src/models/RecModel.py:17-27 accepts any
             # size): the windowed lazy regularisation of train_step works on rows of any such width; dense calls on these segments
             # run the plain dense pass

@@ -159,8 +159,8 @@ class ShardedDCCF(object):
             raise ValueError('unknown optimizer ' + opt_name)
         if (ips_local is None) == (expo_local is None):
             raise ValueError('exposure: give the sharded IPS factors (ips_local) or the local rows of the dense matrix (expo_local)')
-        if not 1 <= D <= 128 or not 1 <= self.n_layers <= 8:
-            raise ValueError('embedding size 1 .. 128, n_layers 1 .. 8')
+        if not 1 <= D <= 256 or not 1 <= self.n_layers <= 8 or (D > 128 and self.n_layers > 1):
+            raise ValueError('embedding size 1 .. 256 (above 128: n_layers 1), n_layers 1 .. 8')
         self.F = feat_local.shape[1]
         self.nU = (user_num + world - 1 - rank) // world if user_num > rank else 0
         self.nI = (item_num + world - 1 - rank) // world if item_num > rank else 0

@@ -51,7 +51,8 @@ int dccf_profile_read(dccf_ctx* ctx, double* ms, int64_t* counts);
 /* ---- DCCF model view: replaces the attributes set up by DCCF._init_weights (src/models/DCCF.py:47-64) ----- */
 typedef struct {
   int64_t user_num, item_num;
-  int32_t D;            /* --u_vector_size == --i_vector_size (src/models/RecModel.py:17-27); any 1 <= D <= 128   */
+  int32_t D;            /* --u_vector_size == --i_vector_size (src/models/RecModel.py:17-27); any 1 <= D <= 256   */
+                        /* (above 128: n_extra must be 0, dccf_predict_projected and the deterministic mode do not apply) */
   int32_t F;            /* feature width, taken from the .npy (src/models/DCCF.py:59); any F >= 1               */
   int32_t S;            /* --sample-num   (src/models/DCCF.py:19)                                              */
   int32_t A;            /* --attribute-num (src/models/DCCF.py:20)                                             */
@@ -144,7 +145,7 @@ int dccf_train_fwdbwd(dccf_ctx* ctx, const dccf_model_t* model, const dccf_rand_
 int dccf_dense_opt_step(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t n, float lr, float wd,
                         float l2, float clip, int64_t step, int32_t zero_grad, void* stream);
 /* Same step for a flat buffer whose first part is row-structured: segment q covers elements [seg_begin[q], seg_begin[q] +
- * seg_rows[q]*seg_width[q]) as rows of seg_width[q] floats (a multiple of 4 up to 128; seg_begin a multiple of 256) with one
+ * seg_rows[q]*seg_width[q]) as rows of seg_width[q] floats (a multiple of 4 up to 256; seg_begin a multiple of 256) with one
  * "touched" byte per row (dccf_grads_t.touchedU/V).  Widths of 16, 32, 64 or 128 take the row-aware streaming pass described
  * next; any other width is legal everywhere the LAZY optimizer runs (dccf_train_step with lazy_K > 0, dccf_lazy_*) and makes
  * this entry the plain dense step (gradient read and re-zeroed everywhere, every touched byte cleared); the two-phase and hosted

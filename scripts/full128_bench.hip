@@ -7,6 +7,8 @@
 //   AL 1   the A operand (32 users x 128) in LDS instead of 64 registers per lane (fewer VGPRs: three workgroups per CU)
 //   NW     waves per workgroup (tile = NW x 32 items)
 //   DBG    bit 0: no global stores, bit 1: no MFMA, bit 2: B operand fetched once (no loads in the loop)
+//   k_full2: A in LDS, dwordx4 B loads, TWO register copies of the B operand — the loads of tile T + 2 are issued while tile T is
+//          multiplied, so a tile's operand has a whole tile time (MFMA + epilogue) to arrive instead of an epilogue
 // Diagnostic only; on the GPU box:
 //     hipcc --offload-arch=gfx950 -O3 -ffp-contract=off scripts/full128_bench.hip -o /tmp/full128 && /tmp/full128 > gpurun_out/full128_bench.txt
 #include <hip/hip_runtime.h>
@@ -197,6 +199,96 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
   }
 }
 
+
+// A in LDS (frees the 64 registers of the register-resident A), B double-buffered in registers: prefetch distance 2 tiles
+template <int NW, int WPE>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_full2(Args a) {
+  constexpr int D = 128, TW = NW * 32, CW = TW + 8, ALD = 68;
+  __shared__ __attribute__((aligned(16))) float Cs[2][32][CW];
+  __shared__ float Bu[32];
+  __shared__ __attribute__((aligned(16))) float As[2 * 32 * ALD];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane >> 5, c31 = lane & 31;
+  const int64_t gt = (a.I + TW - 1) / TW;
+  const int64_t band = blockIdx.x / a.splits, sp = blockIdx.x % a.splits;
+  const int64_t T0 = gt * sp / a.splits, T1 = gt * (sp + 1) / a.splits;
+  const int64_t u0 = band * 32;
+  for (int idx = threadIdx.x; idx < 32 * D; idx += 64 * NW) {
+    const int row = idx / D, e = idx % D;
+    As[((e & 1) * 32 + row) * ALD + (e >> 1)] = a.P[min(u0 + row, a.U - 1) * D + e];
+  }
+  if (threadIdx.x < 32) Bu[threadIdx.x] = a.bu[min(u0 + (int64_t)threadIdx.x, a.U - 1)];
+  __syncthreads();
+  float4 qa[16], qb[16];
+  float bina = 0.f, prna = 1.f, binb = 0.f, prnb = 1.f;
+#define PREF(T_, Q_, BIN_, PRN_)                                                                                                       \
+  {                                                                                                                                    \
+    const int64_t i_ = min((T_) * TW + wave * 32 + c31, a.I - 1);                                                                      \
+    const float4* qc_ = reinterpret_cast<const float4*>(a.QT4) + (T_) * (int64_t)(D * TW / 4) + (int64_t)h * TW + wave * 32 + c31;      \
+    _Pragma("unroll") for (int q = 0; q < 16; ++q) Q_[q] = qc_[(int64_t)q * 2 * TW];                                                   \
+    BIN_ = a.bi[i_];                                                                                                                   \
+    PRN_ = fmaxf(a.prop[i_], a.Mclip);                                                                                                 \
+  }
+  int buf = 0;
+#define TILE(T_, Q_, BIN_, PRN_)                                                                                                       \
+  {                                                                                                                                    \
+    const float bic = BIN_ + a.b0, prc = PRN_;                                                                                         \
+    const float rinv = 1.0f / prc;                                                                                                     \
+    const int64_t c0 = (T_) * TW;                                                                                                      \
+    f32x16 acc;                                                                                                                        \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[r] = 0.f;                                                                       \
+    const float4* ap = reinterpret_cast<const float4*>(&As[(h * 32 + c31) * ALD]);                                                     \
+    _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                                                                   \
+      const float4 av = ap[q];                                                                                                         \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, Q_[q].x, acc, 0, 0, 0);                                                         \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, Q_[q].y, acc, 0, 0, 0);                                                         \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, Q_[q].z, acc, 0, 0, 0);                                                         \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, Q_[q].w, acc, 0, 0, 0);                                                         \
+    }                                                                                                                                  \
+    if ((T_) + 2 < T1) PREF((T_) + 2, Q_, BIN_, PRN_)                                                                                  \
+    float (*C)[CW] = Cs[buf];                                                                                                          \
+    buf ^= 1;                                                                                                                          \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                                   \
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;                                                                                  \
+      float v = acc[r] + Bu[row] + bic;                                                                                                \
+      const float q = v * rinv;                                                                                                        \
+      v = fmaf(fmaf(-q, prc, v), rinv, q);                                                                                             \
+      C[row][wave * 32 + c31] = v;                                                                                                     \
+    }                                                                                                                                  \
+    __syncthreads();                                                                                                                   \
+    if (c0 + TW <= a.I && u0 + 32 <= a.U) {                                                                                            \
+      float* orow = a.out + (u0 + wave) * a.I + c0 + lane;                                                                             \
+      _Pragma("unroll") for (int rr = 0; rr < 32 / NW; ++rr) {                                                                         \
+        _Pragma("unroll") for (int q = 0; q < TW / 64; ++q) orow[q * 64] = C[wave + NW * rr][q * 64 + lane];                           \
+        orow += (int64_t)NW * a.I;                                                                                                     \
+      }                                                                                                                                \
+    } else {                                                                                                                           \
+      _Pragma("unroll") for (int rr = 0; rr < 32 / NW; ++rr) {                                                                         \
+        const int row = wave + NW * rr;                                                                                                \
+        const int64_t u = u0 + row;                                                                                                    \
+        if (u < a.U) {                                                                                                                 \
+          float* orow = a.out + u * a.I + c0;                                                                                          \
+          _Pragma("unroll") for (int q = 0; q < TW / 64; ++q) {                                                                        \
+            const int c = q * 64 + lane;                                                                                               \
+            if (c0 + c < a.I) orow[c] = C[row][c];                                                                                     \
+          }                                                                                                                            \
+        }                                                                                                                              \
+      }                                                                                                                                \
+    }                                                                                                                                  \
+  }
+  if (T0 < T1) PREF(T0, qa, bina, prna)
+  if (T0 + 1 < T1) PREF(T0 + 1, qb, binb, prnb)
+  for (int64_t T = T0; T < T1; T += 2) {
+    TILE(T, qa, bina, prna)
+    if (T + 1 < T1) TILE(T + 1, qb, binb, prnb)
+  }
+#undef PREF
+#undef TILE
+}
+
+template <int NW, int WPE>
+static int run2(Args a, const char* name);
+
 static std::vector<float> hP, hQ, hbu, hbi, hprop;
 
 template <int NW, int LD, int ST, int AL, int DBG, int WPE>
@@ -256,6 +348,53 @@ static int run(Args a, const char* name, float* hout_check) {
   return 0;
 }
 
+template <int NW, int WPE>
+static int run2(Args a, const char* name) {
+  constexpr int TW = NW * 32;
+  const int64_t bands = (a.U + 31) / 32, gt = (a.I + TW - 1) / TW;
+  a.splits = gt >= 64 ? 32 : (gt >= 16 ? 8 : 1);
+  a.Ipad = gt * TW;
+  float* QT4 = nullptr;
+  CHECK(hipMalloc((void**)&QT4, (size_t)a.Ipad * 128 * 4));
+  hipLaunchKernelGGL(k_qt4, dim3(4096), dim3(256), 0, 0, a.Q, a.I, a.Ipad, TW, QT4);
+  a.QT4 = QT4;
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  float best = 1e9f;
+  for (int it = 0; it < 6; ++it) {
+    CHECK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL((k_full2<NW, WPE>), dim3((unsigned)(bands * a.splits)), dim3(64 * NW), 0, 0, a);
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (it >= 1 && ms < best) best = ms;
+  }
+  CHECK(hipGetLastError());
+  double maxerr = 0.0;
+  uint64_t st = 12345;
+  for (int t = 0; t < 200; ++t) {
+    st = st * 6364136223846793005ULL + 1442695040888963407ULL;
+    int64_t u = (int64_t)((st >> 33) % (uint64_t)a.U), i = (int64_t)((st >> 13) % (uint64_t)a.I);
+    if (t == 0) { u = 0; i = 0; }
+    if (t == 1) { u = a.U - 1; i = a.I - 1; }
+    if (t == 2) { u = 1; i = a.I - 1; }
+    if (t == 3) { u = a.U - 1; i = 0; }
+    float got = 0.f;
+    CHECK(hipMemcpy(&got, a.out + u * a.I + i, 4, hipMemcpyDeviceToHost));
+    double ref = 0.0;
+    for (int k = 0; k < 128; ++k) ref += (double)hP[u * 128 + k] * (double)hQ[i * 128 + k];
+    ref = (ref + hbu[u] + hbi[i] + a.b0) / fmax((double)hprop[i], (double)a.Mclip);
+    maxerr = fmax(maxerr, fabs(ref - (double)got));
+  }
+  printf("%-44s NW %d double-buffered B, A in LDS, WPE %d : %7.3f ms  %6.1f TFLOP/s  max|err| %.2e\n", name, NW, WPE, best,
+         2.0 * (double)a.U * (double)a.I * 128.0 / best / 1e9, maxerr);
+  fflush(stdout);
+  CHECK(hipFree(QT4));
+  return 0;
+}
+
 int main() {
   const int64_t U = 75258, I = 64443;
   hP.resize(U * 128); hQ.resize(I * 128); hbu.resize(U); hbi.resize(I); hprop.resize(I);
@@ -276,6 +415,9 @@ int main() {
   CHECK(hipMemcpy(prop, hprop.data(), I * 4, hipMemcpyHostToDevice));
   a.P = P; a.Q = Q; a.bu = bu; a.bi = bi; a.prop = prop; a.b0 = 0.1f; a.Mclip = 0.1f; a.out = out; a.U = U; a.I = I;
   int rc = 0;
+  rc |= run2<4, 2>(a, "prefetch distance 2");
+  rc |= run2<4, 3>(a, "prefetch distance 2, 3 waves per SIMD");
+  rc |= run2<8, 2>(a, "8 waves: prefetch distance 2");
   rc |= run<4, 0, 0, 0, 0, 2>(a, "current form (round 2)", out);
   rc |= run<4, 0, 0, 0, 1, 2>(a, "  no stores", out);
   rc |= run<4, 0, 0, 0, 2, 2>(a, "  no MFMA", out);

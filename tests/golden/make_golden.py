@@ -268,6 +268,18 @@ def gen_dccf_ext(outdir):
     ])
 
 
+def gen_dccf_wide(outdir):
+    """Round-3 cases: embedding sizes above 128 (src/models/RecModel.py:17-27 accepts any u_vector_size == i_vector_size), with
+    their own torch seed so that the earlier fixtures regenerate bit for bit."""
+    torch.manual_seed(2021)
+    gen_dccf(outdir, cases=[
+        # name, U, I, D, F, pairs, S, A, std, dropout, optimizer, lr, l2, steps, rank, init_scale, n_layers
+        ('dccf_d192_f768_adam', 20, 25, 192, 768, 2, 10, 2, 0.1, 0.2, 'Adam', 0.001, 1e-4, 2, 1, 10.0, 1),
+        ('dccf_d256_f96_adagrad', 16, 20, 256, 96, 3, 4, 2, 0.2, 0.3, 'Adagrad', 0.01, 1e-3, 2, 1, 10.0, 1),
+        ('dccf_d160_f1000_gd_mse', 18, 22, 160, 1000, 2, 6, 2, 0.1, 0.2, 'GD', 0.01, 1e-4, 2, 0, 10.0, 1),
+    ])
+
+
 # ----------------------------------------------------------------------------- G2: MF family
 def gen_mf(outdir):
     from models.RecModel import RecModel
@@ -573,6 +585,8 @@ if __name__ == '__main__':
         gen_metrics(HERE)
     if 'dccf_ext' in which:
         gen_dccf_ext(HERE)
+    if 'dccf_wide' in which:
+        gen_dccf_wide(HERE)
     if 'e2e' in which:
         gen_e2e(HERE)
     if 'e2e_init' in which:

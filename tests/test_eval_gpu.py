@@ -226,7 +226,7 @@ def test_device_train_set_flags_a_user_without_admissible_negative():
     full, tail = ds.epoch_batches(0, 4)
     X = np.concatenate([full.cpu().numpy().reshape(-1, 2), tail.cpu().numpy()])
     assert X.min() >= 0 and X[:, 1].max() < I_
-    with pytest.raises(AssertionError, match='no admissible'):
+    with pytest.raises(RuntimeError, match='no admissible'):
         ds.check_negatives()
     ok = DeviceTrainSet(uid[I_:], iid[I_:], 3, I_, seed=5)
     ok.epoch_batches(0, 4)

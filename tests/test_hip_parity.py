@@ -16,7 +16,9 @@ DCCF_CASES = ['dccf_d16_f32_adam', 'dccf_d64_f768_adam', 'dccf_d64_f32_nodrop_gd
               # round 2: --n_layers 2 / 3 (src/models/DCCF.py:61-62,91-94), widths that are not a kernel tile
               # (src/models/RecModel.py:17-27), feature files wider than 896 (src/models/DCCF.py:59)
               'dccf_d64_f768_l2_adam', 'dccf_d24_f100_l3_adagrad', 'dccf_d48_f1024_adam', 'dccf_d100_f800_gd',
-              'dccf_d128_f32_l2_mse']
+              'dccf_d128_f32_l2_mse',
+              # round 3: embedding sizes above 128 (the 256 column tile with a run-time width; src/models/RecModel.py:17-27)
+              'dccf_d192_f768_adam', 'dccf_d256_f96_adagrad', 'dccf_d160_f1000_gd_mse']
 PKEYS = ['uid_embeddings.weight', 'iid_embeddings.weight', 'mlp.0.weight', 'mlp.0.bias']
 
 

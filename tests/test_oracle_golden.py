@@ -11,7 +11,9 @@ DCCF_CASES = ['dccf_d16_f32_adam', 'dccf_d64_f768_adam', 'dccf_d64_f32_nodrop_gd
               'dccf_d128_f768_adam', 'dccf_d64_f768_mse',
               # round 2 (make_golden.py dccf_ext): --n_layers 2 / 3, widths that are not a kernel tile, F > 896
               'dccf_d64_f768_l2_adam', 'dccf_d24_f100_l3_adagrad', 'dccf_d48_f1024_adam', 'dccf_d100_f800_gd',
-              'dccf_d128_f32_l2_mse']
+              'dccf_d128_f32_l2_mse',
+              # round 3: embedding sizes above 128 (src/models/RecModel.py:17-27 accepts any)
+              'dccf_d192_f768_adam', 'dccf_d256_f96_adagrad', 'dccf_d160_f1000_gd_mse']
 
 
 def pkeys(g):
