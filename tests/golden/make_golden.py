@@ -568,6 +568,58 @@ def gen_e2e_init(outdir):
         shutil.rmtree(tmp)
 
 
+def gen_fit_rate(outdir):
+    """the UNMODIFIED reference's own `BaseRunner.fit` rate (pairs/s = len(train) / seconds of one fit
+    epoch, per-epoch negative sampling and batching included, second epoch onward) at D = 64 on the 5k x 5k set, the README
+    hyper-parameters, all the container's threads.  Prints one JSON line (recorded in BASELINE.md / profiles/)."""
+    import json
+    import logging
+    import time
+    from dccf_amd import synth
+    from data_loaders.DataLoader import DataLoader
+    from data_processor.DataProcessor import DataProcessor
+    from runners.BaseRunner import BaseRunner
+    from models.DCCF import DCCF
+    c = dict(E2E_CONFIGS['c1'], D=int(os.environ.get('FIT_D', '64')))
+    CAP.enabled = False
+    tmp = tempfile.mkdtemp()
+    cwd = os.getcwd()
+    try:
+        os.makedirs(os.path.join(tmp, 'src'))
+        synth.write_dataset(os.path.join(tmp, 'dataset'), 'toy', c['user_num'], c['item_num'], c['n_draws'],
+                            feat_dim=c['feat_dim'], seed=c['data_seed'])
+        os.chdir(os.path.join(tmp, 'src'))
+        logging.basicConfig(level=logging.WARNING)
+        torch.manual_seed(2019)
+        np.random.seed(2019)
+        dl = DataLoader(path='../dataset/', dataset='toy', label='label', sep=',')
+        dl.feature_info(include_id=DCCF.include_id, include_item_features=DCCF.include_item_features,
+                        include_user_features=DCCF.include_user_features)
+        model = DCCF(path=dl.path, dataset=dl.dataset, sentence_model='paraphrase-distilroberta-base-v1', sample_num=10,
+                     attribute_num=2, std=0.1, label_min=dl.label_min, label_max=dl.label_max, feature_num=0,
+                     user_num=dl.user_num, item_num=dl.item_num, u_vector_size=c['D'], i_vector_size=c['D'], n_layers=1,
+                     random_seed=2019, model_path=os.path.join(tmp, 'm.pt'))
+        model.apply(model.init_paras)
+        dl.drop_neg()
+        dp = DataProcessor(dl, model, rank=1, test_neg_n=c['test_neg_n'])
+        runner = BaseRunner(optimizer='Adam', learning_rate=0.001, epoch=2, batch_size=128, eval_batch_size=128 * 128,
+                            dropout=0.2, l2=1e-4, metrics='ndcg@5,recall@5,precision@5', check_epoch=0, early_stop=1)
+        n_epochs = int(os.environ.get('FIT_EPOCHS', '2'))
+        secs = []
+        for e in range(n_epochs):
+            train = dp.get_train_data(epoch=e)
+            t0 = time.time()
+            runner.fit(model, train, dp, epoch=e)
+            secs.append(time.time() - t0)
+        n = len(dl.train_df)
+        print(json.dumps({'what': 'unmodified reference BaseRunner.fit (src/runners/BaseRunner.py:159-191), CPU', 'D': c['D'],
+                          'users': c['user_num'], 'items': c['item_num'], 'train_pairs': n, 'threads': torch.get_num_threads(),
+                          'fit_seconds_per_epoch': [round(x, 2) for x in secs], 'pairs_per_s': [round(n / x, 1) for x in secs]}), flush=True)
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp)
+
+
 if __name__ == '__main__':
     install_shims()
     which = sys.argv[1:] or ['dccf', 'mf', 'opt', 'batches', 'metrics']
@@ -591,3 +643,5 @@ if __name__ == '__main__':
         gen_e2e(HERE)
     if 'e2e_init' in which:
         gen_e2e_init(HERE)
+    if 'fit_rate' in which:
+        gen_fit_rate(HERE)
