@@ -1708,7 +1708,7 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
   const bool det = ctx->det && train && !ctx->slot_where;
   ARG_CHECK(!det || N * (int64_t)(S1 * A + 1) < 2139062143LL, "deterministic mode: too many slots");
   ARG_CHECK(!det || D <= 128, "deterministic mode covers embedding sizes up to 128 (above, two roles add into one gradient row)");
-  const bool fold = train && NX == 0 && D == y.DT && S1 <= 16 && A <= 4 && N <= knobs().fold_max_n && !det;
+  const bool fold = train && NX == 0 && D == y.DT && D <= 128 && S1 <= 16 && A <= 4 && N <= knobs().fold_max_n && !det;      // (the 256 tile has run-time-width instances only)
   if (!fold) {
     const int64_t units = (train && rank == 1) ? N / 2 : N;
     const int GS = S1 <= 16 ? 16 : (S1 <= 32 ? 32 : 64);
