@@ -565,8 +565,8 @@ def test_argument_errors_are_reported(L, ctx):
         L.dense_opt_step('adam', t.view(-1), t.view(-1), None, None, 0.1, 0, 0, 50, 1)
     with pytest.raises(RuntimeError):
         L.dense_opt_step('adam', torch.zeros(4), torch.zeros(4), torch.zeros(4), torch.zeros(4), 0.1, 0, 0, 50, 1)  # CPU tensors
-    W = torch.zeros(130, 130 + 8, device=dev())      # wider than the largest column tile
-    m = L.model_struct(torch.zeros(5, 130, device=dev()), torch.zeros(5, 130, device=dev()), W, torch.zeros(130, device=dev()),
+    W = torch.zeros(260, 260 + 8, device=dev())      # wider than the largest column tile (256 since round 3)
+    m = L.model_struct(torch.zeros(5, 260, device=dev()), torch.zeros(5, 260, device=dev()), W, torch.zeros(260, device=dev()),
                        torch.zeros(5, 8, device=dev()), torch.zeros(5, 5, device=dev()), 10, 2, 0.1)
     with pytest.raises(RuntimeError, match='D must be'):
         L.dccf_predict(ctx, m, L.rand_struct(seed=1), torch.zeros(2, 2, dtype=torch.int64, device=dev()), 0.0)
