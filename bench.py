@@ -344,7 +344,7 @@ def main():
         kernels['k_prep (unprepared steps only: %d of %d)' % (timed_counts['prep'], n_prof)] = timed['prep']
     pmc = None
     try:
-        pmc = json.load(open(os.path.join(REPO, 'profiles', 'r02_pmc_traffic.json')))['_meta']
+        pmc = json.load(open(os.path.join(REPO, 'profiles', 'r03_pmc_traffic.json')))['_meta']
     except Exception:
         pass
 
@@ -357,7 +357,7 @@ def main():
                 'frac': round(gb / (ms / 1e3) / HBM_PEAK_GBS, 4),
                 'traffic': round(pmc['dense_adam_bytes_per_param'] * (n_params - hosted * D) / 1e9, 4) if pmc else None,
                 'traffic_unit': 'GB per launch; NOT measured in this run: bytes/param of the separate rocprofv3 --pmc FETCH_SIZE / '
-                                'WRITE_SIZE passes committed as profiles/r02_pmc_traffic.json',
+                                'WRITE_SIZE passes committed as profiles/r03_pmc_traffic.json',
                 'algorithmic_per_launch': round(gb, 4), 'avg_launch_ms': round(ms, 5),
                 'hosted_in_backward_launch': {'item_rows': hosted, 'GB': round(24.0 * hosted * D / 1e9, 4)}}
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # bash scripts/collect_profiles.sh  (on the GPU box, from the repo root): the bench lines, rocprofv3 kernel statistics of the three
-# layouts and the PMC traffic passes behind profiles/r02_*; everything lands in gpurun_out/final/ (copy what is to be kept).
+# layouts and the PMC traffic passes behind profiles/r03_*; everything lands in gpurun_out/final/ (copy what is to be kept).
 set -e
 OUT=$PWD/gpurun_out/final
 mkdir -p $OUT
@@ -22,6 +22,6 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p
 cd $OLDPWD
 echo "rocprof done"
 for d in lazy dense repl shard; do f=$(find $OUT/prof_$d -name "*kernel_stats.csv" | head -1); python scripts/prof_summary.py $f > $OUT/stats_$d.md; rm -rf $OUT/prof_$d; done
-PMC_OUT=gpurun_out/final timeout -k 10 600 python scripts/pmc_traffic.py r02 > $OUT/pmc.log 2>&1
+PMC_OUT=gpurun_out/final timeout -k 10 600 python scripts/pmc_traffic.py r03 > $OUT/pmc.log 2>&1
 rm -rf gpurun_out/pmc
 echo "all done"
