@@ -103,6 +103,29 @@ def test_mark_global_matches_oracle_streams():
     assert sorted(got) == sorted(list(users) + [(1 << 40) | i for i in items])
 
 
+def test_mark_global_without_list_and_counters():
+    """The public C entry with NULL list / counters (bytes only — how the replicated step marks an unannounced step's rows): round 2
+    found k_dp_mark writing `*cnt_next = 0` through the NULL counter there (a GPU abort, fixed in 9fc7d5d); this calls the entry
+    that way directly.  The bytes must be exactly the rows of X_all and of every rank's Philox candidates."""
+    import ctypes as C
+    from dccf_amd import _lib as L
+    from oracle import philox as PH
+    U, I, G, N, S, seed, step0 = 1003, 517, 3, 40, 10, 77, 12
+    rng = np.random.RandomState(1)
+    X_all = np.stack([np.stack([rng.randint(0, U, N), rng.randint(0, I, N)], 1) for _ in range(G)]).astype(np.int64)
+    Xd = torch.as_tensor(X_all).cuda()
+    fU = torch.zeros((U + 3) // 4 * 4, dtype=torch.uint8, device='cuda')[:U]
+    fV = torch.zeros((I + 3) // 4 * 4, dtype=torch.uint8, device='cuda')[:I]
+    L.check(L.load().dp_mark_global(L.ptr(Xd, torch.int64), G, N, S, I, seed, step0, L.ptr(fU, torch.uint8), L.ptr(fV, torch.uint8),
+                                    0, 1, None, None, None, L.stream()))
+    torch.cuda.synchronize()
+    users, items = set(X_all[:, :, 0].reshape(-1).tolist()), set(X_all[:, :, 1].reshape(-1).tolist())
+    for r in range(G):
+        items |= set(PH.candidates(seed, step0 + r, N, S, I).reshape(-1).tolist())
+    assert sorted(torch.nonzero(fU).flatten().tolist()) == sorted(users)
+    assert sorted(torch.nonzero(fV).flatten().tolist()) == sorted(items)
+
+
 @pytest.mark.parametrize('overlap', [False, True, 'prep'])
 def test_replicated_trainer_world1_equals_single_gpu_step(overlap):
     """At G = 1 the replicated step (fwd/bwd -> export -> [all_gather] -> import -> Adam), with and without the optimizer
