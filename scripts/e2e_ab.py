@@ -10,6 +10,7 @@ Arms (what differs from the reference in each is listed in profiles/r02_e2e_ab.m
   host_sampling  --fused_sampling 0: the reference's numpy sampling, bit-identical batches and evaluation negatives
   graph          --use_graph 1: the step replayed as one hipGraph
   host_eval      --device_eval 0: the reference's host-side metric code
+  torch_perm     DCCF_TORCH_PERM=1: the epoch's permutation by torch.randperm instead of the keyed bijection
 """
 import argparse
 import json
@@ -34,6 +35,8 @@ ARMS = {
     'projected': ['--eval_noise', 'projected'],
     # diagnostic: candidates / noise / dropout masks from torch's generator through the injected kernel path (no Philox)
     'torch_draws': ['--fused_sampling', '0', '--device_eval', '0'],
+    # diagnostic: the epoch's permutation from torch.randperm instead of the keyed bijection of k_epoch_batches
+    'torch_perm': [],
 }
 
 
@@ -79,10 +82,13 @@ def main():
                         '--verbose', str(logging.WARNING)] + ARMS[arm]
                 if arm == 'torch_draws':
                     os.environ['DCCF_TORCH_DRAWS'] = '1'
+                if arm == 'torch_perm':
+                    os.environ['DCCF_TORCH_PERM'] = '1'
                 try:
                     runner = M.main(argv)
                 finally:
                     os.environ.pop('DCCF_TORCH_DRAWS', None)
+                    os.environ.pop('DCCF_TORCH_PERM', None)
                 valid.append(runner.valid_results)
                 test.append(runner.test_results)
                 init.append(runner.init_results[1])
