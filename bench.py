@@ -342,11 +342,19 @@ def main():
                 % (timed_counts['lazy_catchup'], n_prof)] = timed['lazy_catchup']
     if 'prep' in timed:
         kernels['k_prep (unprepared steps only: %d of %d)' % (timed_counts['prep'], n_prof)] = timed['prep']
-    pmc = None
+    pmc, pmc_all = None, {}
     try:
-        pmc = json.load(open(os.path.join(REPO, 'profiles', 'r03_pmc_traffic.json')))['_meta']
+        pmc_all = json.load(open(os.path.join(REPO, 'profiles', 'r03_pmc_traffic.json')))
+        pmc = pmc_all['_meta']
     except Exception:
         pass
+    PMC_NOTE = ('MB of HBM traffic per launch; NOT measured in this run: the separate rocprofv3 --pmc FETCH_SIZE (doubled, as '
+                'MI355X_MICROARCH.md prescribes for gfx950) / --pmc WRITE_SIZE passes of the same command at this batch size, committed as '
+                'profiles/r03_pmc_traffic.json')
+
+    def pmc_mb(short):
+        v = pmc_all.get(short)
+        return round(v['total_mb'], 2) if (v and B == 128 and D == 64 and F == 768) else None
 
     def dense_launch(ms, hosted):
         """The HBM-bound form of the optimizer launch: 24 B per parameter it streams."""
@@ -372,7 +380,8 @@ def main():
         roofline = {'kernel': 'k_lazy_opt<Adam> (windowed lazy regularisation, K = %d: the rows the step touched, W, b and one K-th of '
                               'the other rows, advanced K steps in registers; + the next step\'s preparation)' % lazy.K,
                     'bound': 'hbm', 'achieved': round(gb / (kernels[dom] / 1e3), 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(gb / (kernels[dom] / 1e3) / HBM_PEAK_GBS, 4), 'traffic': None,
+                    'frac': round(gb / (kernels[dom] / 1e3) / HBM_PEAK_GBS, 4), 'traffic': pmc_mb('lazy_opt (K = 8)'),
+                    'traffic_unit': PMC_NOTE,
                     'algorithmic_per_launch': round(gb, 4), 'avg_launch_ms': round(kernels[dom], 5),
                     'note': 'NOT an HBM-bound launch any more: the replay (2 IEEE divisions + 1 square root per element and step, the '
                             'dense pass\'s exact operation order) is bound by the vector ALU — 16.4 M element-steps cost >= 21 us '
@@ -382,7 +391,8 @@ def main():
         tf = fwd_tf if dom == 'noise_fwd' else bwd_tf
         achieved = tf / (kernels[dom] / 1e3)
         roofline = {'kernel': dom, 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
+                    'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+                    'traffic': pmc_mb('noise_fwd' if dom == 'noise_fwd' else 'noise_bwd_eps'), 'traffic_unit': PMC_NOTE,
                     'algorithmic_per_launch': round(tf, 6), 'avg_launch_ms': round(kernels[dom], 5)}
     roofline.update({
         'launch_structure': 'dccf_train_step with X_next: the launches the timed region runs, bracketed by HIP events inside the '
