@@ -84,6 +84,55 @@ def test_cli_training_matches_reference_on_config1_shape(tmp_path):
     _cli_vs_reference(str(tmp_path), load_golden('e2e_c1'), check_artefacts=False)
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(GOLDEN, 'e2e_c1_init.npz')), reason='config-1 untrained-model golden not generated')
+def test_untrained_model_matches_reference_on_config1_shape(tmp_path):
+    """The evaluation path alone (evaluation negatives, candidates, noise, metric code) on BASELINE config 1's shape: the
+    UNTRAINED model's validation NDCG@5 — what the reference's `Init:` line reports — over as many seeds as the reference side has
+    (tests/golden/e2e_c1_init.npz: 102 seeds of the reference's own DataLoader / DCCF / DataProcessor / BaseRunner.evaluate,
+    tests/golden/make_golden.py e2e_init).  Round 2 saw +0.0013 at 2.6 standard errors with 11 vs 24 seeds; with ~100 seeds per
+    side the standard error of the difference is ~2.3e-4 and the bound is 2 se + 1e-3 (north_star: NDCG within 1e-3)."""
+    from dccf_amd import synth
+    from dccf_amd.data_loader import DataLoader
+    from dccf_amd.data_processor import DataProcessor
+    from dccf_amd.models import DCCF
+    from dccf_amd.runner import BaseRunner
+    g = load_golden('e2e_c1_init')
+    ref = g['init_valid'][:, 0].astype(np.float64)
+    tmp = str(tmp_path)
+    synth.write_dataset(os.path.join(tmp, 'dataset'), 'toy', int(g['user_num']), int(g['item_num']), int(g['n_draws']),
+                        feat_dim=int(g['feat_dim']), seed=int(g['data_seed']))
+    cwd = os.getcwd()
+    os.makedirs(os.path.join(tmp, 'src'), exist_ok=True)
+    os.chdir(os.path.join(tmp, 'src'))
+    try:
+        dl = DataLoader(path='../dataset/', dataset='toy', label='label', sep=',')
+        dl.feature_info(include_id=DCCF.include_id, include_item_features=DCCF.include_item_features,
+                        include_user_features=DCCF.include_user_features)
+        dl.drop_neg()
+        D, mine = int(g['D']), []
+        for seed in [int(x) for x in g['seeds']]:
+            torch.manual_seed(seed)
+            np.random.seed(seed)
+            model = DCCF(path=dl.path, dataset=dl.dataset, sentence_model='paraphrase-distilroberta-base-v1', sample_num=10,
+                         attribute_num=2, std=0.1, label_min=dl.label_min, label_max=dl.label_max, feature_num=0,
+                         user_num=dl.user_num, item_num=dl.item_num, u_vector_size=D, i_vector_size=D, n_layers=1,
+                         random_seed=seed, model_path=os.path.join(tmp, 'm.pt'))
+            model.apply(model.init_paras)
+            dp = DataProcessor(dl, model, rank=1, test_neg_n=int(g['test_neg_n']), seed=seed, fused_eval=True)
+            runner = BaseRunner(optimizer='Adam', learning_rate=float(g['lr']), epoch=0, batch_size=int(g['batch_size']),
+                                eval_batch_size=128 * 128, dropout=0.2, l2=1e-4, metrics='ndcg@5,recall@5,precision@5',
+                                check_epoch=0, early_stop=1)
+            mine.append(float(runner.evaluate(model, dp.get_validation_data(), dp)[0]))
+            del model, dp
+    finally:
+        os.chdir(cwd)
+    mine = np.array(mine)
+    se = np.sqrt(ref.var(ddof=1) / len(ref) + mine.var(ddof=1) / len(mine))
+    assert se <= 5e-4, se
+    assert abs(mine.mean() - ref.mean()) <= 2 * se + 1e-3, 'untrained model: mine %.5f vs reference %.5f (se %.5f, %d / %d seeds)' % (
+        mine.mean(), ref.mean(), se, len(mine), len(ref))
+
+
 def test_exposure_pipeline_ipsbiasedmf_then_dccf(tmp_path):
     """README.md:28-30: train IPSBiasedMF, save the full predicted matrix as <ds>.ips_expo_prob.npy, train DCCF on it.
     Also covers the reference host sampling path (--fused_sampling 0) and checkpoint reload."""
