@@ -262,7 +262,7 @@ class RecModel(BaseModel):
         # one "touched" byte per embedding row (set by the backward) for the row-aware dense optimizer step; the bias
         # vectors and the global bias stay dense
         self.touchedP = self.touchedQ = None
-        if self.ui_vector_size in (16, 32, 64, 128):
+        if self.ui_vector_size % 4 == 0 and 4 <= self.ui_vector_size <= 256:      # (rows of whole float4 slots; see DCCF._allocate)
             self.touchedP = torch.zeros((self.user_num + 3) // 4 * 4, dtype=torch.uint8, device=self.device)[:self.user_num]
             self.touchedQ = torch.zeros((self.item_num + 3) // 4 * 4, dtype=torch.uint8, device=self.device)[:self.item_num]
             self.row_segments = [(self.offsets['uid_embeddings.weight'], self.user_num, self.ui_vector_size, self.touchedP),

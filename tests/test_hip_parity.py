@@ -1116,10 +1116,11 @@ def test_prepared_next_step_state_is_what_k_prep_writes(L, ctx):
     assert m.ctx.prepared_steps() == 1
 
 
-@pytest.mark.parametrize('D', [64, 24])
+@pytest.mark.parametrize('D', [64, 24, 7])
 def test_mf_row_aware_optimizer_equals_dense(L, D):
-    """BiasedMF training steps: the row-aware dense optimizer (touched bytes set by k_mf_train; D = 24 has no row path
-    and must fall back to the dense one) against the plain dense step."""
+    """BiasedMF training steps: the dense optimizer called on the row segments (touched bytes set by k_mf_train; D = 64 takes the
+    row-aware streaming pass, D = 24 — rows of whole float4 slots, but not a power of two — the plain dense pass that clears the
+    bytes wholesale, D = 7 has no row segments at all) against the plain dense step without segments."""
     from dccf_amd.models import BiasedMF, FusedOptimizer
     U, I, B = 1203, 877, 96
     runs = []
@@ -1128,7 +1129,7 @@ def test_mf_row_aware_optimizer_equals_dense(L, D):
                      random_seed=4, model_path='/tmp/mf.pt')
         torch.manual_seed(1)
         m.apply(m.init_paras)
-        assert (getattr(m, 'row_segments', None) is not None) == (D == 64)
+        assert (getattr(m, 'row_segments', None) is not None) == (D % 4 == 0)
         if not rows:
             m.row_segments, m.touchedP, m.touchedQ = None, None, None
         m.optimizer = FusedOptimizer(m, 'adam', 0.01, 1e-4)
@@ -1349,15 +1350,17 @@ def test_init_paras_distribution(L):
         assert float(x.std()) == pytest.approx(0.01, rel=0.25) and abs(float(x.mean())) < 0.003, k
 
 
-@pytest.mark.parametrize('kind,opt_name,rank', [('BiasedMF', 'adam', 1), ('RecModel', 'adagrad', 1), ('IPSBiasedMF', 'gd', 0),
-                                                ('IPSBiasedMF', 'adam', 1)])
-def test_mf_lazy_train_step_equals_dense_step(L, kind, opt_name, rank):
+@pytest.mark.parametrize('kind,opt_name,rank,D', [('BiasedMF', 'adam', 1, 64), ('RecModel', 'adagrad', 1, 64), ('IPSBiasedMF', 'gd', 0, 64),
+                                                  ('IPSBiasedMF', 'adam', 1, 64),
+                                                  # round 3: embedding sizes that are not a kernel tile take the lazy path too
+                                                  ('IPSBiasedMF', 'adam', 1, 24), ('BiasedMF', 'adagrad', 1, 100), ('RecModel', 'gd', 1, 160)])
+def test_mf_lazy_train_step_equals_dense_step(L, kind, opt_name, rank, D):
     """MF family: train_step (mf_train_step: catch-up of the batch's rows, forward + backward, one lazy optimizer launch; window
     K = 4 so that it cycles several times) against forward + the dense optimizer step (src/runners/BaseRunner.py:172-188), a
     mid-run evaluation (flush) included: rows no batch touched are bit-identical, the others agree to the float-atomic tolerance,
     predictions of the steps agree, nothing is left in the gradient buffer."""
     from dccf_amd import models
-    U, I, D, B, steps = 2203, 1877, 64, 48, 23
+    U, I, B, steps = 2203, 1877, 48, 23
     runs, preds, seen_u = [], [], []
     for lazy in (True, False):
         cls = models.BiasedMF if kind != 'RecModel' else models.RecModel
