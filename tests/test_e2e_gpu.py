@@ -24,10 +24,12 @@ def run_cli(tmp, argv):
         os.chdir(cwd)
 
 
-def _cli_vs_reference(tmp, g, check_artefacts):
-    """Runs the CLI mirror once per reference seed on the golden's dataset; asserts the seed-averaged validation NDCG@5 of every
-    epoch within 3 standard errors (of the difference of the two seed means, sample variances, no floor) + 1e-3 of the
-    reference's own runs.  What moves the mean and what does not was measured arm by arm: profiles/r02_e2e_ab.md."""
+def _cli_vs_reference(tmp, g, check_artefacts, extra_seeds=0):
+    """Runs the CLI mirror once per reference seed (+ `extra_seeds` more of its own: a run costs about a second here, the
+    reference's costs half an hour) on the golden's dataset; asserts the seed-averaged validation NDCG@5 of every epoch and of the
+    untrained model within 2 standard errors (of the difference of the two seed means, sample variances, no floor) + 1e-3 — the
+    north_star's tolerance — of the reference's own runs.  What moves the mean and what does not was measured arm by arm:
+    profiles/r02_e2e_ab.md, profiles/r03_e2e_ab.md."""
     from dccf_amd import synth
     synth.write_dataset(os.path.join(tmp, 'dataset'), 'toy', int(g['user_num']), int(g['item_num']), int(g['n_draws']),
                         feat_dim=int(g['feat_dim']), seed=int(g['data_seed']))
@@ -35,7 +37,7 @@ def _cli_vs_reference(tmp, g, check_artefacts):
     ref_valid = np.stack([g['seed%d/valid' % s][:, 0] for s in seeds])         # [seeds, epochs] ndcg@5
     ref_init = np.array([g['seed%d/init_valid' % s][0] for s in seeds])
     mine, mine_init = [], []
-    for seed in seeds:
+    for seed in seeds + [max(seeds) + 1 + k for k in range(extra_seeds)]:
         runner = run_cli(tmp, ['--rank', '1', '--model_name', 'DCCF', '--optimizer', 'Adam', '--lr', str(float(g['lr'])),
                                '--dataset', 'toy', '--path', '../dataset/', '--metric', 'ndcg@5,recall@5,precision@5',
                                '--epoch', str(int(g['epochs'])), '--test_neg_n', str(int(g['test_neg_n'])),
@@ -45,17 +47,17 @@ def _cli_vs_reference(tmp, g, check_artefacts):
         mine.append([v[0] for v in runner.valid_results])
         mine_init.append(runner.init_results[1][0])
     mine, mine_init = np.array(mine), np.array(mine_init)
-    assert mine.shape == ref_valid.shape
-    n = len(seeds)
+    assert mine.shape[1] == ref_valid.shape[1]
+    n, nm = len(seeds), len(mine)
     # the untrained model: evaluation alone (negatives, candidates, noise, metric code) against the reference's
-    se0 = np.sqrt(ref_init.var(ddof=1) / n + mine_init.var(ddof=1) / n)
-    assert abs(mine_init.mean() - ref_init.mean()) <= 3 * se0 + 1e-3, (mine_init.mean(), ref_init.mean(), se0)
+    se0 = np.sqrt(ref_init.var(ddof=1) / n + mine_init.var(ddof=1) / nm)
+    assert abs(mine_init.mean() - ref_init.mean()) <= 2 * se0 + 1e-3, (mine_init.mean(), ref_init.mean(), se0)
     # training must move NDCG well above the untrained level, as it does in the reference
     assert mine[:, -1].mean() > ref_init.mean() + 0.5 * (ref_valid[:, -1].mean() - ref_init.mean())
     for e in range(mine.shape[1]):
-        se = np.sqrt(ref_valid[:, e].var(ddof=1) / n + mine[:, e].var(ddof=1) / n)
-        assert abs(mine[:, e].mean() - ref_valid[:, e].mean()) <= 3 * se + 1e-3, \
-            'epoch %d: mine %.4f vs reference %.4f (se %.4f, %d seeds)' % (e + 1, mine[:, e].mean(), ref_valid[:, e].mean(), se, n)
+        se = np.sqrt(ref_valid[:, e].var(ddof=1) / n + mine[:, e].var(ddof=1) / nm)
+        assert abs(mine[:, e].mean() - ref_valid[:, e].mean()) <= 2 * se + 1e-3, \
+            'epoch %d: mine %.4f vs reference %.4f (se %.4f, %d / %d seeds)' % (e + 1, mine[:, e].mean(), ref_valid[:, e].mean(), se, nm, n)
     if not check_artefacts:
         return
     # artefacts with the reference's names and formats
@@ -81,7 +83,8 @@ def test_cli_training_matches_reference_statistically(tmp_path):
 def test_cli_training_matches_reference_on_config1_shape(tmp_path):
     """BASELINE.json configs[0] / SURVEY.md section 8d C1: 5,000 users x 5,000 items, D = 16, F = 768 (the k_noise_fwd<16, ., 6> /
     k_bwd<16, .> instances), 3 epochs, --test_neg_n 100: the reference's own main.py runs of tests/golden/e2e_c1.npz."""
-    _cli_vs_reference(str(tmp_path), load_golden('e2e_c1'), check_artefacts=False)
+    g = load_golden('e2e_c1')
+    _cli_vs_reference(str(tmp_path), g, check_artefacts=False, extra_seeds=len(g['seeds']))
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(GOLDEN, 'e2e_c1_init.npz')), reason='config-1 untrained-model golden not generated')
