@@ -673,6 +673,216 @@ __global__ __launch_bounds__(64 * NW) void k_mf_full_rows(mf_model_t M, float* _
   }
 }
 
+// ---- line form (round 3): B through LDS by DMA, line-aligned stores --------------------------------------------------------------
+// Q [I][D], bi, prop -> the operand stream of k_mf_full_lines: per tile of 32 items a [D / 8][2][32][4] image — the 16 bytes lane
+// (c, h) feeds to four consecutive k-steps of v_mfma_f32_32x32x2_f32 (k = 2 (4 q + j) + h, j < 4) are one ds_read_b128 — and per tile
+// 64 floats of epilogue operands: bi[i] (kind >= 1) and max(prop[i], M) (kind 2).  Padded with zero tiles to Tpad.
+__global__ __launch_bounds__(256) void k_full_lines_prep(mf_model_t M, int D, int64_t Tpad, float* __restrict__ QT4, float* __restrict__ AUX) {
+  const int64_t n = Tpad * D * 32;
+  for (int64_t x = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; x < n; x += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t T = x / (D * 32);
+    const int rem = (int)(x % (D * 32));
+    const int j = rem & 3, col = (rem >> 2) & 31, qh = rem >> 7;
+    const int k = 2 * (4 * (qh >> 1) + j) + (qh & 1);
+    const int64_t it = T * 32 + col;
+    QT4[x] = it < M.item_num ? M.Q[it * D + k] : 0.f;
+    if (rem < 64) {
+      const int64_t i2 = T * 32 + (rem & 31);
+      float v = rem < 32 ? 0.f : 1.f;
+      if (i2 < M.item_num) {
+        if (rem < 32 && M.kind >= 1) v = M.bi[i2];
+        if (rem >= 32 && M.kind == 2) v = fmaxf(M.prop[i2], M.M);
+      }
+      AUX[T * 64 + rem] = v;
+    }
+  }
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Line form, D in {16, 32, 64, 128}.  A workgroup is 4 waves = 4 bands of 32 users (A operand register-resident) that multiply the SAME
+// tiles of 32 items: the tiles arrive 16 KB at a time (128 / D of them) by LDS-DMA (global_load_lds_dwordx4: no registers, no address
+// arithmetic per k-step, 4 wave-instructions per wave and 16 KB instead of D / 2 dword loads per wave and TILE), two buffers, one barrier
+// per 16 KB; the L2 -> CU traffic of Q^T is a quarter of k_mf_full_rows's, where every wave fetched its own operand.  blockIdx & 7
+// (the XCD) picks the item range.
+// The stores are LINE-ALIGNED.  item_num is odd as a rule, so a row of `out` starts anywhere in a 128-byte line and a tile's 128-byte
+// row piece straddles two lines; written that way the matrix leaves at 3.5 TB/s, as whole lines at 5.7 (scripts/store_shapes.hip,
+// profiles/r03_store_shapes.txt).  Every wave keeps 64 floats per row in LDS in MEMORY-LINE coordinates: the 32 new values of row u go to
+// positions (d_u + j) mod 64, d_u = (address of out[u][0] / 4) mod 32 being the row's phase — that completes one of the two lines, which
+// leaves as dwordx4 stores (8 rows x 128 B per instruction), while the other line keeps the row's last d_u values for the next tile.
+// Only the first line of a workgroup's item range and the flush after its last tile are masked dword stores.
+template <int D>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_mf_full_lines(mf_model_t M, float* __restrict__ out,
+                                                                                                     const float* __restrict__ QT4,
+                                                                                                     const float* __restrict__ AUX, int splits) {
+  constexpr int S = 128 / D, TILE = D * 32, CHUNK = S * TILE, NQ = D / 8, CW = 64;           // CHUNK = 4096 floats = 16 KB
+  static_assert(S * D == 128 && CHUNK == 4096, "D must be 16, 32, 64 or 128");
+  extern __shared__ __attribute__((aligned(128))) float sm[];   // [2][CHUNK] operand | [2][S][64] epilogue operands | [4][32][CW] windows
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane >> 5, c31 = lane & 31;
+  float* const Ax = sm + 2 * CHUNK;
+  float* const Cw = sm + 2 * CHUNK + 2 * S * 64 + wave * 32 * CW;
+  const int64_t I = M.item_num, U = M.user_num;
+  const int64_t gt = (I + 31) / 32;
+  const int64_t grp = blockIdx.x / splits, sp = blockIdx.x % splits;
+  const int64_t T0 = gt * sp / splits, T1 = gt * (sp + 1) / splits;
+  if (T0 >= T1) return;                                         // (the whole workgroup: before any barrier)
+  const int64_t u0 = (grp * 4 + wave) * 32;
+  const bool rows_full = u0 + 32 <= U;
+  const int kind = M.kind;
+  const float b0 = kind >= 1 ? M.b0[0] : 0.f;
+  float pa[D / 2];
+  {
+    const float4* prow = reinterpret_cast<const float4*>(M.P + min(u0 + c31, U - 1) * D);
+#pragma unroll
+    for (int j = 0; j < D / 4; ++j) {
+      const float4 v = prow[j];
+      pa[2 * j] = h ? v.y : v.x;
+      pa[2 * j + 1] = h ? v.w : v.z;
+    }
+  }
+  const uint32_t obase = (uint32_t)((uintptr_t)out >> 2);
+  const uint32_t cw_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)Cw;
+  float bu[16];
+  uint32_t wadr[2][16];                                        // LDS byte address of this lane's value of accumulator row r: even / odd tiles
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+    bu[r] = kind >= 1 ? M.bu[min(u0 + row, U - 1)] : 0.f;
+    const uint32_t d = (obase + (uint32_t)(((u0 + row) * I) & 31)) & 31u;
+    wadr[0][r] = cw_lds + (uint32_t)(row * CW + (int)((d + c31) & 63u)) * 4u;
+    wadr[1][r] = cw_lds + (uint32_t)(row * CW + (int)((d + c31 + 32u) & 63u)) * 4u;
+  }
+  uint32_t dr[4];                                               // phases of the rows this lane stores: row 8 i + (lane >> 3), piece lane & 7
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dr[i] = (obase + (uint32_t)(((u0 + 8 * i + (lane >> 3)) * I) & 31)) & 31u;
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)sm);
+  // (inline asm, not __builtin_amdgcn_global_load_lds: hipcc drains a builtin DMA with vmcnt(0) before the next ds_read of the array)
+  auto dma = [&](int64_t Tc, int buf) {
+    const float4* src = reinterpret_cast<const float4*>(QT4) + Tc * (int64_t)(TILE / 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int pc = j * 4 + wave;                              // 16 pieces of 1 KB: wave-uniform
+      const uint32_t ldsb = lds0 + (uint32_t)(buf * CHUNK + pc * 256) * 4u;
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src + pc * 64 + lane), "s"(ldsb) : "memory", "m0");
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+      if ((s & 3) == wave) {                                    // the tile's 64 epilogue operands: one 256-byte DMA
+        const uint32_t ldsb = lds0 + (uint32_t)(2 * CHUNK + (buf * S + s) * 64) * 4u;
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(AUX + (Tc + s) * 64 + lane), "s"(ldsb) : "memory", "m0");
+      }
+  };
+  const int64_t colmin = T0 * 32, colmax = min(T1 * 32, I);
+  // the line at window floats [lineoff, lineoff + 32) holds columns [cT - d_u, cT - d_u + 32) of row u
+  auto emit = [&](int lineoff, int64_t cT, bool masked) {
+    f32x4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f32x4*>(Cw + (8 * i + (lane >> 3)) * CW + lineoff + 4 * (lane & 7));
+    if (!masked) {
+      const float* base = out + u0 * I + cT;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float* p = base + ((int64_t)(8 * i + (lane >> 3)) * I - (int64_t)dr[i] + 4 * (lane & 7));
+        asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v[i]) : "memory");
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t row = u0 + 8 * i + (lane >> 3), col0 = cT - (int64_t)dr[i] + 4 * (lane & 7);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (row < U && col0 + e >= colmin && col0 + e < colmax) out[row * I + col0 + e] = v[i][e];
+      }
+    }
+  };
+  dma(T0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (T0 + S < T1) dma(T0 + S, 1);
+  // one chunk: S tiles out of operand buffer bpar; wp0 = window line of its first tile
+  auto chunk = [&](int64_t Tc, const int bpar, const int wp0) {
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const int64_t T = Tc + s;
+      if (s == 0 || T < T1) {
+        const int wp = (wp0 + s) & 1;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float4* bq = reinterpret_cast<const float4*>(sm + bpar * CHUNK + s * TILE) + h * 32 + c31;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const float4 b = bq[q * 64];
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[4 * q], b.x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[4 * q + 1], b.y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[4 * q + 2], b.z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[4 * q + 3], b.w, acc, 0, 0, 0);
+        }
+        const float bic = Ax[(bpar * S + s) * 64 + c31] + b0, prc = Ax[(bpar * S + s) * 64 + 32 + c31];
+        if (s == S - 1 || T + 1 >= T1) {
+          // the chunk's operand is consumed: when every wave is here its buffer is free for the chunk after the next, and the next
+          // chunk (in flight since the previous barrier) has landed.  The stores this wait also covers were issued a tile ago.
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          if (Tc + 2 * S < T1) dma(Tc + 2 * S, bpar);
+        }
+        if (kind == 2) {
+          // v / prc with one divisor per column: r = 1 / prc once, q = v r, one residual step q + (v - q prc) r (= the correctly rounded
+          // quotient's own correction step): 3 packed instructions per 2 values on the pipe the fp32 MFMA shares with the vector ALU
+          const float rinv = 1.0f / prc;
+          const f32x2 bic2 = {bic, bic}, rinv2 = {rinv, rinv}, nprc2 = {-prc, -prc};
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            f32x2 v = {acc[r], acc[r + 1]};
+            const f32x2 b2 = {bu[r], bu[r + 1]};
+            v = v + b2 + bic2;
+            const f32x2 q = v * rinv2;
+            v = __builtin_elementwise_fma(__builtin_elementwise_fma(q, nprc2, v), rinv2, q);
+            acc[r] = v[0];
+            acc[r + 1] = v[1];
+          }
+        } else if (kind == 1) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = acc[r] + bu[r] + bic;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) *reinterpret_cast<__attribute__((address_space(3))) float*>(wadr[wp][r]) = acc[r];
+        const int64_t cT = T * 32;
+        emit(wp * 32, cT, !(rows_full && T > T0 && cT + 32 <= colmax));
+      }
+    }
+  };
+  int64_t Tc = T0;
+  for (; Tc + S < T1; Tc += 2 * S) {
+    chunk(Tc, 0, 0);
+    chunk(Tc + S, 1, S & 1);
+  }
+  if (Tc < T1) chunk(Tc, 0, 0);
+  emit((int)((T1 - T0) & 1) * 32, T1 * 32, true);              // the rows' leftovers: columns [T1 * 32 - d_u, T1 * 32) below colmax
+}
+
+template <int D>
+static int launch_full_lines(const mf_model_t* M, float* out, hipStream_t st) {
+  constexpr int S = 128 / D;
+  const int64_t groups = (M->user_num + 127) / 128, gt = (M->item_num + 31) / 32;
+  const int splits = 8;                       // = the XCDs: workgroups are dealt round-robin, XCD x only ever reads item range x
+  ARG_CHECK(groups * splits < 2147483647LL, "matrix too large for one launch");
+  ARG_CHECK((uintptr_t)M->P % 16 == 0 && (uintptr_t)out % 4 == 0, "P must be 16-byte aligned, out 4-byte aligned");
+  const int64_t Tpad = gt + 2 * S;            // a chunk's DMA reads whole chunks
+  float* QT4 = nullptr;
+  HIP_TRY(hipMallocAsync((void**)&QT4, (size_t)Tpad * (D * 32 + 64) * sizeof(float), st));
+  float* AUX = QT4 + Tpad * D * 32;
+  hipLaunchKernelGGL(k_full_lines_prep, dim3((unsigned)min((int64_t)4096, (Tpad * D * 32 + 255) / 256)), dim3(256), 0, st, *M, D, Tpad, QT4, AUX);
+  const size_t smem = (size_t)(2 * 4096 + 2 * S * 64 + 4 * 32 * 64) * sizeof(float);
+  HIP_TRY(hipFuncSetAttribute((const void*)k_mf_full_lines<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL((k_mf_full_lines<D>), dim3((unsigned)(groups * splits)), dim3(256), smem, st, *M, out, QT4, AUX, splits);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipFreeAsync(QT4, st));
+  return 0;
+}
+
 template <int D, int RB, int NW = 8>
 static int launch_full_rows(const mf_model_t* M, float* out, hipStream_t st) {
   const int64_t bands = (M->user_num + 32 * RB - 1) / (32 * RB), gt = (M->item_num + NW * 32 - 1) / (NW * 32);
@@ -703,6 +913,15 @@ extern "C" int mf_predict_full(const mf_model_t* M, float* out, void* stream) {
   ARG_CHECK(M->kind == 0 || (M->bu && M->bi && M->b0), "bias pointers missing");
   ARG_CHECK(M->kind != 2 || M->prop, "propensity missing");
   ARG_CHECK(M->user_num > 0 && M->item_num > 0, "empty matrix");
+  const char* form = getenv("DCCF_FULL_FORM");
+  if (!(form && (!strcmp(form, "rows") || !strcmp(form, "band"))))
+    switch (M->D) {                            // the line form (round 3): profiles/r03_full_matrix_bench.json
+      case 16: return launch_full_lines<16>(M, out, (hipStream_t)stream);
+      case 32: return launch_full_lines<32>(M, out, (hipStream_t)stream);
+      case 64: return launch_full_lines<64>(M, out, (hipStream_t)stream);
+      case 128: return launch_full_lines<128>(M, out, (hipStream_t)stream);
+      default: break;
+    }
   switch (M->D) {
     // forms per D as measured (CDs-shaped 75k x 64k, profiles/r02_full_matrix_bench.json): the row-band form (32 or 64 users
     // per workgroup, A operand in registers, tile-major Q^T, 1-KB row segments) for D <= 64: 5.1 / 6.0 / 9.1 ms at D = 16 /

@@ -395,6 +395,653 @@ static int run2(Args a, const char* name) {
   return 0;
 }
 
+// k_full3: the B operand through LDS, shared by the workgroup.  A workgroup is NW waves = NW bands of 32 users (A register-resident,
+// 64 VGPRs) that all multiply the SAME tile of TW = 64 items; the tile (32 KB of the [T][q][h][64][4] image, contiguous in HBM) comes
+// in by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, 32 wave-instructions per tile instead of 64 dword loads per WAVE per 32
+// items), two LDS buffers: tile T + 1 is in flight while tile T is multiplied.  Per tile: DMA(T + 1) -> 128 MFMAs (B fragments by
+// ds_read_b128) -> vmcnt(0) + barrier -> epilogue + stores of T straight from the accumulators (not waited for until a tile later).
+// L2 -> CU traffic of the B operand drops NW-fold; blockIdx % 8 (the XCD) picks the item split, so an XCD's L2 sees one eighth of Q^T.
+__device__ __forceinline__ float dppx1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false)); }
+__device__ __forceinline__ float dppx2(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false)); }
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+
+// ST 1: the tile leaves as dwordx4 stores of 4 rows x 256 B: a 4 x 4 transpose inside each quad of lanes (two DPP rounds) turns a lane's
+// 4 rows x 1 column into 1 row x 4 columns, and v_permlane32_swap puts the two 32-column halves of a row into the two halves of the wave
+template <int NW, int WPE, int DBG, int ST>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_full3(Args a) {
+  constexpr int D = 128, TW = 64, TILE = D * TW;                 // floats per tile
+  __shared__ __attribute__((aligned(16))) float Bs[2 * TILE];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane >> 5, c31 = lane & 31;
+  const int64_t gt = (a.I + TW - 1) / TW;
+  const int64_t grp = blockIdx.x / a.splits, sp = blockIdx.x % a.splits;
+  const int64_t T0 = gt * sp / a.splits, T1 = gt * (sp + 1) / a.splits;
+  const int64_t u0 = (grp * NW + wave) * 32;
+  float pa[64];
+  {
+    const float4* prow = reinterpret_cast<const float4*>(a.P + min(u0 + c31, a.U - 1) * D);
+#pragma unroll
+    for (int j = 0; j < D / 4; ++j) {
+      const float4 v = prow[j];
+      pa[2 * j] = h ? v.y : v.x;
+      pa[2 * j + 1] = h ? v.w : v.z;
+    }
+  }
+  float bu[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bu[r] = a.bu[min(u0 + (r & 3) + 8 * (r >> 2) + 4 * h, a.U - 1)] + a.b0;
+  constexpr int PER = TILE / 4 / (64 * NW);                     // 16-byte pieces per lane and tile
+  auto dma = [&](int64_t T, int buf) {
+    const float4* src = reinterpret_cast<const float4*>(a.QT4) + T * (int64_t)(TILE / 4);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int piece = (j * NW + wave) * 64;                   // wave-uniform
+      // inline asm, not __builtin_amdgcn_global_load_lds: hipcc drains a builtin DMA (vmcnt(0)) before the next ds_read of the array
+      const uint32_t ldsb = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)Bs) +
+                            (uint32_t)(buf * TILE + piece * 4) * 4u;
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src + piece + lane), "s"(ldsb) : "memory", "m0");
+    }
+  };
+  float bin[2] = {0.f, 0.f}, prn[2] = {1.f, 1.f};
+  auto aux = [&](int64_t T) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int64_t i = min(T * TW + nt * 32 + c31, a.I - 1);
+      bin[nt] = a.bi[i];
+      prn[nt] = a.prop[i];                                     // (raw: any use here would wait for the DMAs issued before it)
+    }
+  };
+  if (T0 < T1) {
+    dma(T0, 0);
+    aux(T0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int buf = 0;
+  for (int64_t T = T0; T < T1; ++T) {
+    const float bic[2] = {bin[0], bin[1]}, prc[2] = {fmaxf(prn[0], a.Mclip), fmaxf(prn[1], a.Mclip)};
+    if (!(DBG & 4) && T + 1 < T1) {
+      dma(T + 1, buf ^ 1);
+      aux(T + 1);
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    const float4* bq = reinterpret_cast<const float4*>(Bs + buf * TILE) + h * TW + c31;
+    if (!(DBG & 2)) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float4 b0 = bq[q * 2 * TW], b1 = bq[q * 2 * TW + 32];
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[4 * q], b0.x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[4 * q], b1.x, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[4 * q + 1], b0.y, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[4 * q + 1], b1.y, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[4 * q + 2], b0.z, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[4 * q + 2], b1.z, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[4 * q + 3], b0.w, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[4 * q + 3], b1.w, acc[1], 0, 0, 0);
+      }
+    } else {
+      acc[0][0] = bq[0].x;
+      acc[1][0] = bq[32].x;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // tile T + 1 has landed (and the stores of tile T - 1 have left)
+    __builtin_amdgcn_s_barrier();                               // ... for every wave; buffer `buf` is free for tile T + 2
+    buf ^= 1;
+    if (DBG & 1) {
+      if (acc[0][0] == 12345.678f) a.out[0] = acc[1][3];
+      continue;
+    }
+    const int64_t c0 = T * TW;
+    const bool full = c0 + TW <= a.I && u0 + 32 <= a.U;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const float rinv = 1.0f / prc[nt];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[nt][r] + (bu[r] - a.b0) + (bic[nt] + a.b0);
+        const float q = v * rinv;
+        v = fmaf(fmaf(-q, prc[nt], v), rinv, q);
+        acc[nt][r] = v;
+      }
+    }
+    if (full && ST) {
+      const bool odd = lane & 1, up = lane & 2;
+      float* o = a.out + (u0 + (c31 & 3)) * a.I + c0 + h * 32 + 4 * (c31 >> 2);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float y[2][4];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          float x0 = acc[nt][4 * g], x1 = acc[nt][4 * g + 1], x2 = acc[nt][4 * g + 2], x3 = acc[nt][4 * g + 3];
+          const float a0 = odd ? dppx1(x1) : x0, a1 = odd ? x1 : dppx1(x0), a2 = odd ? dppx1(x3) : x2, a3 = odd ? x3 : dppx1(x2);
+          y[nt][0] = up ? dppx2(a2) : a0;
+          y[nt][2] = up ? a2 : dppx2(a0);
+          y[nt][1] = up ? dppx2(a3) : a1;
+          y[nt][3] = up ? a3 : dppx2(a1);
+        }
+        float4 X, Y;
+        float* xs = &X.x;
+        float* ys = &Y.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const u32x2v sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(y[0][j]), __float_as_uint(y[1][j]), false, false);
+          xs[j] = __uint_as_float(sw[0]);
+          ys[j] = __uint_as_float(sw[1]);
+        }
+        float* orow = o + (int64_t)(8 * g) * a.I;
+        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+        *reinterpret_cast<f4u*>(orow) = f4u{X.x, X.y, X.z, X.w};
+        *reinterpret_cast<f4u*>(orow + 4 * a.I) = f4u{Y.x, Y.y, Y.z, Y.w};
+      }
+    } else if (full) {
+      float* o = a.out + (u0 + 4 * h) * a.I + c0 + c31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float* orow = o + (int64_t)((r & 3) + 8 * (r >> 2)) * a.I;
+        orow[0] = acc[0][r];
+        orow[32] = acc[1][r];
+      }
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = u0 + (r & 3) + 8 * (r >> 2) + 4 * h, col = c0 + nt * 32 + c31;
+          if (row < a.U && col < a.I) a.out[row * a.I + col] = acc[nt][r];
+        }
+    }
+  }
+}
+
+template <int NW, int WPE, int DBG, int ST>
+static int run3(Args a, const char* name) {
+  constexpr int TW = 64;
+  const int64_t groups = (a.U + 32 * NW - 1) / (32 * NW), gt = (a.I + TW - 1) / TW;
+  a.splits = 8;
+  a.Ipad = gt * TW;
+  float* QT4 = nullptr;
+  CHECK(hipMalloc((void**)&QT4, (size_t)a.Ipad * 128 * 4));
+  hipLaunchKernelGGL(k_qt4, dim3(4096), dim3(256), 0, 0, a.Q, a.I, a.Ipad, TW, QT4);
+  a.QT4 = QT4;
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  float best = 1e9f;
+  for (int it = 0; it < 6; ++it) {
+    CHECK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL((k_full3<NW, WPE, DBG, ST>), dim3((unsigned)(groups * a.splits)), dim3(64 * NW), 0, 0, a);
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (it >= 1 && ms < best) best = ms;
+  }
+  CHECK(hipGetLastError());
+  double maxerr = -1.0;
+  if (DBG == 0) {
+    maxerr = 0.0;
+    uint64_t st = 12345;
+    for (int t = 0; t < 300; ++t) {
+      st = st * 6364136223846793005ULL + 1442695040888963407ULL;
+      int64_t u = (int64_t)((st >> 33) % (uint64_t)a.U), i = (int64_t)((st >> 13) % (uint64_t)a.I);
+      if (t == 0) { u = 0; i = 0; }
+      if (t == 1) { u = a.U - 1; i = a.I - 1; }
+      if (t == 2) { u = 1; i = a.I - 1; }
+      if (t == 3) { u = a.U - 1; i = 0; }
+      if (t >= 4 && t < 36) { u = 33 + (t & 3); i = (t - 4) * 131 + (t & 7); }
+      if (t >= 36 && t < 68) { u = a.U - 1 - (t & 31); i = a.I - 1 - (t - 36) * 3; }
+      float got = 0.f;
+      CHECK(hipMemcpy(&got, a.out + u * a.I + i, 4, hipMemcpyDeviceToHost));
+      double ref = 0.0;
+      for (int k = 0; k < 128; ++k) ref += (double)hP[u * 128 + k] * (double)hQ[i * 128 + k];
+      ref = (ref + hbu[u] + hbi[i] + a.b0) / fmax((double)hprop[i], (double)a.Mclip);
+      maxerr = fmax(maxerr, fabs(ref - (double)got));
+    }
+  }
+  printf("%-44s NW %d B through LDS (DMA), WPE %d DBG %d ST %d : %7.3f ms  %6.1f TFLOP/s  max|err| %.2e\n", name, NW, WPE, DBG, ST, best,
+         2.0 * (double)a.U * (double)a.I * 128.0 / best / 1e9, maxerr);
+  fflush(stdout);
+  CHECK(hipFree(QT4));
+  return 0;
+}
+
+// k_full4: k_full3 with the epilogue once per PAIR tiles: a wave then writes PAIR x 256 B of every row back to back (the misaligned
+// 128-byte pieces of k_full3's rows meet their neighbours in L2 one tile time later, after ~2 MB of other rows went through that L2)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int NW, int WPE, int DBG, int PAIR, int EP>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_full4(Args a) {
+  constexpr int D = 128, TW = 64, TILE = D * TW;
+  __shared__ __attribute__((aligned(16))) float Bs[2 * TILE];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane >> 5, c31 = lane & 31;
+  const int64_t gt = (a.I + TW - 1) / TW;
+  const int64_t grp = blockIdx.x / a.splits, sp = blockIdx.x % a.splits;
+  const int64_t T0 = gt * sp / a.splits, T1 = gt * (sp + 1) / a.splits;
+  const int64_t u0 = (grp * NW + wave) * 32;
+  float pa[64];
+  {
+    const float4* prow = reinterpret_cast<const float4*>(a.P + min(u0 + c31, a.U - 1) * D);
+#pragma unroll
+    for (int j = 0; j < D / 4; ++j) {
+      const float4 v = prow[j];
+      pa[2 * j] = h ? v.y : v.x;
+      pa[2 * j + 1] = h ? v.w : v.z;
+    }
+  }
+  float bu[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bu[r] = a.bu[min(u0 + (r & 3) + 8 * (r >> 2) + 4 * h, a.U - 1)];
+  constexpr int PER = TILE / 4 / (64 * NW);
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)Bs);
+  auto dma = [&](int64_t T, int buf) {
+    const float4* src = reinterpret_cast<const float4*>(a.QT4) + T * (int64_t)(TILE / 4);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int piece = (j * NW + wave) * 64;
+      const uint32_t ldsb = lds0 + (uint32_t)(buf * TILE + piece * 4) * 4u;
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src + piece + lane), "s"(ldsb) : "memory", "m0");
+    }
+  };
+  float bin[PAIR][2], prn[PAIR][2], binx[2] = {0.f, 0.f}, prnx[2] = {1.f, 1.f};
+  if (T0 < T1) {
+    dma(T0, 0);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int64_t i = min(T0 * TW + nt * 32 + c31, a.I - 1);
+      bin[0][nt] = a.bi[i];
+      prn[0][nt] = a.prop[i];
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int buf = 0;
+  for (int64_t Ts = T0; Ts < T1; Ts += PAIR) {
+    const int np = (int)min((int64_t)PAIR, T1 - Ts);
+    f32x16 acc[2 * PAIR];
+#pragma unroll
+    for (int p = 0; p < PAIR; ++p) {
+      if (p < np) {
+        const int64_t T = Ts + p;
+        if (!(DBG & 4) && T + 1 < T1) {
+          dma(T + 1, buf ^ 1);
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            const int64_t i = min((T + 1) * TW + nt * 32 + c31, a.I - 1);
+            const float b = a.bi[i], pr = a.prop[i];            // raw: a use here would wait for the DMAs issued before it
+            if (p + 1 < PAIR) {
+              bin[p + 1 < PAIR ? p + 1 : 0][nt] = b;
+              prn[p + 1 < PAIR ? p + 1 : 0][nt] = pr;
+            } else {
+              binx[nt] = b;
+              prnx[nt] = pr;
+            }
+          }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[2 * p + nt][r] = 0.f;
+        const float4* bq = reinterpret_cast<const float4*>(Bs + buf * TILE) + h * TW + c31;
+        if (!(DBG & 2)) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const float4 b0 = bq[q * 2 * TW], b1 = bq[q * 2 * TW + 32];
+            acc[2 * p] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[4 * q], b0.x, acc[2 * p], 0, 0, 0);
+            acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[4 * q], b1.x, acc[2 * p + 1], 0, 0, 0);
+            acc[2 * p] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[4 * q + 1], b0.y, acc[2 * p], 0, 0, 0);
+            acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[4 * q + 1], b1.y, acc[2 * p + 1], 0, 0, 0);
+            acc[2 * p] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[4 * q + 2], b0.z, acc[2 * p], 0, 0, 0);
+            acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[4 * q + 2], b1.z, acc[2 * p + 1], 0, 0, 0);
+            acc[2 * p] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[4 * q + 3], b0.w, acc[2 * p], 0, 0, 0);
+            acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[4 * q + 3], b1.w, acc[2 * p + 1], 0, 0, 0);
+          }
+        } else {
+          acc[2 * p][0] = bq[0].x;
+          acc[2 * p + 1][0] = bq[32].x;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        buf ^= 1;
+      }
+    }
+    if (DBG & 1) {
+      if (acc[0][0] == 12345.678f) a.out[0] = acc[1][3];
+    } else {
+      const int64_t c0 = Ts * TW;
+      const bool full = np == PAIR && c0 + PAIR * TW <= a.I && u0 + 32 <= a.U;
+#pragma unroll
+      for (int x = 0; x < 2 * PAIR; ++x) {
+        const float prc = fmaxf(prn[x >> 1][x & 1], a.Mclip), bic = bin[x >> 1][x & 1] + a.b0;
+        const float rinv = 1.0f / prc;
+        if (EP) {                                                // two elements per lane and instruction (v_pk_*_f32)
+          const f32x2 bic2 = {bic, bic}, rinv2 = {rinv, rinv}, nprc2 = {-prc, -prc};
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            f32x2 v = {acc[x][r], acc[x][r + 1]};
+            const f32x2 b2 = {bu[r], bu[r + 1]};
+            v = v + b2 + bic2;
+            const f32x2 q = v * rinv2;
+            v = __builtin_elementwise_fma(__builtin_elementwise_fma(q, nprc2, v), rinv2, q);
+            acc[x][r] = v[0];
+            acc[x][r + 1] = v[1];
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[x][r] + bu[r] + bic;
+            const float q = v * rinv;
+            acc[x][r] = fmaf(fmaf(-q, prc, v), rinv, q);
+          }
+        }
+      }
+      if (full && EP) {
+        // a wave-uniform row base (scalar registers) + one 32-bit lane offset: no vector address arithmetic per store
+        // (inline asm: hipcc turns the same thing written in C++ into 32 per-lane 64-bit pointers advanced with vector adds every tile)
+        const uint32_t loffb = ((uint32_t)(4 * h) * (uint32_t)a.I + (uint32_t)c31) * 4u;
+        const float* o = a.out + u0 * a.I + c0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float* orow = o + (int64_t)((r & 3) + 8 * (r >> 2)) * a.I;
+#pragma unroll
+          for (int x = 0; x < 2 * PAIR; ++x)
+            asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(loffb), "v"(acc[x][r]), "s"(orow), "n"(128 * x) : "memory");
+        }
+      } else if (full) {
+        float* o = a.out + (u0 + 4 * h) * a.I + c0 + c31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float* orow = o + (int64_t)((r & 3) + 8 * (r >> 2)) * a.I;
+#pragma unroll
+          for (int x = 0; x < 2 * PAIR; ++x) orow[32 * x] = acc[x][r];
+        }
+      } else {
+#pragma unroll
+        for (int x = 0; x < 2 * PAIR; ++x)
+          if (x < 2 * np)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int64_t row = u0 + (r & 3) + 8 * (r >> 2) + 4 * h, col = c0 + x * 32 + c31;
+              if (row < a.U && col < a.I) a.out[row * a.I + col] = acc[x][r];
+            }
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      bin[0][nt] = binx[nt];
+      prn[0][nt] = prnx[nt];
+    }
+  }
+}
+
+template <int NW, int WPE, int DBG, int PAIR, int EP>
+static int run4(Args a, const char* name) {
+  constexpr int TW = 64;
+  const int64_t groups = (a.U + 32 * NW - 1) / (32 * NW), gt = (a.I + TW - 1) / TW;
+  a.splits = 8;
+  a.Ipad = gt * TW;
+  float* QT4 = nullptr;
+  CHECK(hipMalloc((void**)&QT4, (size_t)a.Ipad * 128 * 4));
+  hipLaunchKernelGGL(k_qt4, dim3(4096), dim3(256), 0, 0, a.Q, a.I, a.Ipad, TW, QT4);
+  a.QT4 = QT4;
+  CHECK(hipMemset(a.out, 0xff, (size_t)a.U * a.I * 4));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  float best = 1e9f;
+  for (int it = 0; it < 6; ++it) {
+    CHECK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL((k_full4<NW, WPE, DBG, PAIR, EP>), dim3((unsigned)(groups * a.splits)), dim3(64 * NW), 0, 0, a);
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (it >= 1 && ms < best) best = ms;
+  }
+  CHECK(hipGetLastError());
+  double maxerr = -1.0;
+  if (DBG == 0) {
+    maxerr = 0.0;
+    uint64_t st = 12345;
+    for (int t = 0; t < 400; ++t) {
+      st = st * 6364136223846793005ULL + 1442695040888963407ULL;
+      int64_t u = (int64_t)((st >> 33) % (uint64_t)a.U), i = (int64_t)((st >> 13) % (uint64_t)a.I);
+      if (t == 0) { u = 0; i = 0; }
+      if (t == 1) { u = a.U - 1; i = a.I - 1; }
+      if (t == 2) { u = 1; i = a.I - 1; }
+      if (t == 3) { u = a.U - 1; i = 0; }
+      if (t >= 4 && t < 36) { u = 33 + (t & 3); i = (t - 4) * 131 + (t & 7); }
+      if (t >= 36 && t < 100) { u = a.U - 1 - (t & 31); i = a.I - 1 - (t - 36) * 3; }
+      if (t >= 100 && t < 164) { u = (t * 977) % a.U; i = (gt * ((t & 7) + 1) / 8) * TW - 70 + (t - 100) * 2; if (i >= a.I) i = a.I - 1; }
+      float got = 0.f;
+      CHECK(hipMemcpy(&got, a.out + u * a.I + i, 4, hipMemcpyDeviceToHost));
+      double ref = 0.0;
+      for (int k = 0; k < 128; ++k) ref += (double)hP[u * 128 + k] * (double)hQ[i * 128 + k];
+      ref = (ref + hbu[u] + hbi[i] + a.b0) / fmax((double)hprop[i], (double)a.Mclip);
+      maxerr = fmax(maxerr, fabs(ref - (double)got));
+    }
+  }
+  printf("%-44s NW %d B through LDS (DMA), WPE %d DBG %d PAIR %d EP %d : %7.3f ms  %6.1f TFLOP/s  max|err| %.2e\n", name, NW, WPE, DBG, PAIR, EP, best,
+         2.0 * (double)a.U * (double)a.I * 128.0 / best / 1e9, maxerr);
+  fflush(stdout);
+  CHECK(hipFree(QT4));
+  return 0;
+}
+
+// k_full5: k_full4's operand path (B tiles of 32 items by LDS-DMA, shared by the 4 bands of a workgroup) + LINE-ALIGNED stores.
+// item_num is odd, so a row of `out` starts anywhere in a 128-byte line and a tile's 128-byte row piece straddles two lines: the
+// matrix then leaves at 3.5 TB/s instead of the 5.7 TB/s of whole-line stores (scripts/store_shapes.hip).  Here every wave keeps a
+// window of 64 floats per row in LDS in MEMORY-LINE coordinates: a tile's 32 new values of row u go to positions d_u + j
+// (d_u = (address of out[u][0] / 4) mod 32, the row's phase; positions are taken mod 64, the two lines alternate), which completes one
+// line; the line leaves as dwordx4 stores of 8 rows x 128 B, all line-aligned, the other line holds the row's d_u leftover values
+// for the next tile.  Only the first line of a split's column range and the flush after its last tile use masked dword stores.
+template <int D, int WPE, int DBG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_full5(Args a) {
+  constexpr int NW = 4, TW = 32, TILE = D * TW, NQ = D / 8, CW = 64;
+  __shared__ __attribute__((aligned(128))) float sm[2 * TILE + NW * 32 * CW];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane >> 5, c31 = lane & 31;
+  float* Cw = sm + 2 * TILE + wave * 32 * CW;
+  const int64_t gt = (a.I + TW - 1) / TW;
+  const int64_t grp = blockIdx.x / a.splits, sp = blockIdx.x % a.splits;
+  const int64_t T0 = gt * sp / a.splits, T1 = gt * (sp + 1) / a.splits;
+  if (T0 >= T1) return;
+  const int64_t u0 = (grp * NW + wave) * 32;
+  const bool rows_full = u0 + 32 <= a.U;
+  float pa[D / 2];
+  {
+    const float4* prow = reinterpret_cast<const float4*>(a.P + min(u0 + c31, a.U - 1) * D);
+#pragma unroll
+    for (int j = 0; j < D / 4; ++j) {
+      const float4 v = prow[j];
+      pa[2 * j] = h ? v.y : v.x;
+      pa[2 * j + 1] = h ? v.w : v.z;
+    }
+  }
+  const uint32_t obase = (uint32_t)((uintptr_t)a.out >> 2);
+  float bu[16];
+  uint32_t wadr[2][16];                                        // LDS byte address of this lane's value of row r, even / odd tiles
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+    bu[r] = a.bu[min(u0 + row, a.U - 1)];
+    const uint32_t d = (obase + (uint32_t)(((u0 + row) * a.I) & 31)) & 31u;
+    const uint32_t cw = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)Cw;
+    wadr[0][r] = cw + (uint32_t)(row * CW + (int)((d + c31) & 63u)) * 4u;
+    wadr[1][r] = cw + (uint32_t)(row * CW + (int)((d + c31 + 32u) & 63u)) * 4u;
+  }
+  // the rows this lane reads back and stores: row 8 i + (lane >> 3), 16-byte piece lane & 7 of a line
+  uint32_t dr[4], voff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 8 * i + (lane >> 3);
+    dr[i] = (obase + (uint32_t)(((u0 + row) * a.I) & 31)) & 31u;
+    voff[i] = (uint32_t)(((int64_t)row * a.I - (int64_t)dr[i] + 4 * (lane & 7)) * 4);       // bytes from out + u0 * I + c0 (wraps below 0: 32-bit two's complement is what the 64-bit add needs only if non-negative -> see emit)
+  }
+  constexpr int PIECES = TILE / 4 / 64;                         // 1 KiB wave-instructions per tile
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)sm);
+  auto dma = [&](int64_t T, int buf) {
+    const float4* src = reinterpret_cast<const float4*>(a.QT4) + T * (int64_t)(TILE / 4);
+#pragma unroll
+    for (int j = 0; j < (PIECES + NW - 1) / NW; ++j) {
+      const int pc = j * NW + wave;
+      if (PIECES % NW == 0 || pc < PIECES) {
+        const uint32_t ldsb = lds0 + (uint32_t)(buf * TILE + pc * 256) * 4u;
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src + pc * 64 + lane), "s"(ldsb) : "memory", "m0");
+      }
+    }
+  };
+  const int64_t colmin = T0 * TW, colmax = min(T1 * TW, a.I);
+  // the line at window floats [lineoff, lineoff + 32) holds columns [cT - d_u, cT - d_u + 32) of row u
+  auto emit = [&](int lineoff, int64_t cT, bool masked) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    f4v v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f4v*>(Cw + (8 * i + (lane >> 3)) * CW + lineoff + 4 * (lane & 7));
+    if (!masked) {
+      const float* base = a.out + u0 * a.I + cT;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float* p = base + ((int64_t)(8 * i + (lane >> 3)) * a.I - (int64_t)dr[i] + 4 * (lane & 7));
+        asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v[i]) : "memory");
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t row = u0 + 8 * i + (lane >> 3), col0 = cT - (int64_t)dr[i] + 4 * (lane & 7);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (row < a.U && col0 + e >= colmin && col0 + e < colmax) a.out[row * a.I + col0 + e] = v[i][e];
+      }
+    }
+  };
+  float bin = 0.f, prn = 1.f;
+  dma(T0, 0);
+  {
+    const int64_t i = min(T0 * TW + c31, a.I - 1);
+    bin = a.bi[i];
+    prn = a.prop[i];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  auto tile = [&](int64_t T, const int par) {                   // par = (T - T0) & 1: the LDS buffer AND the window's line
+    const float bic = bin + a.b0, prc = fmaxf(prn, a.Mclip);
+    if (!(DBG & 4) && T + 1 < T1) {
+      dma(T + 1, par ^ 1);
+      const int64_t i = min((T + 1) * TW + c31, a.I - 1);
+      bin = a.bi[i];
+      prn = a.prop[i];
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float4* bq = reinterpret_cast<const float4*>(sm + par * TILE) + h * TW + c31;
+    if (!(DBG & 2)) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const float4 b = bq[q * 2 * TW];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[4 * q], b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[4 * q + 1], b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[4 * q + 2], b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[4 * q + 3], b.w, acc, 0, 0, 0);
+      }
+    } else {
+      acc[0] = bq[0].x;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (DBG & 1) {
+      if (acc[0] == 12345.678f) a.out[0] = acc[3];
+      return;
+    }
+    const float rinv = 1.0f / prc;
+    const f32x2 bic2 = {bic, bic}, rinv2 = {rinv, rinv}, nprc2 = {-prc, -prc};
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      f32x2 v = {acc[r], acc[r + 1]};
+      const f32x2 b2 = {bu[r], bu[r + 1]};
+      v = v + b2 + bic2;
+      const f32x2 q = v * rinv2;
+      v = __builtin_elementwise_fma(__builtin_elementwise_fma(q, nprc2, v), rinv2, q);
+      *reinterpret_cast<__attribute__((address_space(3))) float*>(wadr[par][r]) = v[0];
+      *reinterpret_cast<__attribute__((address_space(3))) float*>(wadr[par][r + 1]) = v[1];
+    }
+    const int64_t cT = T * TW;
+    emit(par * 32, cT, !(rows_full && T > T0 && cT + TW <= colmax));
+  };
+  int64_t T = T0;
+  for (; T + 1 < T1; T += 2) {
+    tile(T, 0);
+    tile(T + 1, 1);
+  }
+  int par = 0;
+  if (T < T1) {
+    tile(T, 0);
+    par = 1;
+  }
+  if (!(DBG & 1)) emit(par * 32, T1 * TW, true);               // the rows' leftovers: columns [T1 * TW - d_u, T1 * TW) (below colmax)
+}
+
+template <int D, int WPE, int DBG>
+static int run5(Args a, const char* name) {
+  constexpr int TW = 32, NW = 4;
+  const int64_t groups = (a.U + 32 * NW - 1) / (32 * NW), gt = (a.I + TW - 1) / TW;
+  a.splits = 8;
+  a.Ipad = gt * TW;
+  float* QT4 = nullptr;
+  CHECK(hipMalloc((void**)&QT4, (size_t)a.Ipad * 128 * 4));
+  hipLaunchKernelGGL(k_qt4, dim3(4096), dim3(256), 0, 0, a.Q, a.I, a.Ipad, TW, QT4);
+  a.QT4 = QT4;
+  CHECK(hipMemset(a.out, 0xff, (size_t)a.U * a.I * 4));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  float best = 1e9f;
+  for (int it = 0; it < 6; ++it) {
+    CHECK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL((k_full5<D, WPE, DBG>), dim3((unsigned)(groups * a.splits)), dim3(64 * NW), 0, 0, a);
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (it >= 1 && ms < best) best = ms;
+  }
+  CHECK(hipGetLastError());
+  double maxerr = -1.0;
+  if (DBG == 0) {
+    maxerr = 0.0;
+    uint64_t st = 12345;
+    for (int t = 0; t < 600; ++t) {
+      st = st * 6364136223846793005ULL + 1442695040888963407ULL;
+      int64_t u = (int64_t)((st >> 33) % (uint64_t)a.U), i = (int64_t)((st >> 13) % (uint64_t)a.I);
+      if (t == 0) { u = 0; i = 0; }
+      if (t == 1) { u = a.U - 1; i = a.I - 1; }
+      if (t == 2) { u = 1; i = a.I - 1; }
+      if (t == 3) { u = a.U - 1; i = 0; }
+      if (t >= 4 && t < 36) { u = 33 + (t & 3); i = (t - 4) * 131 + (t & 7); }
+      if (t >= 36 && t < 100) { u = a.U - 1 - (t & 31); i = a.I - 1 - (t - 36) * 3; }
+      if (t >= 100 && t < 356) { u = (t * 977) % a.U; i = (gt * ((t & 7) + 1) / 8) * TW - 40 + ((t - 100) >> 3) * 2; if (i >= a.I) i = a.I - 1; }
+      if (t >= 356 && t < 420) { u = (t * 131) % a.U; i = t - 356; }
+      float got = 0.f;
+      CHECK(hipMemcpy(&got, a.out + u * a.I + i, 4, hipMemcpyDeviceToHost));
+      double ref = 0.0;
+      for (int k = 0; k < 128; ++k) ref += (double)hP[u * 128 + k] * (double)hQ[i * 128 + k];
+      ref = (ref + hbu[u] + hbi[i] + a.b0) / fmax((double)hprop[i], (double)a.Mclip);
+      const double e = fabs(ref - (double)got);
+      if (!(e < 1e-3) && maxerr < 1e-3) printf("   first mismatch at u %lld i %lld: got %g want %g\n", (long long)u, (long long)i, got, ref);
+      maxerr = fmax(maxerr, e != e ? 1e30 : e);
+    }
+  }
+  printf("%-44s D %d line-aligned stores, WPE %d DBG %d : %7.3f ms  %6.1f TFLOP/s  max|err| %.2e\n", name, D, WPE, DBG, best,
+         2.0 * (double)a.U * (double)a.I * 128.0 / best / 1e9, maxerr);
+  fflush(stdout);
+  CHECK(hipFree(QT4));
+  return 0;
+}
+
 int main() {
   const int64_t U = 75258, I = 64443;
   hP.resize(U * 128); hQ.resize(I * 128); hbu.resize(U); hbi.resize(I); hprop.resize(I);
@@ -415,6 +1062,27 @@ int main() {
   CHECK(hipMemcpy(prop, hprop.data(), I * 4, hipMemcpyHostToDevice));
   a.P = P; a.Q = Q; a.bu = bu; a.bi = bi; a.prop = prop; a.b0 = 0.1f; a.Mclip = 0.1f; a.out = out; a.U = U; a.I = I;
   int rc = 0;
+  CHECK(hipMemset(out, 0xff, (size_t)U * I * 4));
+  rc |= run3<4, 2, 0, 0>(a, "B through LDS, 4 bands per workgroup");
+  rc |= run3<4, 2, 1, 0>(a, "  no stores");
+  rc |= run3<4, 2, 2, 0>(a, "  no MFMA");
+  rc |= run3<4, 2, 4, 0>(a, "  no DMA in the loop");
+  rc |= run3<8, 2, 0, 0>(a, "B through LDS, 8 bands per workgroup");
+  CHECK(hipMemset(out, 0xff, (size_t)U * I * 4));
+  rc |= run3<4, 2, 0, 1>(a, "B through LDS + transposed x4 stores");
+  rc |= run3<4, 2, 2, 1>(a, "  no MFMA");
+  rc |= run3<8, 2, 0, 1>(a, "8 bands + transposed x4 stores");
+  rc |= run4<4, 2, 0, 1, 0>(a, "k_full4, epilogue per tile");
+  rc |= run4<4, 2, 0, 1, 1>(a, "k_full4 + packed epilogue, scalar row bases");
+  rc |= run4<4, 2, 0, 2, 0>(a, "k_full4, epilogue per 2 tiles");
+  rc |= run4<4, 2, 0, 2, 1>(a, "k_full4, per 2 tiles + packed epilogue");
+  rc |= run4<4, 2, 4, 1, 1>(a, "  packed, no DMA in the loop");
+  rc |= run4<8, 2, 0, 1, 1>(a, "k_full4 packed, 8 bands");
+  rc |= run5<128, 2, 0>(a, "k_full5");
+  rc |= run5<128, 2, 1>(a, "  no stores");
+  rc |= run5<128, 2, 2>(a, "  no MFMA");
+  rc |= run5<128, 2, 4>(a, "  no DMA in the loop");
+  if (getenv("FULL128_ONLY3")) return rc;
   rc |= run2<4, 2>(a, "prefetch distance 2");
   rc |= run2<4, 3>(a, "prefetch distance 2, 3 waves per SIMD");
   rc |= run2<8, 2>(a, "8 waves: prefetch distance 2");
