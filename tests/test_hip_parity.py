@@ -357,12 +357,17 @@ def test_mf_family_matches_reference(L, ctx, kind):
     close(L.mf_predict_full(struct(), device=dev()), g['full'], FWD_RTOL, FWD_ATOL, kind + ' full matrix')
 
 
+@pytest.mark.parametrize('form', ['lines', 'rows'])
 @pytest.mark.parametrize('D', [16, 32, 64, 128, 24])
 @pytest.mark.parametrize('kind', ['RecModel', 'BiasedMF', 'IPSBiasedMF'])
-def test_mf_full_matrix_every_kernel_form_ragged_sizes(L, D, kind):
-    """mf_predict_full for every D-specific kernel form (row-band D=16, LDS-band 32/64/128, generic tile 24) at sizes that
-    are multiples of nothing (user bands, 64- and 256-item tiles all end ragged) against the formula in fp64
-    (src/models/IPSBiasedMF.py:37-57: (P Q^T + bu + bi + b0) / max(prop, M))."""
+def test_mf_full_matrix_every_kernel_form_ragged_sizes(L, D, kind, form, monkeypatch):
+    """mf_predict_full for every D-specific kernel form (the line form of round 3 and, with DCCF_FULL_FORM=rows, round 2's row-band
+    form for D = 16 / 32 / 64 / 128; the generic tile for 24) at sizes that are multiples of nothing (user bands, 32-, 64- and 256-item
+    tiles all end ragged) against the formula in fp64 (src/models/IPSBiasedMF.py:37-57: (P Q^T + bu + bi + b0) / max(prop, M))."""
+    if form == 'rows':
+        monkeypatch.setenv('DCCF_FULL_FORM', 'rows')
+    else:
+        monkeypatch.delenv('DCCF_FULL_FORM', raising=False)
     U, I = 257 + 31, 2 * 256 + 77
     g = torch.Generator(device='cuda').manual_seed(D)
     P, Q = torch.randn(U, D, generator=g, device='cuda') * 0.3, torch.randn(I, D, generator=g, device='cuda') * 0.3
@@ -379,6 +384,30 @@ def test_mf_full_matrix_every_kernel_form_ragged_sizes(L, D, kind):
         ref = ref / torch.clamp(prop.double(), min=0.3)[None, :]
     assert bool(torch.isfinite(out[:U]).all()) and bool(torch.isnan(out[U]).all())
     close(out[:U], ref.cpu().numpy(), 2e-6, 1e-6, 'full matrix D=%d %s' % (D, kind))
+
+
+@pytest.mark.parametrize('U,I,off', [(1, 1, 0), (5, 31, 3), (33, 32, 1), (130, 64, 7), (31, 257, 31), (64, 1000, 13), (257, 4101, 2),
+                                     (128, 96, 0), (129, 33, 5)])
+@pytest.mark.parametrize('D', [16, 64, 128])
+def test_mf_full_matrix_line_form_edges(L, D, U, I, off, monkeypatch):
+    """The line form's stores are aligned to the 128-byte lines of `out` whatever the row length and the pointer are: tiny matrices
+    (fewer item tiles than item ranges, fewer users than a band), row lengths that ARE multiples of 32, and an `out` that starts
+    `off` floats into its allocation.  Nothing outside [out, out + U * I) may be written, everything inside must be
+    (README.md:28-30; formula src/models/IPSBiasedMF.py:37-57)."""
+    monkeypatch.delenv('DCCF_FULL_FORM', raising=False)
+    g = torch.Generator(device='cuda').manual_seed(D + U + I)
+    P, Q = torch.randn(U, D, generator=g, device='cuda') * 0.3, torch.randn(I, D, generator=g, device='cuda') * 0.3
+    bu, bi = torch.randn(U, generator=g, device='cuda') * 0.1, torch.randn(I, generator=g, device='cuda') * 0.1
+    prop = torch.rand(I, generator=g, device='cuda')
+    b0 = torch.full((1,), 0.1, device='cuda')
+    m = L.mf_struct('IPSBiasedMF', P, Q, bu, bi, b0, prop, 0.3)
+    flat = torch.full((off + U * I + 200,), float('nan'), device='cuda')
+    out = flat[off:off + U * I].view(U, I)
+    L.mf_predict_full(m, out=out)
+    ref = (P.double() @ Q.double().T + bu.double()[:, None] + bi.double()[None, :] + 0.1) / torch.clamp(prop.double(), min=0.3)[None, :]
+    assert bool(torch.isnan(flat[:off]).all()) and bool(torch.isnan(flat[off + U * I:]).all()), 'wrote outside the matrix'
+    assert bool(torch.isfinite(out).all()), 'left a hole'
+    close(out, ref.cpu().numpy(), 2e-6, 1e-6, 'full matrix D=%d %dx%d +%d' % (D, U, I, off))
 
 
 def test_mf_train_mse_and_duplicates_vs_oracle(L, ctx):
