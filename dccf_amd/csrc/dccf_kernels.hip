@@ -270,12 +270,31 @@ __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT,
   const int dbase = blockIdx.y * DW;
   // register-resident B operands
   float bf[NGF * 4 * ND], bi[NGI * 4 * ND];
+  // FAL (F a whole number of chunks, feature rows 16-byte aligned): the wave's feature k-steps come in SUPER-GROUPS of 16 — lane
+  // (row, h) of super-group (tq, sg) takes the columns f = 128 tq + 32 o + m, m = 8 sg + 4 h + j, o, j < 4: four runs of four
+  // CONSECUTIVE columns = four dwordx4 loads instead of sixteen dword loads that each touched a different line of the row (the
+  // plain form's group takes f = 128 tq + (2 c2 + h) + 32 o: every 128-byte line of a feature row was requested by 16 different
+  // instructions; scripts/bf16x6_bench.hip: 20.4 -> 17.6 us for the B = 128 tile loop, 542 -> 456 us at evaluation size).  The
+  // noise keeps its definition — eps(l, 128 tq + m + 32 o) = word o of Philox(l, 32 tq + m) — so the four calls m = 8 sg + 4 h + j
+  // supply exactly the 16 values; only the ORDER of the k-steps (fp32 summation order) differs from the plain form.
+  constexpr bool SG = FAL && (NCM % 2 == 0);
 #define FWD_LOAD_BF(PASS)                                                                                             \
+  if (SG) {                                                                                                           \
+    _Pragma("unroll") for (int sl = 0; sl < NGF / 4; ++sl) {                                                          \
+      const int sq = wave * (NGF / 4) + sl, tq = (PASS) * NCM + (sq >> 2), sg = sq & 3;                               \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                   \
+        _Pragma("unroll") for (int o = 0; o < 4; ++o)                                                                 \
+          _Pragma("unroll") for (int nt = 0; nt < ND; ++nt)                                                           \
+            bf[((sl * 4 + j) * 4 + o) * ND + nt] =                                                                    \
+                WT[(int64_t)(Dr + tq * 128 + 32 * o + 8 * sg + 4 * h + j) * DP + dbase + nt * 32 + c31];              \
+    }                                                                                                                 \
+  } else {                                                                                                            \
   _Pragma("unroll") for (int g = 0; g < NGF; ++g) {                                                                   \
     const int q = wave * NGF + g, tq = (PASS) * NCM + (q >> 4), c2 = q & 15;                                         \
     _Pragma("unroll") for (int o = 0; o < 4; ++o)                                                                     \
       _Pragma("unroll") for (int nt = 0; nt < ND; ++nt)                                                               \
         bf[(g * 4 + o) * ND + nt] = WT[(int64_t)(Dr + tq * 128 + 2 * c2 + h + 32 * o) * DP + dbase + nt * 32 + c31]; \
+  }                                                                                                                   \
   }
   if (!MP) { FWD_LOAD_BF(0) }
 #pragma unroll
@@ -369,6 +388,34 @@ __global__ __launch_bounds__(512) void k_noise_fwd(const float* __restrict__ WT,
       asm volatile("" : "+v"(fbase));               // opaque per tile: the clamped offsets below must not be hoisted
       for (int pass = 0; pass < (MP ? npass : 1); ++pass) {
       if (MP) { FWD_LOAD_BF(pass) }
+      if (SG) {
+        int fb4 = 4 * h;
+        asm volatile("" : "+v"(fb4));               // (opaque per tile, as fbase)
+#pragma unroll
+        for (int sl = 0; sl < NGF / 4; ++sl) {
+          const int sq = wave * (NGF / 4) + sl, tq = pass * NCM + (sq >> 2), sg = sq & 3;
+          float4 fv4[4], nv4[4];
+#pragma unroll
+          for (int o = 0; o < 4; ++o) {
+            const int f0 = fb4 + tq * 128 + 32 * o + 8 * sg;
+            fv4[o] = *reinterpret_cast<const float4*>(frow + f0);
+            if (MODE == 1) nv4[o] = *reinterpret_cast<const float4*>(nrow + f0);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float a[4];
+            if (MODE == 0) noise4((uint32_t)l, (uint32_t)(tq * 32 + 8 * sg + 4 * h + j), nkey, nscale, a);
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+              const float fe = j == 0 ? fv4[o].x : (j == 1 ? fv4[o].y : (j == 2 ? fv4[o].z : fv4[o].w));
+              if (MODE == 1) a[o] = j == 0 ? nv4[o].x : (j == 1 ? nv4[o].y : (j == 2 ? nv4[o].z : nv4[o].w));
+              const float av = fe + a[o];           // sample_feature_embeddings = feature + noise (DCCF.py:87)
+#pragma unroll
+              for (int nt = 0; nt < ND; ++nt) acc[nt] = MFMA32(av, bf[((sl * 4 + j) * 4 + o) * ND + nt], acc[nt]);
+            }
+          }
+        }
+      } else
 #pragma unroll                                      // out of the tile loop and kept live (they would spill the W slice)
       for (int g = 0; g < NGF; ++g) {
         const int q = wave * NGF + g, tq = pass * NCM + (q >> 4), c2 = q & 15;
@@ -1644,6 +1691,8 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
     }
     const dim3 grid((unsigned)(tile_blocks + lh.blocks), y.GY), block(512);
     const size_t smem = (size_t)8 * 32 * y.ND * 32 * 4;
+    // the whole-chunk instances read the feature (and injected noise) rows as dwordx4
+    const bool fal_ok = (uintptr_t)M->feat % 16 == 0 && (fused || (uintptr_t)rnd->noise % 16 == 0);
     prof_begin(ctx, st);
 #define LAUNCH_FWD3(D_, MODE_, NCM_, FAL_, MP_, GEN_)                                                                 \
   {                                                                                                                  \
@@ -1658,8 +1707,8 @@ static int run_dccf(dccf_ctx* ctx, const dccf_model_t* M, const dccf_rand_t* rnd
   }
 #define LAUNCH_FWD2(D_, MODE_)                                                                          \
   if (D != D_) { if (y.FP == 768) LAUNCH_FWD3(D_, MODE_, 6, false, false, true) else LAUNCH_FWD3(D_, MODE_, 6, false, true, true) } \
-  else if (y.FP == 256) { if (F == 256) LAUNCH_FWD3(D_, MODE_, 2, true, false, false) else LAUNCH_FWD3(D_, MODE_, 2, false, false, false) }      \
-  else if (y.FP == 768) { if (F == 768) LAUNCH_FWD3(D_, MODE_, 6, true, false, false) else LAUNCH_FWD3(D_, MODE_, 6, false, false, false) } \
+  else if (y.FP == 256) { if (F == 256 && fal_ok) LAUNCH_FWD3(D_, MODE_, 2, true, false, false) else LAUNCH_FWD3(D_, MODE_, 2, false, false, false) }      \
+  else if (y.FP == 768) { if (F == 768 && fal_ok) LAUNCH_FWD3(D_, MODE_, 6, true, false, false) else LAUNCH_FWD3(D_, MODE_, 6, false, false, false) } \
   else if (y.FP == 896) LAUNCH_FWD3(D_, MODE_, 7, false, false, false)                                  \
   else LAUNCH_FWD3(D_, MODE_, 6, false, true, false)
 #define LAUNCH_FWD(D_) if (fused) LAUNCH_FWD2(D_, 0) else LAUNCH_FWD2(D_, 1)
