@@ -315,28 +315,57 @@ __device__ __forceinline__ void lazy_window_pass(float* __restrict__ p, float* _
     const int64_t r0 = max(win0, z.row_off[q]) - z.row_off[q], r1 = min(win1, z.row_off[q] + z.rows[q]) - z.row_off[q];
     if (r1 <= r0) continue;
     const int w4 = sg.width[q] >> 2;
-    const int64_t nslot = (r1 - r0) * w4;
-    for (int64_t x0 = bid * nthreads; x0 < nslot; x0 += nblk * nthreads) {      // (uniform per workgroup: every lane reaches wave_min_int)
+    const int64_t nslot = (r1 - r0) * w4, stride = nblk * nthreads;
+    // Software-pipelined: a slot's row state (`last`, claim) and its p / s1 / s2 are fetched one iteration AHEAD, all at once and
+    // whether or not the slot turns out to need the replay (nearly all do: only the step's own rows do not), so the replay of slot k
+    // (K steps x ~45 vector instructions) runs while slot k + 1's loads are in flight.  Hosted in the forward launch a workgroup has 2
+    // waves per SIMD and a handful of slots per thread: fetched one after the other (state, then data, then the replay) the loop was
+    // two round trips per slot and latency-bound.
+    struct Slot {
+      int64_t grow, i;
+      int last, claim;
+      bool live;
+      float4 pv, av, bv;
+    };
+    auto fetch = [&](int64_t x0, Slot& f) {
       const int64_t x = x0 + threadIdx.x;
-      const bool live = x < nslot;
-      const int64_t xc = live ? x : nslot - 1;
+      f.live = x < nslot;
+      const int64_t xc = f.live ? x : nslot - 1;
       const int64_t row = r0 + xc / w4;
-      const int64_t grow = z.row_off[q] + row;
-      const int from = lazy_from(z, pend, grow, t);
+      f.grow = z.row_off[q] + row;
+      f.i = (sg.begin[q] >> 2) + row * w4 + xc % w4;
+      f.last = z.last[f.grow];
+      f.claim = claim[f.grow];
+      f.pv = reinterpret_cast<const float4*>(p)[f.i];
+      f.av = make_float4(0, 0, 0, 0);
+      f.bv = make_float4(0, 0, 0, 0);
+      if (KIND != DCCF_OPT_GD) f.av = reinterpret_cast<const float4*>(s1)[f.i];
+      if (KIND == DCCF_OPT_ADAM) f.bv = reinterpret_cast<const float4*>(s2)[f.i];
+    };
+    int64_t x0 = bid * nthreads;                    // (uniform per workgroup: every lane reaches wave_min_int)
+    if (x0 >= nslot) continue;
+    Slot cur, nxt;
+    fetch(x0, cur);
+    for (; x0 < nslot; x0 += stride) {
+      const bool more = x0 + stride < nslot;
+      if (more) fetch(x0 + stride, nxt);
+      // lazy_from on the fetched state: the effective `last` (the previous step's window is marked one launch late), bounded by K
+      int from = (cur.grow >= pend.w0 && cur.grow < pend.w1 && cur.last < pend.t) ? pend.t : cur.last;
+      if (from < t - z.K) {
+        z.cnt[15] = 1;
+        from = t - z.K;
+      }
       // a row this step touched is the list's business (its last is t - 1 until that wave has updated it: never replay it here)
-      const bool need = live && from < t && (flush || claim[grow] != t);
+      const bool need = cur.live && from < t && (flush || cur.claim != t);
       const int fr = need ? from : t;
       const int lo = max(wave_min_int(fr), sct_base);      // (no row is more than K steps behind: the bound is for memory safety)
-      if (lo >= t || !need) continue;
-      const int64_t i = (sg.begin[q] >> 2) + row * w4 + xc % w4;
-      float4 pv = reinterpret_cast<float4*>(p)[i];
-      float4 av = make_float4(0, 0, 0, 0), bv = make_float4(0, 0, 0, 0);
-      if (KIND != DCCF_OPT_GD) av = reinterpret_cast<float4*>(s1)[i];
-      if (KIND == DCCF_OPT_ADAM) bv = reinterpret_cast<float4*>(s2)[i];
-      lazy_replay4_u<KIND>(pv, av, bv, a, sct, sct_base, fr, t, lo);
-      reinterpret_cast<float4*>(p)[i] = pv;
-      if (KIND != DCCF_OPT_GD) reinterpret_cast<float4*>(s1)[i] = av;
-      if (KIND == DCCF_OPT_ADAM) reinterpret_cast<float4*>(s2)[i] = bv;
+      if (lo < t && need) {
+        lazy_replay4_u<KIND>(cur.pv, cur.av, cur.bv, a, sct, sct_base, fr, t, lo);
+        reinterpret_cast<float4*>(p)[cur.i] = cur.pv;
+        if (KIND != DCCF_OPT_GD) reinterpret_cast<float4*>(s1)[cur.i] = cur.av;
+        if (KIND == DCCF_OPT_ADAM) reinterpret_cast<float4*>(s2)[cur.i] = cur.bv;
+      }
+      if (more) cur = nxt;
     }
   }
 }
