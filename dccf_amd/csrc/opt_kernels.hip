@@ -269,7 +269,9 @@ __device__ __forceinline__ void opt_st4(float4* q, const float4& v) {
     *q = v;
   }
 }
-template <int KIND, int UN, bool TO, bool NT = false>
+// GW: row widths that are not a power of two (any multiple of 4 up to 256: src/models/RecModel.py:17-27 accepts any embedding size) —
+// the row of a slot by a 32-bit division instead of a shift (segments stay below 2^32 elements: checked at launch)
+template <int KIND, int UN, bool TO, bool NT = false, bool GW = false>
 __global__ __launch_bounds__(256) void k_dense_opt_rows(float* __restrict__ p, float* __restrict__ g, float* __restrict__ s1,
                                                         float* __restrict__ s2, int64_t n, OptArgs a, RowSegs sg,
                                                         int phase, PrepNext pn) {
@@ -309,8 +311,14 @@ __global__ __launch_bounds__(256) void k_dense_opt_rows(float* __restrict__ p, f
       for (int q = 0; q < 4; ++q)
         if (q < sg.n && e >= sg.begin[q] && e < sg.end[q]) {
           const int64_t off = e - sg.begin[q];
-          fl[u] = sg.flags[q] + (off >> wsh[q]);
-          first[u] = (off & (sg.width[q] - 1)) == 0;
+          if (GW) {
+            const uint32_t row = (uint32_t)off / (uint32_t)sg.width[q];
+            fl[u] = sg.flags[q] + row;
+            first[u] = (uint32_t)off == row * (uint32_t)sg.width[q];
+          } else {
+            fl[u] = sg.flags[q] + (off >> wsh[q]);
+            first[u] = (off & (sg.width[q] - 1)) == 0;
+          }
           if (TO) tonly = (sg.to_mask >> q) & 1;
         }
       av[u] = bv[u] = gv[u] = make_float4(0, 0, 0, 0);
@@ -354,7 +362,8 @@ __global__ __launch_bounds__(256) void k_dense_opt_rows(float* __restrict__ p, f
       if (touched[u]) reinterpret_cast<float4*>(g)[i] = make_float4(0, 0, 0, 0);
       if (KIND != DCCF_OPT_GD) opt_st4<NT>(reinterpret_cast<float4*>(s1) + i, av[u]);
       if (KIND == DCCF_OPT_ADAM) opt_st4<NT>(reinterpret_cast<float4*>(s2) + i, bv[u]);
-      if (fl[u] && touched[u] && first[u]) *fl[u] = 0;
+      // (GW: a row of such a width may straddle two waves — the other wave must still see the byte: the host clears the bytes after the launch)
+      if (!GW && fl[u] && touched[u] && first[u]) *fl[u] = 0;
     }
   }
   if (phase == OPT_PHASE_UNTOUCHED) return;
@@ -469,12 +478,8 @@ static int launch_job(const OptJob& j0, int phase, const int64_t* list, const in
   bool general = false;
   for (int q = 0; q < j.sg.n; ++q) general = general || !tile_width(j.sg.width[q]);
   if (general) {
-    // row widths that are not a power of two: no "whole rows per wave" — the pass reads and re-zeroes the gradient everywhere
-    // (the plain dense step) and the rows' touched bytes are cleared wholesale
-    ARG_CHECK(phase == OPT_PHASE_ALL && j.sg.to_mask == 0, "the two-phase / hosted optimizer pass needs row widths of 16, 32, 64 or 128");
-    for (int q = 0; q < j.sg.n; ++q)
-      HIP_TRY(hipMemsetAsync(j.sg.flags[q], 0, (size_t)((j.sg.end[q] - j.sg.begin[q]) / j.sg.width[q]), st));
-    j.sg.n = 0;
+    // row widths that are not a power of two: the GW instances (a division per slot instead of a shift)
+    for (int q = 0; q < j.sg.n; ++q) ARG_CHECK(j.sg.end[q] - j.sg.begin[q] < 4294967296LL, "row segment too large for a width that is not 16, 32, 64 or 128");
   }
   if (phase == OPT_PHASE_TOUCHED) {
     ARG_CHECK(list && cnt, "touched phase needs the row list");
@@ -520,8 +525,20 @@ static int launch_job(const OptJob& j0, int phase, const int64_t* list, const in
   else if (j.kind == DCCF_OPT_ADAGRAD) OPT_ROWS_LAUNCH(DCCF_OPT_ADAGRAD, UN_, TO_, NT_); \
   else OPT_ROWS_LAUNCH(DCCF_OPT_ADAM, UN_, TO_, NT_)
 #define OPT_ROWS_KIND(UN_, TO_) OPT_ROWS_KIND4(UN_, TO_, false)
+#define OPT_ROWS_LAUNCH_GW(KIND_, TO_) \
+  hipLaunchKernelGGL((k_dense_opt_rows<KIND_, 1, TO_, false, true>), dim3(grid), dim3(256), 0, st, j.p, j.g, j.s1, j.s2, j.n, j.a, j.sg, phase, pn)
+#define OPT_ROWS_KIND_GW(TO_)                                                   \
+  if (j.kind == DCCF_OPT_GD) OPT_ROWS_LAUNCH_GW(DCCF_OPT_GD, TO_);              \
+  else if (j.kind == DCCF_OPT_ADAGRAD) OPT_ROWS_LAUNCH_GW(DCCF_OPT_ADAGRAD, TO_); \
+  else OPT_ROWS_LAUNCH_GW(DCCF_OPT_ADAM, TO_)
   // TO: a segment in "only the marked rows" mode (its other rows were updated by the pass hosted in the backward launch)
-  if (j.n >= big_n) {
+  if (general) {
+    ARG_CHECK(j.sg.to_mask == 0, "the pass hosted in the backward launch needs row widths of 16, 32, 64 or 128");
+    OPT_ROWS_KIND_GW(false);
+    if (phase == OPT_PHASE_ALL)
+      for (int q = 0; q < j.sg.n; ++q)
+        HIP_TRY(hipMemsetAsync(j.sg.flags[q], 0, (size_t)((j.sg.end[q] - j.sg.begin[q]) / j.sg.width[q]), st));
+  } else if (j.n >= big_n) {
     if (j.sg.to_mask) { OPT_ROWS_KIND(2, true); }
     else if (un_big >= 4) { if (nt_big) { OPT_ROWS_KIND4(4, false, true); } else { OPT_ROWS_KIND4(4, false, false); } }
     else if (un_big <= 1) { if (nt_big) { OPT_ROWS_KIND4(1, false, true); } else { OPT_ROWS_KIND4(1, false, false); } }
@@ -529,6 +546,8 @@ static int launch_job(const OptJob& j0, int phase, const int64_t* list, const in
   } else {
     if (j.sg.to_mask) { OPT_ROWS_KIND(1, true); } else { OPT_ROWS_KIND(1, false); }
   }
+#undef OPT_ROWS_KIND_GW
+#undef OPT_ROWS_LAUNCH_GW
 #undef OPT_ROWS_KIND
 #undef OPT_ROWS_KIND4
 #undef OPT_ROWS_LAUNCH

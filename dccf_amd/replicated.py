@@ -59,7 +59,7 @@ class HipBackend(object):
         # windowed lazy regularisation in the overlapped form of the step: phase 1 advances one K-th of the
         # rows no rank touches by K steps instead of streaming all of them every step
         self.lazy = None
-        if tr.lazy_K >= 2 and tr.overlap and tr.D in (16, 32, 64, 128):
+        if tr.lazy_K >= 2 and tr.overlap and tr.D % 4 == 0 and 4 <= tr.D <= 128:       # (any row width the lazy kernels take)
             self.lazy = L.LazyState(self.opt, tr.lazy_K, tr.user_num + tr.item_num, 64, tr.lr, tr.flat_p.device)
             self.lazy.sync_all(tr.t)
         self.scratch = L.DpScratch(tr.user_num + tr.item_num, tr.G, tr.flat_g.device)

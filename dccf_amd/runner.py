@@ -174,10 +174,10 @@ class BaseRunner(object):
         tr = getattr(model, '_replicated', None)
         if tr is None:
             D = getattr(model, 'ui_vector_size', 0)
-            if (getattr(model, 'kind', '') != 'DCCF' or D not in (16, 32, 64, 128) or not self.fused_sampling
+            if (getattr(model, 'kind', '') != 'DCCF' or D % 4 != 0 or not 4 <= D <= 128 or not self.fused_sampling
                     or data_processor.rank != 1):
-                raise RuntimeError('training on several GPUs covers --model_name DCCF --rank 1 --fused_sampling 1 with an '
-                                   'embedding size of 16, 32, 64 or 128')
+                raise RuntimeError('training on several GPUs (replicated layout) covers --model_name DCCF --rank 1 --fused_sampling 1 '
+                                   'with an embedding size that is a multiple of 4 up to 128 (--mp sharded: up to 256)')
             o.flush()
             tr = replicated.ReplicatedDCCF(rank, G, model.user_num, model.item_num, D, model.sample_num, model.attribute_num,
                                            model.std, self.dropout, o.lr, o.l2, model.random_seed,

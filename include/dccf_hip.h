@@ -146,10 +146,10 @@ int dccf_dense_opt_step(int32_t kind, float* p, float* g, float* s1, float* s2, 
                         float l2, float clip, int64_t step, int32_t zero_grad, void* stream);
 /* Same step for a flat buffer whose first part is row-structured: segment q covers elements [seg_begin[q], seg_begin[q] +
  * seg_rows[q]*seg_width[q]) as rows of seg_width[q] floats (a multiple of 4 up to 256; seg_begin a multiple of 256) with one
- * "touched" byte per row (dccf_grads_t.touchedU/V).  Widths of 16, 32, 64 or 128 take the row-aware streaming pass described
- * next; any other width is legal everywhere the LAZY optimizer runs (dccf_train_step with lazy_K > 0, dccf_lazy_*) and makes
- * this entry the plain dense step (gradient read and re-zeroed everywhere, every touched byte cleared); the two-phase and hosted
- * forms (dccf_dense_opt_phase, dccf_train_step with overlap != 0) need one of the four widths.  A row whose byte is 0 has an all-zero gradient by construction, so
+ * "touched" byte per row (dccf_grads_t.touchedU/V).  Every such width takes the row-aware streaming pass described next and its
+ * two-phase form (widths other than 16, 32, 64, 128: the row of a slot by a division instead of a shift, the bytes cleared by a
+ * memset after the launch; segments below 2^32 elements); only the form HOSTED in the backward launch (dccf_train_step with
+ * overlap == 2) needs one of the four widths.  A row whose byte is 0 has an all-zero gradient by construction, so
  * g is neither read nor re-zeroed for it (24 instead of 32 B/param of traffic); touched rows are read, zeroed and their
  * byte cleared.  Elements outside the segments are treated densely.  seg_* are HOST arrays, nseg <= 4. */
 int dccf_dense_opt_step_rows(int32_t kind, float* p, float* g, float* s1, float* s2, int64_t n, float lr, float wd,

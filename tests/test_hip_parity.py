@@ -893,11 +893,11 @@ def test_overlapped_train_step_equals_split_step(L, opt_name, B, l2, D, NL):
     gen = torch.Generator(device='cuda').manual_seed(9)
     full = torch.stack([torch.stack([torch.randint(0, U // 2 if k % 2 else 40, (2 * B,), generator=gen, device='cuda'),
                                      torch.randint(0, I, (2 * B,), generator=gen, device='cuda')], 1) for k in range(6)])
-    tile = D in (16, 32, 64, 128)       # the overlapped / hosted forms need one of the four tile widths; the lazy ones any multiple of 4
+    tile = D in (16, 32, 64, 128)       # the form hosted in the backward launch needs one of the four tile widths; the others any multiple of 4
     # 'step' / 'prep' run with the windowed lazy regularisation (DCCF.lazy_K = 16 by default: 6 steps never complete a cycle of
     # windows, so most rows are brought up to date by the flush); 'dense' / 'denseprep' are the same calls with lazy_K = 0;
     # 'lazy3' cycles the windows twice
-    for mode in ('split', 'step', 'overlap', 'prep', 'hosted', 'dense', 'denseprep', 'lazy3') if tile else ('split', 'step', 'prep', 'dense', 'denseprep', 'lazy3'):
+    for mode in ('split', 'step', 'overlap', 'prep', 'hosted', 'dense', 'denseprep', 'lazy3') if tile else ('split', 'step', 'overlap', 'prep', 'dense', 'denseprep', 'lazy3'):
         m = DCCF(path=None, dataset=None, sentence_model=None, sample_num=10, attribute_num=2, std=0.1, label_min=0, label_max=1,
                  feature_num=0, user_num=U, item_num=I, u_vector_size=D, i_vector_size=D, n_layers=NL, random_seed=11,
                  model_path='/tmp/x.pt', feature_embedding=feat, expo_prob=expo)
@@ -971,7 +971,7 @@ def test_every_form_of_the_train_step_is_bit_identical_in_deterministic_mode(L, 
                                      torch.randint(0, 60 if k % 3 == 0 else I, (2 * B,), generator=gen, device='cuda')], 1) for k in range(nst)])
     tile = D in (16, 32, 64, 128)
     states = []
-    modes = ('split', 'step', 'overlap', 'prep', 'hosted', 'dense', 'denseprep', 'lazy3', 'split') if tile else ('split', 'step', 'prep', 'dense', 'denseprep', 'lazy3', 'split')
+    modes = ('split', 'step', 'overlap', 'prep', 'hosted', 'dense', 'denseprep', 'lazy3', 'split') if tile else ('split', 'step', 'overlap', 'prep', 'dense', 'denseprep', 'lazy3', 'split')
     for mode in modes:
         m = DCCF(path=None, dataset=None, sentence_model=None, sample_num=10, attribute_num=2, std=0.1, label_min=0, label_max=1,
                  feature_num=0, user_num=U, item_num=I, u_vector_size=D, i_vector_size=D, n_layers=NL, random_seed=11,

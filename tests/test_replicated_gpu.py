@@ -237,7 +237,8 @@ W2 = dict(U=700, I=450, D=64, F=96, S=10, A=2, B=40, steps=5)
 @pytest.mark.parametrize('overlap,world,opt_name,n_layers,D', [
     (False, 2, 'adam', 1, 64), (True, 2, 'adam', 1, 64), ('prep', 2, 'adam', 1, 64), ('prep', 3, 'adam', 1, 64),
     ('prep', 2, 'adagrad', 1, 64), ('prep', 2, 'gd', 1, 64), (False, 2, 'gd', 1, 64), ('prep', 2, 'adam', 2, 64),
-    (True, 2, 'adam', 3, 64), (False, 2, 'adagrad', 2, 64), ('prep', 2, 'adam', 1, 16), ('prep', 2, 'adam', 1, 128)])
+    (True, 2, 'adam', 3, 64), (False, 2, 'adagrad', 2, 64), ('prep', 2, 'adam', 1, 16), ('prep', 2, 'adam', 1, 128),
+    ('prep', 2, 'adam', 1, 48), (True, 2, 'adam', 1, 24), (False, 2, 'gd', 1, 100), ('prep', 2, 'adagrad', 2, 100)])
 def test_two_ranks_hip_backend_replicas_bit_identical(tmp_path, overlap, world, opt_name, n_layers, D):
     """World size 2 (and 3) with the HIP backend (the ranks share this box's one GPU, gloo as the transport): the replicas
     end bit-identical, nothing is left in the gradient buffer, the flags or the tables, and the result equals the same
@@ -471,21 +472,23 @@ def test_cli_on_two_ranks(tmp_path, layout):
             'epoch %d: two ranks %.4f vs reference %.4f (se %.4f)' % (e + 1, mine[:, e].mean(), ref[:, e].mean(), se)
 
 
+@pytest.mark.parametrize('D', [16, 24])
 @pytest.mark.parametrize('layout', ['replicated', 'sharded'])
-def test_cli_on_two_ranks_extra_layers_adagrad(tmp_path, layout):
+def test_cli_on_two_ranks_extra_layers_adagrad(tmp_path, layout, D):
     """The same launch (both layouts) with --n_layers 2 --optimizer Adagrad and a batch size that leaves the epoch's schedule uneven: the extra
-    layers travel in the dense tail of the exchange, the replicas stay identical and the checkpoint holds all six tensors."""
+    layers travel in the dense tail of the exchange, the replicas stay identical and the checkpoint holds all six tensors.  D = 24: an
+    embedding size that is no column tile (src/models/RecModel.py:17-27 accepts any)."""
     import torch.multiprocessing as mp
     from dccf_amd import synth
     tmp = str(tmp_path)
     synth.write_dataset(os.path.join(tmp, 'dataset'), 'toy', 300, 200, 5000, feat_dim=32, seed=3)
-    cfg = dict(lr=0.01, epochs=2, test_neg_n=50, D=16, batch_size=96, seeds=[7], optimizer='Adagrad', more=['--n_layers', '2', '--mp', layout])
+    cfg = dict(lr=0.01, epochs=2, test_neg_n=50, D=D, batch_size=96, seeds=[7], optimizer='Adagrad', more=['--n_layers', '2', '--mp', layout])
     from conftest import free_port
     mp.spawn(_cli_rank_main, args=(2, free_port(), tmp, cfg), nprocs=2, join=True)
     r0, r1 = (dict(np.load(os.path.join(tmp, 'cli%d.npz' % r))) for r in range(2))
     for k in r0:
         assert np.array_equal(r0[k], r1[k], equal_nan=True), k
-    assert {'mlp.1.weight', 'mlp.1.bias'} <= set(r0) and r0['mlp.1.weight'].shape == (16, 16)
+    assert {'mlp.1.weight', 'mlp.1.bias'} <= set(r0) and r0['mlp.1.weight'].shape == (D, D)
     sd = torch.load(os.path.join(tmp, 'model', 'DCCF', 'two.pt'), map_location='cpu')
     assert len(sd) == 6
     # the extra layer was trained: N(0, 0.01) at the start, Adagrad's first steps move every touched element by ~lr
