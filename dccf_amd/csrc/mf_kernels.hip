@@ -677,7 +677,10 @@ __global__ __launch_bounds__(64 * NW) void k_mf_full_rows(mf_model_t M, float* _
 // Q [I][D], bi, prop -> the operand stream of k_mf_full_lines: per tile of 32 items a [D / 8][2][32][4] image — the 16 bytes lane
 // (c, h) feeds to four consecutive k-steps of v_mfma_f32_32x32x2_f32 (k = 2 (4 q + j) + h, j < 4) are one ds_read_b128 — and per tile
 // 64 floats of epilogue operands: bi[i] (kind >= 1) and max(prop[i], M) (kind 2).  Padded with zero tiles to Tpad.
-__global__ __launch_bounds__(256) void k_full_lines_prep(mf_model_t M, int D, int64_t Tpad, float* __restrict__ QT4, float* __restrict__ AUX) {
+// (k < kvalid of the model's columns [koff, koff + kvalid) are real, the rest of the D-wide image is zero: embedding sizes that are no
+// tile of the kernel are padded here, sizes above 128 run as two passes over the halves of the contraction)
+__global__ __launch_bounds__(256) void k_full_lines_prep(mf_model_t M, int D, int64_t Tpad, float* __restrict__ QT4, float* __restrict__ AUX,
+                                                         int koff, int kvalid, int kind) {
   const int64_t n = Tpad * D * 32;
   for (int64_t x = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; x < n; x += (int64_t)gridDim.x * blockDim.x) {
     const int64_t T = x / (D * 32);
@@ -685,13 +688,13 @@ __global__ __launch_bounds__(256) void k_full_lines_prep(mf_model_t M, int D, in
     const int j = rem & 3, col = (rem >> 2) & 31, qh = rem >> 7;
     const int k = 2 * (4 * (qh >> 1) + j) + (qh & 1);
     const int64_t it = T * 32 + col;
-    QT4[x] = it < M.item_num ? M.Q[it * D + k] : 0.f;
+    QT4[x] = (it < M.item_num && k < kvalid) ? M.Q[it * M.D + koff + k] : 0.f;
     if (rem < 64) {
       const int64_t i2 = T * 32 + (rem & 31);
       float v = rem < 32 ? 0.f : 1.f;
       if (i2 < M.item_num) {
-        if (rem < 32 && M.kind >= 1) v = M.bi[i2];
-        if (rem >= 32 && M.kind == 2) v = fmaxf(M.prop[i2], M.M);
+        if (rem < 32 && kind >= 1) v = M.bi[i2];
+        if (rem >= 32 && kind == 2) v = fmaxf(M.prop[i2], M.M);
       }
       AUX[T * 64 + rem] = v;
     }
@@ -715,7 +718,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int D>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_mf_full_lines(mf_model_t M, float* __restrict__ out,
                                                                                                      const float* __restrict__ QT4,
-                                                                                                     const float* __restrict__ AUX, int splits) {
+                                                                                                     const float* __restrict__ AUX, int splits,
+                                                                                                     int koff, int kvalid, int kind, int add) {
+  // koff / kvalid: this launch contracts the model's columns [koff, koff + kvalid) (kvalid <= D: the rest of the tile is zero);
+  // kind: the epilogue of THIS launch (0: none); add: the contraction continues the partial product already in `out`
   constexpr int S = 128 / D, TILE = D * 32, CHUNK = S * TILE, NQ = D / 8, CW = 64;           // CHUNK = 4096 floats = 16 KB
   static_assert(S * D == 128 && CHUNK == 4096, "D must be 16, 32, 64 or 128");
   extern __shared__ __attribute__((aligned(128))) float sm[];   // [2][CHUNK] operand | [2][S][64] epilogue operands | [4][32][CW] windows
@@ -730,16 +736,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (T0 >= T1) return;                                         // (the whole workgroup: before any barrier)
   const int64_t u0 = (grp * 4 + wave) * 32;
   const bool rows_full = u0 + 32 <= U;
-  const int kind = M.kind;
   const float b0 = kind >= 1 ? M.b0[0] : 0.f;
-  float pa[D / 2];
-  {
+  float pa[D / 2];                                              // pa[i] = P[u][koff + 2 i + h]
+  if (kvalid == D && M.D == D && (uintptr_t)M.P % 16 == 0) {
     const float4* prow = reinterpret_cast<const float4*>(M.P + min(u0 + c31, U - 1) * D);
 #pragma unroll
     for (int j = 0; j < D / 4; ++j) {
       const float4 v = prow[j];
       pa[2 * j] = h ? v.y : v.x;
       pa[2 * j + 1] = h ? v.w : v.z;
+    }
+  } else {
+    const float* prow = M.P + min(u0 + c31, U - 1) * M.D + koff;
+#pragma unroll
+    for (int i = 0; i < D / 2; ++i) {
+      const float v = prow[min(2 * i + h, kvalid - 1)];        // (the load itself is unconditional: a clamped index)
+      pa[i] = 2 * i + h < kvalid ? v : 0.f;
     }
   }
   const uint32_t obase = (uint32_t)((uintptr_t)out >> 2);
@@ -828,6 +840,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           __builtin_amdgcn_s_barrier();
           if (Tc + 2 * S < T1) dma(Tc + 2 * S, bpar);
         }
+        if (add) {                                               // second pass of an embedding size above 128 (rare: plain loads)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t row = u0 + (r & 3) + 8 * (r >> 2) + 4 * h, col = T * 32 + c31;
+            if (row < U && col < I) acc[r] += out[row * I + col];
+          }
+        }
         if (kind == 2) {
           // v / prc with one divisor per column: r = 1 / prc once, q = v r, one residual step q + (v - q prc) r (= the correctly rounded
           // quotient's own correction step): 3 packed instructions per 2 values on the pipe the fp32 MFMA shares with the vector ALU
@@ -864,20 +883,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 template <int D>
-static int launch_full_lines(const mf_model_t* M, float* out, hipStream_t st) {
+static int launch_full_lines(const mf_model_t* M, float* out, hipStream_t st, int koff, int kvalid, int kind, int add) {
   constexpr int S = 128 / D;
   const int64_t groups = (M->user_num + 127) / 128, gt = (M->item_num + 31) / 32;
   const int splits = 8;                       // = the XCDs: workgroups are dealt round-robin, XCD x only ever reads item range x
   ARG_CHECK(groups * splits < 2147483647LL, "matrix too large for one launch");
-  ARG_CHECK((uintptr_t)M->P % 16 == 0 && (uintptr_t)out % 4 == 0, "P must be 16-byte aligned, out 4-byte aligned");
+  ARG_CHECK((uintptr_t)out % 4 == 0, "out must be 4-byte aligned");
   const int64_t Tpad = gt + 2 * S;            // a chunk's DMA reads whole chunks
   float* QT4 = nullptr;
   HIP_TRY(hipMallocAsync((void**)&QT4, (size_t)Tpad * (D * 32 + 64) * sizeof(float), st));
   float* AUX = QT4 + Tpad * D * 32;
-  hipLaunchKernelGGL(k_full_lines_prep, dim3((unsigned)min((int64_t)4096, (Tpad * D * 32 + 255) / 256)), dim3(256), 0, st, *M, D, Tpad, QT4, AUX);
+  hipLaunchKernelGGL(k_full_lines_prep, dim3((unsigned)min((int64_t)4096, (Tpad * D * 32 + 255) / 256)), dim3(256), 0, st, *M, D, Tpad, QT4, AUX,
+                     koff, kvalid, kind);
   const size_t smem = (size_t)(2 * 4096 + 2 * S * 64 + 4 * 32 * 64) * sizeof(float);
   HIP_TRY(hipFuncSetAttribute((const void*)k_mf_full_lines<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  hipLaunchKernelGGL((k_mf_full_lines<D>), dim3((unsigned)(groups * splits)), dim3(256), smem, st, *M, out, QT4, AUX, splits);
+  hipLaunchKernelGGL((k_mf_full_lines<D>), dim3((unsigned)(groups * splits)), dim3(256), smem, st, *M, out, QT4, AUX, splits, koff, kvalid, kind, add);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipFreeAsync(QT4, st));
   return 0;
@@ -909,19 +929,26 @@ static int launch_full_rows(const mf_model_t* M, float* out, hipStream_t st) {
 
 extern "C" int mf_predict_full(const mf_model_t* M, float* out, void* stream) {
   ARG_CHECK(M && out, "NULL argument");
-  ARG_CHECK(M->P && M->Q && M->D >= 2 && M->D % 2 == 0 && M->D <= 128 && M->kind >= 0 && M->kind <= 2, "bad model");
+  ARG_CHECK(M->P && M->Q && M->D >= 1 && M->D <= 256 && M->kind >= 0 && M->kind <= 2, "bad model (embedding sizes up to 256)");
   ARG_CHECK(M->kind == 0 || (M->bu && M->bi && M->b0), "bias pointers missing");
   ARG_CHECK(M->kind != 2 || M->prop, "propensity missing");
   ARG_CHECK(M->user_num > 0 && M->item_num > 0, "empty matrix");
   const char* form = getenv("DCCF_FULL_FORM");
-  if (!(form && (!strcmp(form, "rows") || !strcmp(form, "band"))))
-    switch (M->D) {                            // the line form (round 3): profiles/r03_full_matrix_bench.json
-      case 16: return launch_full_lines<16>(M, out, (hipStream_t)stream);
-      case 32: return launch_full_lines<32>(M, out, (hipStream_t)stream);
-      case 64: return launch_full_lines<64>(M, out, (hipStream_t)stream);
-      case 128: return launch_full_lines<128>(M, out, (hipStream_t)stream);
-      default: break;
-    }
+  const bool old_form = form && (!strcmp(form, "rows") || !strcmp(form, "band") || !strcmp(form, "tile"));
+  if (!old_form || M->D > 128 || M->D % 2) {
+    // the line form (round 3: profiles/r03_full_matrix_bench.json) for EVERY embedding size (src/models/RecModel.py:17-27 accepts
+    // any): the contraction is padded with zeros to the kernel's next tile (16, 32, 64, 128); sizes above 128 run as two launches —
+    // the first writes the plain product of the columns [0, 128), the second continues it with the rest and applies the epilogue
+    auto pass = [&](int koff, int kvalid, int kind, int add) -> int {
+      if (kvalid <= 16) return launch_full_lines<16>(M, out, (hipStream_t)stream, koff, kvalid, kind, add);
+      if (kvalid <= 32) return launch_full_lines<32>(M, out, (hipStream_t)stream, koff, kvalid, kind, add);
+      if (kvalid <= 64) return launch_full_lines<64>(M, out, (hipStream_t)stream, koff, kvalid, kind, add);
+      return launch_full_lines<128>(M, out, (hipStream_t)stream, koff, kvalid, kind, add);
+    };
+    if (M->D <= 128) return pass(0, M->D, M->kind, 0);
+    if (int e = pass(0, 128, 0, 0)) return e;
+    return pass(128, M->D - 128, M->kind, 1);
+  }
   switch (M->D) {
     // forms per D as measured (CDs-shaped 75k x 64k, profiles/r02_full_matrix_bench.json): the row-band form (32 or 64 users
     // per workgroup, A operand in registers, tile-major Q^T, 1-KB row segments) for D <= 64: 5.1 / 6.0 / 9.1 ms at D = 16 /

@@ -299,7 +299,8 @@ int mf_train_fwdbwd(dccf_ctx* ctx, const mf_model_t* model, const int64_t* X, co
  * ids: unused (may be NULL; kept for ABI 5).  Results equal mf_train_fwdbwd + dccf_dense_opt_step_rows (untouched rows bit for bit). */
 int mf_train_step(dccf_ctx* ctx, const mf_model_t* model, const int64_t* X, const float* Y, int64_t N, int32_t rank,
                   const mf_grads_t* grads, const dccf_opt_t* opt, int32_t* ids, float* prediction, float* loss, void* stream);
-/* "save the full predicted user-item matrix as the exposure probability" (README.md:28-30): out [user_num, item_num]. */
+/* "save the full predicted user-item matrix as the exposure probability" (README.md:28-30): out [user_num, item_num], row-major,
+ * 4-byte aligned; any embedding size D <= 256 (the contraction is zero-padded to 16 / 32 / 64 / 128; above 128: two launches). */
 int mf_predict_full(const mf_model_t* model, float* out, void* stream);
 
 /* ---- fused on-device training negatives: replaces DataProcessor._sample_neg_from_uid_list for train=True, neg_n=1

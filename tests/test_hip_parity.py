@@ -358,13 +358,15 @@ def test_mf_family_matches_reference(L, ctx, kind):
 
 
 @pytest.mark.parametrize('form', ['lines', 'rows'])
-@pytest.mark.parametrize('D', [16, 32, 64, 128, 24])
+@pytest.mark.parametrize('D', [16, 32, 64, 128, 24, 100, 7, 1, 160, 255, 256])
 @pytest.mark.parametrize('kind', ['RecModel', 'BiasedMF', 'IPSBiasedMF'])
 def test_mf_full_matrix_every_kernel_form_ragged_sizes(L, D, kind, form, monkeypatch):
     """mf_predict_full for every D-specific kernel form (the line form of round 3 and, with DCCF_FULL_FORM=rows, round 2's row-band
     form for D = 16 / 32 / 64 / 128; the generic tile for 24) at sizes that are multiples of nothing (user bands, 32-, 64- and 256-item
     tiles all end ragged) against the formula in fp64 (src/models/IPSBiasedMF.py:37-57: (P Q^T + bu + bi + b0) / max(prop, M))."""
     if form == 'rows':
+        if D > 128 or D % 2:
+            pytest.skip('the older forms cover even sizes up to 128')
         monkeypatch.setenv('DCCF_FULL_FORM', 'rows')
     else:
         monkeypatch.delenv('DCCF_FULL_FORM', raising=False)
@@ -383,7 +385,7 @@ def test_mf_full_matrix_every_kernel_form_ragged_sizes(L, D, kind, form, monkeyp
     if kind == 'IPSBiasedMF':
         ref = ref / torch.clamp(prop.double(), min=0.3)[None, :]
     assert bool(torch.isfinite(out[:U]).all()) and bool(torch.isnan(out[U]).all())
-    close(out[:U], ref.cpu().numpy(), 2e-6, 1e-6, 'full matrix D=%d %s' % (D, kind))
+    close(out[:U], ref.cpu().numpy(), 2e-6, 1e-6 if D <= 128 else 2e-6, 'full matrix D=%d %s' % (D, kind))
 
 
 @pytest.mark.parametrize('U,I,off', [(1, 1, 0), (5, 31, 3), (33, 32, 1), (130, 64, 7), (31, 257, 31), (64, 1000, 13), (257, 4101, 2),
