@@ -24,9 +24,9 @@ def run_cli(tmp, argv):
         os.chdir(cwd)
 
 
-def _cli_vs_reference(tmp, g, check_artefacts, extra_seeds=0):
-    """Runs the CLI mirror once per reference seed (+ `extra_seeds` more of its own: a run costs about a second here, the
-    reference's costs half an hour) on the golden's dataset; asserts the seed-averaged validation NDCG@5 of every epoch and of the
+def _cli_vs_reference(tmp, g, check_artefacts, extra_seeds=0, max_runs=160):
+    """Runs the CLI mirror once per reference seed (+ `extra_seeds` more of its own, at most `max_runs` in all: a run costs about a
+    second here, the reference's costs half an hour) on the golden's dataset; asserts the seed-averaged validation NDCG@5 of every epoch and of the
     untrained model within 2 standard errors (of the difference of the two seed means, sample variances, no floor) + 1e-3 — the
     north_star's tolerance — of the reference's own runs.  What moves the mean and what does not was measured arm by arm:
     profiles/r02_e2e_ab.md, profiles/r03_e2e_ab.md."""
@@ -37,7 +37,7 @@ def _cli_vs_reference(tmp, g, check_artefacts, extra_seeds=0):
     ref_valid = np.stack([g['seed%d/valid' % s][:, 0] for s in seeds])         # [seeds, epochs] ndcg@5
     ref_init = np.array([g['seed%d/init_valid' % s][0] for s in seeds])
     mine, mine_init = [], []
-    for seed in seeds + [max(seeds) + 1 + k for k in range(extra_seeds)]:
+    for seed in (seeds + [max(seeds) + 1 + k for k in range(extra_seeds)])[:max_runs]:
         runner = run_cli(tmp, ['--rank', '1', '--model_name', 'DCCF', '--optimizer', 'Adam', '--lr', str(float(g['lr'])),
                                '--dataset', 'toy', '--path', '../dataset/', '--metric', 'ndcg@5,recall@5,precision@5',
                                '--epoch', str(int(g['epochs'])), '--test_neg_n', str(int(g['test_neg_n'])),
@@ -75,7 +75,7 @@ def _cli_vs_reference(tmp, g, check_artefacts, extra_seeds=0):
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(GOLDEN, 'e2e.npz')), reason='e2e golden not generated')
 def test_cli_training_matches_reference_statistically(tmp_path):
-    """800 users x 600 items, D = 32, F = 64, 4 epochs: 41 runs of the reference's own main.py (tests/golden/e2e.npz)."""
+    """800 users x 600 items, D = 32, F = 64, 4 epochs: 240 runs of the reference's own main.py (tests/golden/e2e.npz)."""
     _cli_vs_reference(str(tmp_path), load_golden('e2e'), check_artefacts=True)
 
 
@@ -84,7 +84,7 @@ def test_cli_training_matches_reference_on_config1_shape(tmp_path):
     """BASELINE.json configs[0] / SURVEY.md section 8d C1: 5,000 users x 5,000 items, D = 16, F = 768 (the k_noise_fwd<16, ., 6> /
     k_bwd<16, .> instances), 3 epochs, --test_neg_n 100: the reference's own main.py runs of tests/golden/e2e_c1.npz."""
     g = load_golden('e2e_c1')
-    _cli_vs_reference(str(tmp_path), g, check_artefacts=False, extra_seeds=len(g['seeds']))
+    _cli_vs_reference(str(tmp_path), g, check_artefacts=False, extra_seeds=len(g['seeds']), max_runs=100)
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(GOLDEN, 'e2e_c1_init.npz')), reason='config-1 untrained-model golden not generated')
