@@ -65,10 +65,16 @@ def main():
     print('\n`default` = Philox evaluation negatives + device metric code; `host_all` = `--fused_sampling 0 --device_eval 0` (the reference\'s numpy\n'
           'sampling and host metric code); `torch_draws` = noise / dropout from torch\'s generator through the injected kernel path.  Round 2\'s\n'
           '+0.0013 (11 reference seeds against 24) does not survive 100 seeds per side: no arm is further than 1e-4 … 1.2e-4 from the reference.\n')
-    table('Small config (800 × 600, D = 32, F = 64, 4 epochs)', 'e2e', 'r03_e2e_ab_small_120seeds.json', ['default', 'torch_perm'])
+    table('Small config (800 × 600, D = 32, F = 64, 4 epochs)', 'e2e', 'r03_e2e_ab_small_240seeds.json', ['default', 'host_sampling'])
+    d = json.load(open(os.path.join(REPO, 'profiles', 'r03_e2e_ab_small_240seeds.json')))
+    print('PAIRED over the 240 common seeds (`host_sampling` = `--fused_sampling 0`: the reference\'s own batches and evaluation negatives per seed, only\n'
+          'the noise and dropout draws differ): mean difference per epoch ' + ' / '.join('%+.4f ± %.4f' % (m, e) for m, e in
+          zip(d['host_sampling']['paired']['mean_diff'], d['host_sampling']['paired']['se_diff'])) + '.\n')
+    table('Small config, first 120 seeds of this build: the epoch permutation arm', 'e2e', 'r03_e2e_ab_small_120seeds.json', ['default', 'torch_perm'])
     print('`torch_perm` = the epoch permutation by `torch.randperm` instead of the keyed Feistel bijection of `k_epoch_batches` (ADVICE r2): the\n'
-          'same means, so the residual at epoch 1 is not the permutation.  Epoch 1 is the steep part of the curve on this 1.2 k-user validation set\n'
-          '(per-seed std 0.010–0.011); the reference\'s own first 41 and later 79 seeds differ by 0.0028 there.\n')
+          'same means as `default` on the same seeds, so the permutation moves nothing.  Epoch 1 is the steep part of the curve on this 1.2 k-user\n'
+          'validation set (per-seed std 0.010–0.011): the reference\'s own first and second 120 seeds read 0.0555 and 0.0575 there, and what looked\n'
+          'like +0.0034 at 2.4 se with 120 seeds per side (+0.0053 with 41 in round 2) is +0.0022 with 240, +0.0010 ± 0.0010 paired.\n')
 
 
 if __name__ == '__main__':
