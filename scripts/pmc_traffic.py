@@ -45,7 +45,8 @@ def collect(counter, outdir):
         name = re.match(r'(?:void )?([\w:]+)', full).group(1)
         # bench.py also runs the optimizer kernel on a 3.2 GB buffer (roofline.frac_beyond_llc): a one-segment instance, kept apart
         # (since round 3: the non-temporal, one-slot-per-thread instance <KIND, 1, false, true>; round 2: <KIND, 2, ...>)
-        if name == 'k_dense_opt_rows' and re.search(r'k_dense_opt_rows<\d+, (2,|\d+, (false|true|0|1), (true|1)>)', full):
+        # (template arguments <KIND, UN, TO, NT[, GW]>)
+        if name == 'k_dense_opt_rows' and re.search(r'k_dense_opt_rows<\d+, (2,|\d+, (false|true|0|1), (true|1)[,>])', full):
             name = 'k_dense_opt_rows_beyond_llc'
         a = acc.setdefault(name, [0.0, 0])
         a[0] += float(r['Counter_Value'])
