@@ -704,7 +704,7 @@ __global__ __launch_bounds__(256) void k_full_lines_prep(mf_model_t M, int D, in
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Line form, D in {16, 32, 64, 128}.  A workgroup is 4 waves = 4 bands of 32 users (A operand register-resident) that multiply the SAME
+// Line form; D = the contraction's tile, 16 / 32 / 64 / 128 (the model's embedding size is padded to it: koff / kvalid).  A workgroup is 4 waves = 4 bands of 32 users (A operand register-resident) that multiply the SAME
 // tiles of 32 items: the tiles arrive 16 KB at a time (128 / D of them) by LDS-DMA (global_load_lds_dwordx4: no registers, no address
 // arithmetic per k-step, 4 wave-instructions per wave and 16 KB instead of D / 2 dword loads per wave and TILE), two buffers, one barrier
 // per 16 KB; the L2 -> CU traffic of Q^T is a quarter of k_mf_full_rows's, where every wave fetched its own operand.  blockIdx & 7

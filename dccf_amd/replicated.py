@@ -449,6 +449,21 @@ def bench_main(args, rank, world, dev):
                                           'algorithmic_GB': round(24.0 * n_params / 1e9, 4), 'avg_launch_ms': round(adam_ms, 5),
                                           'note': 'cache-assisted (p + m + v fit the Infinity Cache); not a launch of the default '
                                                   '(lazy) step'}}
+    # the step's collective ALONE (diagnostic, outside the timed region, every rank takes part): n_ag all-gathers of the exchange buffer
+    # back to back on an idle GPU — what the step has to hide behind its first optimizer phase (a device copy at world size 1)
+    n_ag = 20
+    dist.barrier()
+    torch.cuda.synchronize()
+    ag0, ag1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ag0.record()
+    for _ in range(n_ag):
+        if world > 1 or _FORCE_COLLECTIVE:
+            dist.all_gather_into_tensor(tr.bufs, tr.buf, group=tr.group)
+        else:
+            tr.bufs.copy_(tr.buf)
+    ag1.record()
+    torch.cuda.synchronize()
+    ag_us = ag0.elapsed_time(ag1) / n_ag * 1e3
     if rank == 0:
         out = {'metric': 'train pairs/sec at rank=64 Electronics', 'value': round(args.steps * B * world / dt, 1),
                'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -463,7 +478,9 @@ def bench_main(args, rank, world, dev):
                           'batch_size_per_gpu': B, 'global_batch': B * world, 'optimizer': 'Adam lr=1e-3 l2=1e-4 dropout=0.2',
                           'collectives_per_step': 'all_gather x1 (touched gradient rows + [dW|db], %.2f MB per rank)'
                                                   % (tr.words * 4 / 1e6),
-                          'collectives': tr.collectives, 'replicas_agreed_after_warmup': bool(agreed_after_warmup),
+                          'collectives': tr.collectives, 'all_gather_alone_us': round(ag_us, 2),
+                          'step_kernels_us': {'noise_fwd': round(fwd_ms * 1e3, 2), 'k_bwd': round(bwd_ms * 1e3, 2)},
+                          'replicas_agreed_after_warmup': bool(agreed_after_warmup),
                           'replicas_bit_identical': bool(torch.equal(lo, hi))},
                'roofline': roofline, 'cpu_baseline': None}
         import bench
