@@ -327,13 +327,24 @@ __device__ __forceinline__ void lazy_window_pass(float* __restrict__ p, float* _
       bool live;
       float4 pv, av, bv;
     };
+    // slot -> (row, float4 of the row): a shift for the usual widths, a 32-bit division otherwise (a window has far fewer than 2^32 slots; the
+    // compiler's 64-bit division is ~60 vector instructions per slot on the pipe this loop is bound by)
+    const bool small = nslot < (int64_t)4294967295LL;
+    const int w4sh = (w4 & (w4 - 1)) == 0 ? 31 - __clz(w4) : -1;
     auto fetch = [&](int64_t x0, Slot& f) {
       const int64_t x = x0 + threadIdx.x;
       f.live = x < nslot;
       const int64_t xc = f.live ? x : nslot - 1;
-      const int64_t row = r0 + xc / w4;
+      int64_t rw;
+      if (small) {
+        const uint32_t x32 = (uint32_t)xc;
+        rw = w4sh >= 0 ? (int64_t)(x32 >> w4sh) : (int64_t)(x32 / (uint32_t)w4);
+      } else {
+        rw = xc / w4;
+      }
+      const int64_t row = r0 + rw;
       f.grow = z.row_off[q] + row;
-      f.i = (sg.begin[q] >> 2) + row * w4 + xc % w4;
+      f.i = (sg.begin[q] >> 2) + r0 * w4 + xc;
       f.last = z.last[f.grow];
       f.claim = claim[f.grow];
       f.pv = reinterpret_cast<const float4*>(p)[f.i];
