@@ -719,7 +719,7 @@ template <int D>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_mf_full_lines(mf_model_t M, float* __restrict__ out,
                                                                                                      const float* __restrict__ QT4,
                                                                                                      const float* __restrict__ AUX, int splits,
-                                                                                                     int koff, int kvalid, int kind, int add) {
+                                                                                                     int koff, int kvalid, int kind, int add, int splitbar) {
   // koff / kvalid: this launch contracts the model's columns [koff, koff + kvalid) (kvalid <= D: the rest of the tile is zero);
   // kind: the epilogue of THIS launch (0: none); add: the contraction continues the partial product already in `out`
   constexpr int S = 128 / D, TILE = D * 32, CHUNK = S * TILE, NQ = D / 8, CW = 64;           // CHUNK = 4096 floats = 16 KB
@@ -727,6 +727,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   extern __shared__ __attribute__((aligned(128))) float sm[];   // [2][CHUNK] operand | [2][S][64] epilogue operands | [4][32][CW] windows
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = lane >> 5, c31 = lane & 31;
+  int* const bar = reinterpret_cast<int*>(sm + 2 * CHUNK + 2 * S * 64 + 4 * 32 * CW);      // splitbar: arrivals counter
+  if (splitbar && threadIdx.x == 0) *bar = 0;
+  int arrivals = 0;
   float* const Ax = sm + 2 * CHUNK;
   float* const Cw = sm + 2 * CHUNK + 2 * S * 64 + wave * 32 * CW;
   const int64_t I = M.item_num, U = M.user_num;
@@ -837,8 +840,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           // the chunk's operand is consumed: when every wave is here its buffer is free for the chunk after the next, and the next
           // chunk (in flight since the previous barrier) has landed.  The stores this wait also covers were issued a tile ago.
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();
-          if (Tc + 2 * S < T1) dma(Tc + 2 * S, bpar);
+          if (!splitbar) {
+            __builtin_amdgcn_s_barrier();
+            if (Tc + 2 * S < T1) dma(Tc + 2 * S, bpar);
+          } else {
+            // split barrier: ARRIVE here (this wave is done with the chunk's operand and its pieces of the next chunk are in LDS), WAIT
+            // after the tile's epilogue — the waves of a workgroup no longer stand at the barrier while they have an epilogue to do
+            if (lane == 0) __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            arrivals += 4;
+          }
         }
         if (add) {                                               // second pass of an embedding size above 128 (rare: plain loads)
 #pragma unroll
@@ -870,6 +880,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int r = 0; r < 16; ++r) *reinterpret_cast<__attribute__((address_space(3))) float*>(wadr[wp][r]) = acc[r];
         const int64_t cT = T * 32;
         emit(wp * 32, cT, !(rows_full && T > T0 && cT + 32 <= colmax));
+        if (splitbar && (s == S - 1 || T + 1 >= T1)) {
+          while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < arrivals) __builtin_amdgcn_s_sleep(1);
+          if (Tc + 2 * S < T1) dma(Tc + 2 * S, bpar);
+        }
       }
     }
   };
@@ -895,9 +909,11 @@ static int launch_full_lines(const mf_model_t* M, float* out, hipStream_t st, in
   float* AUX = QT4 + Tpad * D * 32;
   hipLaunchKernelGGL(k_full_lines_prep, dim3((unsigned)min((int64_t)4096, (Tpad * D * 32 + 255) / 256)), dim3(256), 0, st, *M, D, Tpad, QT4, AUX,
                      koff, kvalid, kind);
-  const size_t smem = (size_t)(2 * 4096 + 2 * S * 64 + 4 * 32 * 64) * sizeof(float);
+  const size_t smem = (size_t)(2 * 4096 + 2 * S * 64 + 4 * 32 * 64 + 4) * sizeof(float);
+  // (measured, 75 k x 64 k: D = 32 5.07 -> 4.82 ms, 64 7.18 -> 7.03, 128 11.47 -> 11.32, 16 4.30 -> 4.38: on from 32)
+  const int splitbar = getenv("DCCF_FULL_SPLITBAR") ? atoi(getenv("DCCF_FULL_SPLITBAR")) : (D >= 32 ? 1 : 0);
   HIP_TRY(hipFuncSetAttribute((const void*)k_mf_full_lines<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  hipLaunchKernelGGL((k_mf_full_lines<D>), dim3((unsigned)(groups * splits)), dim3(256), smem, st, *M, out, QT4, AUX, splits, koff, kvalid, kind, add);
+  hipLaunchKernelGGL((k_mf_full_lines<D>), dim3((unsigned)(groups * splits)), dim3(256), smem, st, *M, out, QT4, AUX, splits, koff, kvalid, kind, add, splitbar);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipFreeAsync(QT4, st));
   return 0;
