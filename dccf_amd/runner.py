@@ -416,6 +416,25 @@ class BaseRunner(object):
         model.eval()
         if hasattr(model, 'begin_eval'):
             model.begin_eval()
+        world, rank = utils.dist_world_rank()
+        if world > 1 and os.environ.get('DCCF_SHARD_EVAL', '1') != '0' and hasattr(model, '_call'):
+            # Under a multi-rank launch the replicas hold identical parameters: the evaluation batches are dealt to the ranks round
+            # robin and ONE sum-all-reduce (every other rank contributes zeros: exact) gives every rank every prediction.  Batch b
+            # draws with the Philox step the single-process loop would have given it (the model's call counter), so the predictions —
+            # and the metrics every rank then computes for itself — are bit for bit those of the unsharded pass.
+            import torch.distributed as dist
+            p = torch.zeros(es.n, dtype=torch.float32, device=es.Y.device)
+            c0, nb, bs = model._call, 0, self.eval_batch_size
+            for b, batch in enumerate(es.batches(bs, self.no_dropout)):
+                nb = b + 1
+                if b % world != rank:
+                    continue
+                model._call = c0 + b
+                p[b * bs:b * bs + batch['X'].shape[0]] = model.predict(batch)['prediction']
+            model._call = c0 + nb
+            if es.n:
+                dist.all_reduce(p)
+            return p
         preds = [model.predict(b)['prediction'] for b in es.batches(self.eval_batch_size, self.no_dropout)]
         return torch.cat(preds) if preds else torch.zeros(0, dtype=torch.float32, device=es.Y.device)
 

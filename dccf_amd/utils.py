@@ -84,6 +84,14 @@ def is_rank0():
     return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
 
 
+def dist_world_rank():
+    """(world size, rank) of the process group, (1, 0) without one."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank()
+    return 1, 0
+
+
 def barrier():
     """No-op in a single-process run; with several ranks: all of them have reached this point (a file rank 0 wrote is there)."""
     import torch.distributed as dist

@@ -401,6 +401,7 @@ def _cli_rank_main(rank, world, port, tmp, cfg):
     sets, gloo as the transport: both ranks share this box's one GPU), once per seed."""
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
                       WORLD_SIZE=str(world), DCCF_DIST_BACKEND='gloo')
+    os.environ.update(cfg.get('env', {}))
     from dccf_amd import main as M
     os.makedirs(os.path.join(tmp, 'src'), exist_ok=True)
     os.chdir(os.path.join(tmp, 'src'))
@@ -493,3 +494,28 @@ def test_cli_on_two_ranks_extra_layers_adagrad(tmp_path, layout, D):
     assert len(sd) == 6
     # the extra layer was trained: N(0, 0.01) at the start, Adagrad's first steps move every touched element by ~lr
     assert np.abs(r0['mlp.1.weight']).max() > 0.02 and np.isfinite(r0['valid']).all()
+
+
+def test_cli_two_ranks_sharded_evaluation_equals_unsharded(tmp_path):
+    """Under a multi-rank launch the evaluation batches are dealt to the ranks and the predictions meet in one sum-all-reduce
+    (runner.predict_device); every batch keeps the Philox step the single-process loop gives it, so the metrics of every epoch, the
+    untrained model's and the call counter equal those of the run in which every rank evaluates everything (DCCF_SHARD_EVAL=0).  (src/runners/BaseRunner.py:134-157, 305-332 evaluate on one device.)"""
+    import torch.multiprocessing as mp
+    from dccf_amd import synth
+    from conftest import free_port
+    res = {}
+    for mode in ('1', '0'):
+        tmp = os.path.join(str(tmp_path), 'm' + mode)
+        synth.write_dataset(os.path.join(tmp, 'dataset'), 'toy', 300, 200, 5000, feat_dim=32, seed=3)
+        cfg = dict(lr=0.01, epochs=2, test_neg_n=50, D=16, batch_size=96, seeds=[7], optimizer='Adam', more=[], env={'DCCF_SHARD_EVAL': mode})
+        mp.spawn(_cli_rank_main, args=(2, free_port(), tmp, cfg), nprocs=2, join=True)
+        r0, r1 = (dict(np.load(os.path.join(tmp, 'cli%d.npz' % r))) for r in range(2))
+        for k in r0:
+            assert np.array_equal(r0[k], r1[k], equal_nan=True), (mode, k)
+        res[mode] = r0
+    # the untrained model's metrics are a pure evaluation: bit for bit; so are the step and Philox counters.  After training the two
+    # RUNS differ in the last bits of their parameters (float atomics order the gradient sums inside every rank's backward: two runs
+    # of the same command never agree bit for bit, sharded evaluation or not), so the epochs' metrics are compared to 1e-4.
+    assert np.array_equal(res['1']['init'], res['0']['init']) and res['1']['call'] == res['0']['call'] and res['1']['t'] == res['0']['t']
+    assert np.abs(res['1']['valid'] - res['0']['valid']).max() < 1e-4
+    assert np.isfinite(res['1']['valid']).all() and res['1']['valid'].shape[1] == 2
