@@ -48,7 +48,7 @@ def main():
           'the committed goldens (`tests/golden/make_golden.py e2e` / `e2e_init` in the build container; a config-1 run of the reference costs\n'
           '≈ 33 minutes on one core).  ± = standard error of the seed mean; "Δ / se" uses the standard error of the DIFFERENCE of the two\n'
           'means.  Written by `python scripts/e2e_table.py`.\n')
-    table('BASELINE config 1 (5,000 × 5,000, D = 16, F = 768, 3 epochs, `--test_neg_n 100`)', 'e2e_c1', 'r03_e2e_ab_c1_128seeds.json', ['default'])
+    table('BASELINE config 1 (5,000 × 5,000, D = 16, F = 768, 3 epochs, `--test_neg_n 100`)', 'e2e_c1', 'r03_e2e_ab_c1_256seeds.json', ['default'])
     table('Config 1, first 64 seeds of this build: host sampling + host metric code', 'e2e_c1', 'r03_e2e_ab_c1_64seeds.json', ['default', 'host_all'])
     g = dict(np.load(os.path.join(REPO, 'tests', 'golden', 'e2e_c1_init.npz')))
     ref = g['init_valid'][:, 0].astype(np.float64)
