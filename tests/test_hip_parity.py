@@ -412,6 +412,42 @@ def test_mf_full_matrix_line_form_edges(L, D, U, I, off, monkeypatch):
     close(out, ref.cpu().numpy(), 2e-6, 1e-6, 'full matrix D=%d %dx%d +%d' % (D, U, I, off))
 
 
+@pytest.mark.parametrize('D', [64, 128])
+def test_mf_full_matrix_at_config4_size_properties(L, D):
+    """BASELINE config 4 at its full size (CDs-and-Vinyl-shaped 75,258 x 64,443 = 19.4 GB; README.md:28-30), where no dense reference
+    fits a test: (1) two million random entries + the matrix's four corners equal the PAIRWISE predict of the same model
+    (mf_predict: src/models/IPSBiasedMF.py:37-57 on (u, i) rows) to fp32 rounding of two summation orders; (2) linearity — for the plain
+    dot product the row sums equal P (sum_i Q_i) and the column sums (sum_u P_u) Q^T, accumulated in fp64; (3) the guard floats before
+    and after the matrix are untouched."""
+    U, I = 75258, 64443
+    g = torch.Generator(device='cuda').manual_seed(D)
+    P, Q = torch.randn(U, D, generator=g, device='cuda') * 0.1, torch.randn(I, D, generator=g, device='cuda') * 0.1
+    bu, bi = torch.randn(U, generator=g, device='cuda') * 0.1, torch.randn(I, generator=g, device='cuda') * 0.1
+    prop = torch.rand(I, generator=g, device='cuda')
+    b0 = torch.full((1,), 0.1, device='cuda')
+    flat = torch.full((64 + U * I + 64,), float('nan'), device='cuda')
+    out = flat[64:64 + U * I].view(U, I)
+    m = L.mf_struct('IPSBiasedMF', P, Q, bu, bi, b0, prop, 0.1)
+    L.mf_predict_full(m, out=out)
+    X = torch.stack([torch.randint(0, U, (2000000,), generator=g, device='cuda'), torch.randint(0, I, (2000000,), generator=g, device='cuda')], 1)
+    X[:4] = torch.tensor([[0, 0], [0, I - 1], [U - 1, 0], [U - 1, I - 1]], device='cuda')
+    pair = L.mf_predict(m, X.contiguous())
+    got = out[X[:, 0], X[:, 1]]
+    assert bool(torch.isfinite(got).all())
+    err = (got - pair).abs() / (1.0 + pair.abs())
+    assert float(err.max()) < 3e-6, float(err.max())
+    assert bool(torch.isnan(flat[:64]).all()) and bool(torch.isnan(flat[-64:]).all())
+    # linearity of the bare product
+    m0 = L.mf_struct('RecModel', P, Q, bu, bi, b0, prop, 0.1)
+    L.mf_predict_full(m0, out=out)
+    rows = out.sum(1, dtype=torch.float64)
+    cols = out.sum(0, dtype=torch.float64)
+    ref_r = P.double() @ Q.double().sum(0)
+    ref_c = Q.double() @ P.double().sum(0)
+    assert float((rows - ref_r).abs().max()) < 2e-3 and float((cols - ref_c).abs().max()) < 2e-3      # sums of 6e4 .. 8e4 fp32 values
+    assert bool(torch.isnan(flat[:64]).all()) and bool(torch.isnan(flat[-64:]).all())
+
+
 def test_mf_train_mse_and_duplicates_vs_oracle(L, ctx):
     """rank==0 (MSE) and a batch full of duplicate users/items (exercises the LDS duplicate-row chains)."""
     rng = np.random.RandomState(8)
