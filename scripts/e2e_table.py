@@ -50,6 +50,8 @@ def main():
           'means.  Written by `python scripts/e2e_table.py`.\n')
     table('BASELINE config 1 (5,000 × 5,000, D = 16, F = 768, 3 epochs, `--test_neg_n 100`)', 'e2e_c1', 'r03_e2e_ab_c1_256seeds.json', ['default'])
     table('Config 1, first 64 seeds of this build: host sampling + host metric code', 'e2e_c1', 'r03_e2e_ab_c1_64seeds.json', ['default', 'host_all'])
+    table('Config 1, first 128 seeds, `--eval_noise projected` (the evaluation draws the D-dimensional projected noise: same distribution)', 'e2e_c1',
+          'r03_e2e_ab_c1_projected_128seeds.json', ['projected'])
     g = dict(np.load(os.path.join(REPO, 'tests', 'golden', 'e2e_c1_init.npz')))
     ref = g['init_valid'][:, 0].astype(np.float64)
     d = json.load(open(os.path.join(REPO, 'profiles', 'r03_e2e_init_ab_c1.json')))
