@@ -138,3 +138,11 @@ def test_init_distributed_refuses_fewer_gpus_than_local_ranks(monkeypatch):
     assert torch.cuda.device_count() < 64
     with pytest.raises(RuntimeError, match='one GPU per rank'):
         utils.init_distributed()
+
+
+def test_dist_world_rank_without_a_process_group():
+    """utils.dist_world_rank (what the sharded evaluation of runner.predict_device deals its batches by): (1, 0) in a
+    single-process run — the reference's evaluate (src/runners/BaseRunner.py:134-157) is single-process."""
+    from dccf_amd import utils
+    assert utils.dist_world_rank() == (1, 0)
+    assert utils.is_rank0()
